@@ -1,0 +1,205 @@
+/*
+ * srx.h -- C ABI of the MI355X (gfx950) SRGAN/ESRGAN hot-path library `libsrx_hip.so`.
+ *
+ * This is the drop-in boundary (level 2).  The reference
+ * (roclark/torchsr) has no FFI of its own: every FLOP of its hot path is issued
+ * through `torch.nn` modules.  Each entry point below therefore cites the
+ * reference construct (file:line under /root/reference) whose device work it
+ * replaces.  The Python host (`torchsr_amd/`) binds these with ctypes and wraps
+ * them in `torch.autograd.Function`s behind the reference's own
+ * `Generator` / `Discriminator` / `VGGLoss` / trainer surface.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch / HIP types in signatures
+ *    (`stream` is a `hipStream_t` passed as `void*`; NULL = default stream).
+ *  - all tensors are fp32, activations are NHWC ([N][H][W][C_s]) with a channel
+ *    stride C_s that is a multiple of 4 (3-channel images are stored with C_s=4,
+ *    4th channel zero).  Parameters stay in the reference's own layouts
+ *    (Conv2d OIHW, Linear [out][in]) so `state_dict()` is byte compatible;
+ *    MFMA-friendly packed copies are produced by `srx_conv2d_pack`.
+ *  - every call is asynchronous on `stream`, allocates nothing, never
+ *    synchronises and is hipGraph-capture safe.  Scratch memory is handed in by
+ *    the caller (`*_ws_floats` queries say how much).
+ *  - return value: 0 = ok, otherwise an SRX_E_* code; a thread-local message is
+ *    available through `srx_last_error`.
+ *  - re-entrant: no mutable global state except kernel attributes set once.
+ */
+#ifndef SRX_H
+#define SRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRX_VERSION 100 /* 0.1.0, mirrors torchsr/__version__.py:13 */
+
+enum {
+  SRX_OK = 0,
+  SRX_E_BADARG = 1,      /* shape / alignment / null pointer problem */
+  SRX_E_UNSUPPORTED = 2, /* configuration outside what the kernels implement */
+  SRX_E_HIP = 3,         /* a HIP runtime call failed */
+  SRX_E_WORKSPACE = 4    /* workspace too small */
+};
+
+enum { SRX_ACT_NONE = 0, SRX_ACT_RELU = 1, SRX_ACT_LRELU = 2, SRX_ACT_PRELU = 3 };
+
+int srx_version(void);
+/* copies the calling thread's last error message (NUL terminated) into buf */
+int srx_last_error(char* buf, size_t n);
+/* number of compute units of the current device (used by the host for launch heuristics) */
+int srx_device_cus(void);
+
+/* ------------------------------------------------------------------ layout */
+/* NCHW [N][C][H][W] -> NHWC [N][H][W][Cs] (channels C..Cs-1 written as 0).
+ * Replaces the implicit NCHW contract of every reference module's forward
+ * (srgan/generator.py:60, srgan/discriminator.py:71, srgan/loss.py:36). */
+int srx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int Cs, void* stream);
+/* NHWC [N][H][W][Cs] -> NCHW [N][C][H][W]; also `torch.flatten(out, 1)` in NCHW
+ * order for the discriminator head (srgan/discriminator.py:86). */
+int srx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int Cs, void* stream);
+
+/* ------------------------------------------------------------------ conv2d */
+/* One nn.Conv2d instance: srgan/residual.py:27,64,67; srgan/generator.py:38,48,58;
+ * srgan/discriminator.py:32-59; torchvision VGG19 cfg 'E' (srgan/loss.py:30-31);
+ * esrgan/residual.py:31-56; esrgan/generator.py:36-52. */
+typedef struct srx_conv2d {
+  int32_t N, H, W;    /* input batch / spatial size */
+  int32_t Cin;        /* Conv2d.in_channels  */
+  int32_t Cin_s;      /* channel stride of the input tensor  (>= Cin, multiple of 4) */
+  int32_t Cout;       /* Conv2d.out_channels */
+  int32_t Cout_s;     /* channel stride of the output tensor (>= Cout, multiple of 4);
+                         with shuffle=2 this is the stride of the shuffled tensor (>= Cout/4) */
+  int32_t KH, KW, stride, pad;
+  int32_t shuffle;    /* 0, or 2: nn.PixelShuffle(2) fused into the store
+                         (srgan/residual.py:28): output is [N][2Ho][2Wo][Cout/4] */
+  int32_t act;        /* fused epilogue: SRX_ACT_NONE / RELU / LRELU (after bias) */
+  float   slope;      /* LeakyReLU negative_slope */
+  int32_t up;         /* 0/1, or 2: F.interpolate(scale_factor=2, mode='nearest') of the
+                         input fused into the gather (esrgan/generator.py:73,76); H,W are
+                         then the size of the tensor BEFORE upsampling */
+} srx_conv2d_t;
+
+/* sizes (in floats) of the packed weight copies and of scratch buffers */
+size_t srx_conv2d_packed_fwd_floats(const srx_conv2d_t* d);
+size_t srx_conv2d_packed_bwd_floats(const srx_conv2d_t* d);
+size_t srx_conv2d_fwd_ws_floats(const srx_conv2d_t* d);
+size_t srx_conv2d_bwd_data_ws_floats(const srx_conv2d_t* d);
+size_t srx_conv2d_bwd_weight_ws_floats(const srx_conv2d_t* d);
+/* rows of the per-channel (sum, sum of squares) partial table written by
+ * srx_conv2d_fwd when `bn_partials` is non-NULL: table is [rows][Cout][2] */
+int srx_conv2d_stat_rows(const srx_conv2d_t* d);
+
+/* OIHW master weights -> packed forward ([Cout_p][K_p], K=(kh,kw,ci)) and, when
+ * wpk_bwd != NULL, packed data-gradient operands (per stride-parity class,
+ * taps flipped, [Cin_p][K'_p], K'=(tap,co)). */
+int srx_conv2d_pack(const srx_conv2d_t* d, const float* w_oihw, float* wpk_fwd, float* wpk_bwd, void* stream);
+
+/* y = act(conv(x, W) + bias).  bias may be NULL.  bn_partials may be NULL; when
+ * given it receives per-row-block sums for the training-mode BatchNorm that
+ * follows (srgan/residual.py:65,68; srgan/discriminator.py:36-60). */
+int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float* wpk_fwd, const float* bias,
+                   float* y, float* bn_partials, float* ws, size_t ws_floats, void* stream);
+/* dx = conv_transpose(dy, W)  (autograd of nn.Conv2d wrt its input) */
+int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
+                        float* ws, size_t ws_floats, void* stream);
+/* dw (OIHW, overwritten) = autograd of nn.Conv2d wrt its weight */
+int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, const float* dy, float* dw_oihw,
+                          float* ws, size_t ws_floats, void* stream);
+
+/* ------------------------------------------------- elementwise / reductions */
+/* out[c] = sum_m x[m][c]  (bias gradient of Conv2d / Linear); ws >= 2*rows*C floats */
+size_t srx_colsum_ws_floats(int64_t M, int C);
+int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, float* ws, size_t ws_floats, void* stream);
+/* dx = dy * act'(y) for sign-recoverable activations fused into a conv epilogue (ReLU, LeakyReLU) */
+int srx_act_bwd_from_out(const float* dy, const float* y, float* dx, int64_t n, int act, float slope, void* stream);
+/* nn.PReLU (one shared slope): srgan/generator.py:39, srgan/residual.py:29,66 */
+int srx_prelu_fwd(const float* x, const float* slope, float* y, int64_t n, void* stream);
+/* dx and d(slope); ws >= 1024 floats */
+int srx_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx, float* dslope,
+                  int64_t n, float* ws, void* stream);
+/* nn.LeakyReLU as a standalone op (ESRGAN, esrgan/residual.py:36-55) */
+int srx_lrelu_fwd(const float* x, float* y, int64_t n, float slope, void* stream);
+/* y = a*x + b*z  (residual scaling of esrgan/residual.py:86,128; torch.add of srgan/generator.py:78) */
+int srx_axpby(const float* x, const float* z, float* y, int64_t n, float a, float b, void* stream);
+/* nn.Sigmoid of the SRGAN discriminator head (srgan/discriminator.py:68) */
+int srx_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream);
+int srx_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+
+/* -------------------------------------------------------------- batch norm */
+/* nn.BatchNorm2d(C), eps 1e-5, momentum 0.1 (srgan/residual.py:65,68;
+ * srgan/generator.py:49; srgan/discriminator.py:36-60).
+ * stats from an activation tensor: partial table [rows][C][2] */
+int srx_bn_stat_rows(int64_t M);
+int srx_bn_partial_stats(const float* y, float* partials, int64_t M, int C, void* stream);
+/* reduce partials -> save_mean, save_invstd (biased variance); update running stats
+ * (unbiased variance, momentum) and num_batches_tracked (int64) when non-NULL */
+int srx_bn_finalize(const float* partials, int rows, int64_t M, int C, float eps, float momentum,
+                    float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, void* stream);
+/* eval mode: save_mean = running_mean, save_invstd = rsqrt(running_var + eps) */
+int srx_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps,
+                      float* save_mean, float* save_invstd, void* stream);
+/* out = act(gamma*(y-mean)*invstd + beta) [+ residual];  act: NONE / LRELU(slope) / PRELU(*prelu) */
+int srx_bn_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
+                   const float* beta, const float* residual, float* out, int64_t M, int C, int act,
+                   float slope, const float* prelu, void* stream);
+/* backward, pass 1: sums[0..C) = sum dz, sums[C..2C) = sum dz*xhat, sums[2C] = d(prelu slope)
+ * (dz = dout * act'(bn(y))).  ws >= srx_bn_bwd_ws_floats */
+size_t srx_bn_bwd_ws_floats(int64_t M, int C);
+int srx_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, float* sums, int64_t M, int C, int act,
+                          float slope, const float* prelu, float* ws, size_t ws_floats, void* stream);
+/* backward, pass 2: dy = gamma*invstd*(dz - sum_dz/M - xhat*sum_dzxhat/M) (training) or
+ * dy = gamma*invstd*dz (eval, training=0) */
+int srx_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, const float* sums, float* dy, int64_t M,
+                         int C, int act, float slope, const float* prelu, int training, void* stream);
+
+/* ----------------------------------------------------------------- pooling */
+/* nn.MaxPool2d(2,2) of VGG19 (torchvision cfg 'E', srgan/loss.py:30-31); H, W even */
+int srx_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int srx_maxpool2x2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------ linear */
+/* nn.Linear (srgan/discriminator.py:65,67; esrgan/discriminator.py:73,75).
+ * x [B][K], w [J][K] (reference layout), y [B][J] = act(x w^T + bias) */
+size_t srx_linear_ws_floats(int B, int K, int J);
+int srx_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int J,
+                   int act, float slope, float* ws, size_t ws_floats, void* stream);
+int srx_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int K, int J, float* ws,
+                        size_t ws_floats, void* stream);
+int srx_linear_bwd_weight(const float* x, const float* dy, float* dw, int B, int K, int J, void* stream);
+
+/* ------------------------------------------------------------------ losses */
+/* all losses reduce with mean; `loss` is one float on the device; ws >= 2048 floats.
+ * nn.MSELoss (srgan/trainer.py:163,384), nn.L1Loss / F.l1_loss (srgan/loss.py:52; esrgan/trainer.py:163) */
+int srx_mse_fwd(const float* a, const float* b, float* loss, int64_t n, float* ws, void* stream);
+int srx_l1_fwd(const float* a, const float* b, float* loss, int64_t n, float* ws, void* stream);
+/* da = gscale[0] * d(mean loss)/da ; db (if non-NULL) = -da */
+int srx_mse_bwd(const float* a, const float* b, const float* gscale, float* da, float* db, int64_t n, void* stream);
+int srx_l1_bwd(const float* a, const float* b, const float* gscale, float* da, float* db, int64_t n, void* stream);
+/* nn.BCELoss on probabilities against a constant label (srgan/trainer.py:164,446-447,456);
+ * log terms clamped at -100 as torch does */
+int srx_bce_fwd(const float* p, float target, float* loss, int64_t n, float* ws, void* stream);
+int srx_bce_bwd(const float* p, float target, const float* gscale, float* dp, int64_t n, void* stream);
+/* nn.BCEWithLogitsLoss(x - shift[0], target) (esrgan/trainer.py:164,451-453,468); shift may be NULL */
+int srx_bce_logits_fwd(const float* x, const float* shift, float target, float* loss, int64_t n, float* ws, void* stream);
+int srx_bce_logits_bwd(const float* x, const float* shift, float target, const float* gscale, float* dx, int64_t n, void* stream);
+/* sum of squared error -> used for PSNR (srgan/trainer.py:296) is srx_mse_fwd */
+
+/* --------------------------------------------------------------- optimiser */
+/* torch.optim.Adam(lr, betas, eps, weight_decay=0) over one flat buffer
+ * (srgan/trainer.py:171-185).  `step` (int64 on device) is incremented first;
+ * `lr` is a float on the device so StepLR (srgan/trainer.py:186-195) can change
+ * it without re-capturing a graph.  grad_scale multiplies g first (1/world_size
+ * after an all-reduce SUM). */
+int srx_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, float beta1,
+                  float beta2, float eps, float grad_scale, int64_t* step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRX_H */

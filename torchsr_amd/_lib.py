@@ -1,0 +1,140 @@
+"""ctypes binding of ``libsrx_hip.so`` -- the C ABI declared in ``include/srx.h``.
+
+The product path has no CPU fallback: if the HIP library is missing, loading
+raises.  Every entry point returns an ``int`` status; non-zero is turned into a
+``RuntimeError`` carrying the library's thread-local message.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libsrx_hip.so')
+SOURCES = ['api.cpp', 'gconv.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'optim.hip']
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
+
+
+class Conv2dDesc(C.Structure):
+    """Mirror of ``srx_conv2d_t`` (include/srx.h)."""
+    _fields_ = [
+        ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+        ('Cin', C.c_int32), ('Cin_s', C.c_int32), ('Cout', C.c_int32), ('Cout_s', C.c_int32),
+        ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
+        ('shuffle', C.c_int32), ('act', C.c_int32), ('slope', C.c_float), ('up', C.c_int32),
+    ]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``csrc/libsrx_hip.so`` (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, 'srx_common.h'), os.path.join(_HERE, '..', 'include', 'srx.h')]
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(d) for d in deps)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB_PATH] + srcs
+    if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+_Z = C.c_size_t
+_D = C.POINTER(Conv2dDesc)
+
+# name -> (restype, argtypes); status-returning functions have restype int and are checked
+_SIGS = {
+    'srx_version': (_I, []),
+    'srx_last_error': (_I, [C.c_char_p, _Z]),
+    'srx_device_cus': (_I, []),
+    'srx_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'srx_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'srx_conv2d_packed_fwd_floats': (_Z, [_D]),
+    'srx_conv2d_packed_bwd_floats': (_Z, [_D]),
+    'srx_conv2d_fwd_ws_floats': (_Z, [_D]),
+    'srx_conv2d_bwd_data_ws_floats': (_Z, [_D]),
+    'srx_conv2d_bwd_weight_ws_floats': (_Z, [_D]),
+    'srx_conv2d_stat_rows': (_I, [_D]),
+    'srx_conv2d_pack': (_I, [_D, _P, _P, _P, _P]),
+    'srx_conv2d_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    'srx_conv2d_bwd_data': (_I, [_D, _P, _P, _P, _P, _Z, _P]),
+    'srx_conv2d_bwd_weight': (_I, [_D, _P, _P, _P, _P, _Z, _P]),
+    'srx_colsum_ws_floats': (_Z, [_L, _I]),
+    'srx_colsum': (_I, [_P, _P, _L, _I, _I, _P, _Z, _P]),
+    'srx_act_bwd_from_out': (_I, [_P, _P, _P, _L, _I, _F, _P]),
+    'srx_prelu_fwd': (_I, [_P, _P, _P, _L, _P]),
+    'srx_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _L, _P, _P]),
+    'srx_lrelu_fwd': (_I, [_P, _P, _L, _F, _P]),
+    'srx_axpby': (_I, [_P, _P, _P, _L, _F, _F, _P]),
+    'srx_sigmoid_fwd': (_I, [_P, _P, _L, _P]),
+    'srx_sigmoid_bwd': (_I, [_P, _P, _P, _L, _P]),
+    'srx_bn_stat_rows': (_I, [_L]),
+    'srx_bn_partial_stats': (_I, [_P, _P, _L, _I, _P]),
+    'srx_bn_finalize': (_I, [_P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
+    'srx_bn_eval_stats': (_I, [_P, _P, _I, _F, _P, _P, _P]),
+    'srx_bn_act_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _P]),
+    'srx_bn_bwd_ws_floats': (_Z, [_L, _I]),
+    'srx_bn_act_bwd_reduce': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _P, _Z, _P]),
+    'srx_bn_act_bwd_apply': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _I, _P]),
+    'srx_maxpool2x2_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'srx_maxpool2x2_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'srx_linear_ws_floats': (_Z, [_I, _I, _I]),
+    'srx_linear_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    'srx_linear_bwd_data': (_I, [_P, _P, _P, _I, _I, _I, _P, _Z, _P]),
+    'srx_linear_bwd_weight': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'srx_mse_fwd': (_I, [_P, _P, _P, _L, _P, _P]),
+    'srx_l1_fwd': (_I, [_P, _P, _P, _L, _P, _P]),
+    'srx_mse_bwd': (_I, [_P, _P, _P, _P, _P, _L, _P]),
+    'srx_l1_bwd': (_I, [_P, _P, _P, _P, _P, _L, _P]),
+    'srx_bce_fwd': (_I, [_P, _F, _P, _L, _P, _P]),
+    'srx_bce_bwd': (_I, [_P, _F, _P, _P, _L, _P]),
+    'srx_bce_logits_fwd': (_I, [_P, _P, _F, _P, _L, _P, _P]),
+    'srx_bce_logits_bwd': (_I, [_P, _P, _F, _P, _P, _L, _P]),
+    'srx_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
+}
+# functions whose int return value is data, not a status
+_UNCHECKED = {'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows'}
+
+EXPORTS = tuple(_SIGS.keys())
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: the MI355X HIP extension has not been built. '
+                'Run `python -c "import __graft_entry__ as g; g.build()"` (needs hipcc). '
+                'There is no CPU fallback for the product path.')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    lib().srx_last_error(buf, 512)
+    return buf.value.decode('utf-8', 'replace')
+
+
+def call(name: str, *args):
+    """Call a status-returning entry point; raise RuntimeError on failure."""
+    rc = getattr(lib(), name)(*args)
+    if name not in _UNCHECKED and _SIGS[name][0] is _I and rc != 0:
+        raise RuntimeError(f'{name} failed (code {rc}): {last_error()}')
+    return rc

@@ -1,0 +1,341 @@
+// HBM-bound streaming kernels of the SRGAN/ESRGAN path: layout changes at the
+// module boundary, standalone activations, residual scaling, column sums (bias
+// gradients) and the 2x2 max pooling of VGG19.  16-byte accesses, grid capped at
+// 4096 workgroups with a grid-stride loop (256 CUs x 8 blocks and change).
+#include "srx_common.h"
+
+namespace {
+
+unsigned stream_grid(int64_t n) {
+  int64_t b = srx_cdiv(n, 256);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+#define GRID_STRIDE(i, n) \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------ layout
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W,
+                                    int Cs) {
+  const int64_t total = (int64_t)N * H * W * Cs;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % Cs);
+    const int64_t pix = i / Cs;
+    const int w = (int)(pix % W);
+    const int64_t t = pix / W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    dst[i] = c < C ? src[(((int64_t)n * C + c) * H + h) * W + w] : 0.f;
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W,
+                                    int Cs) {
+  const int64_t total = (int64_t)N * C * H * W;
+  GRID_STRIDE(i, total) {
+    const int w = (int)(i % W);
+    int64_t t = i / W;
+    const int h = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    dst[i] = src[(((int64_t)n * H + h) * W + w) * Cs + c];
+  }
+}
+
+// ------------------------------------------------------------- activations
+__global__ void act_bwd_from_out_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                        float* __restrict__ dx, int64_t n, int act, float slope) {
+  const int64_t n4 = n / 4;
+  GRID_STRIDE(i, n4) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+    const f32x4 o = *reinterpret_cast<const f32x4*>(y + i * 4);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = o[e] > 0.f ? g[e] : (act == SRX_ACT_RELU ? 0.f : g[e] * slope);
+    *reinterpret_cast<f32x4*>(dx + i * 4) = r;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    dx[i] = y[i] > 0.f ? dy[i] : (act == SRX_ACT_RELU ? 0.f : dy[i] * slope);
+  }
+}
+
+__global__ void leaky_fwd_kernel(const float* __restrict__ x, const float* __restrict__ slope_ptr, float slope,
+                                 float* __restrict__ y, int64_t n) {
+  if (slope_ptr) slope = slope_ptr[0];
+  const int64_t n4 = n / 4;
+  GRID_STRIDE(i, n4) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    y[i] = x[i] > 0.f ? x[i] : x[i] * slope;
+  }
+}
+
+// dx = x>0 ? dy : a*dy ; per-block partial of d(a) = sum_{x<=0} dy*x
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ slope_ptr, float* __restrict__ dx,
+                                                        float* __restrict__ partial, int64_t n) {
+  __shared__ float red[4];
+  const float a = slope_ptr[0];
+  float acc = 0.f;
+  const int64_t n4 = n / 4;
+  GRID_STRIDE(i, n4) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool pos = v[e] > 0.f;
+      r[e] = pos ? g[e] : a * g[e];
+      acc += pos ? 0.f : g[e] * v[e];
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = r;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    const bool pos = x[i] > 0.f;
+    dx[i] = pos ? dy[i] : a * dy[i];
+    acc += pos ? 0.f : dy[i] * x[i];
+  }
+  acc = srx_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int nb, float scale,
+                                                           float* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += (double)partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] * (double)scale);
+}
+
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ y,
+                             int64_t n, float a, float b) {
+  const int64_t n4 = n / 4;
+  GRID_STRIDE(i, n4) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(x + i * 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(z + i * 4);
+    *reinterpret_cast<f32x4*>(y + i * 4) = a * u + b * v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    y[i] = a * x[i] + b * z[i];
+  }
+}
+
+__global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  GRID_STRIDE(i, n) y[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                   int64_t n) {
+  GRID_STRIDE(i, n) dx[i] = dy[i] * y[i] * (1.0f - y[i]);
+}
+
+// ------------------------------------------------------------------ colsum
+constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                             int64_t M, int C, int Cs) {
+  // one thread per channel (strided over C), rows of this block summed serially: simple and coalesced for C >= 64
+  const int64_t rbeg = (int64_t)blockIdx.x * CS_ROWS;
+  const int64_t rend = min(M, rbeg + CS_ROWS);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int64_t r = rbeg; r < rend; ++r) s += x[r * Cs + c];
+    part[(size_t)blockIdx.x * C + c] = s;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)part[(size_t)r * C + c];
+  out[c] = (float)s;
+}
+
+// ----------------------------------------------------------------- pooling
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, cq = C / 4;
+  const int64_t total = (int64_t)N * Ho * Wo * cq;
+  GRID_STRIDE(i, total) {
+    const int q = (int)(i % cq);
+    int64_t t = i / cq;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const float* p = x + (((int64_t)n * H + 2 * oh) * W + 2 * ow) * C + q * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + C);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)W * C);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(p + (int64_t)W * C + C);
+    f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+    *reinterpret_cast<f32x4*>(y + i * 4) = m;
+  }
+}
+
+// gradient goes to the first maximum in scan order, as ATen's max_pool2d does
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                   int N, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, cq = C / 4;
+  const int64_t total = (int64_t)N * Ho * Wo * cq;
+  GRID_STRIDE(i, total) {
+    const int q = (int)(i % cq);
+    int64_t t = i / cq;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const int64_t base = (((int64_t)n * H + 2 * oh) * W + 2 * ow) * C + q * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + base);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(x + base + C);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(x + base + (int64_t)W * C);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(x + base + (int64_t)W * C + C);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+    f32x4 ga, gb, gc, gd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int idx = 0;
+      float m = a[e];
+      if (b[e] > m) { m = b[e]; idx = 1; }
+      if (c[e] > m) { m = c[e]; idx = 2; }
+      if (d[e] > m) { m = d[e]; idx = 3; }
+      ga[e] = idx == 0 ? g[e] : 0.f;
+      gb[e] = idx == 1 ? g[e] : 0.f;
+      gc[e] = idx == 2 ? g[e] : 0.f;
+      gd[e] = idx == 3 ? g[e] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(dx + base) = ga;
+    *reinterpret_cast<f32x4*>(dx + base + C) = gb;
+    *reinterpret_cast<f32x4*>(dx + base + (int64_t)W * C) = gc;
+    *reinterpret_cast<f32x4*>(dx + base + (int64_t)W * C + C) = gd;
+  }
+}
+
+}  // namespace
+
+extern "C" int srx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int Cs, void* stream) {
+  SRX_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cs >= C, "nchw_to_nhwc: bad argument");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_grid((int64_t)N * H * W * Cs)), dim3(256), 0, srx_stream(stream),
+                     src, dst, N, C, H, W, Cs);
+  SRX_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int Cs, void* stream) {
+  SRX_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cs >= C, "nhwc_to_nchw: bad argument");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(stream_grid((int64_t)N * C * H * W)), dim3(256), 0, srx_stream(stream),
+                     src, dst, N, C, H, W, Cs);
+  SRX_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+  return SRX_OK;
+}
+
+extern "C" size_t srx_colsum_ws_floats(int64_t M, int C) { return (size_t)srx_cdiv(M, CS_ROWS) * C; }
+
+extern "C" int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, float* ws, size_t ws_floats,
+                          void* stream) {
+  SRX_REQUIRE(x && out && ws && M > 0 && C > 0 && Cs >= C, "colsum: bad argument");
+  if (ws_floats < srx_colsum_ws_floats(M, C)) SRX_FAIL(SRX_E_WORKSPACE, "colsum: workspace too small");
+  const int rows = (int)srx_cdiv(M, CS_ROWS);
+  hipStream_t st = srx_stream(stream);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, ws, M, C, Cs);
+  SRX_CHECK_LAUNCH("colsum_partial_kernel");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)srx_cdiv(C, 64)), dim3(64), 0, st, ws, rows, C, out);
+  SRX_CHECK_LAUNCH("colsum_final_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_act_bwd_from_out(const float* dy, const float* y, float* dx, int64_t n, int act, float slope,
+                                    void* stream) {
+  SRX_REQUIRE(dy && y && dx && n > 0, "act_bwd_from_out: bad argument");
+  SRX_REQUIRE(act == SRX_ACT_RELU || act == SRX_ACT_LRELU, "act_bwd_from_out: act must be RELU or LRELU");
+  hipLaunchKernelGGL(act_bwd_from_out_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, srx_stream(stream), dy, y, dx, n,
+                     act, slope);
+  SRX_CHECK_LAUNCH("act_bwd_from_out_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_prelu_fwd(const float* x, const float* slope, float* y, int64_t n, void* stream) {
+  SRX_REQUIRE(x && slope && y && n > 0, "prelu_fwd: bad argument");
+  hipLaunchKernelGGL(leaky_fwd_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, srx_stream(stream), x, slope, 0.f, y, n);
+  SRX_CHECK_LAUNCH("leaky_fwd_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_lrelu_fwd(const float* x, float* y, int64_t n, float slope, void* stream) {
+  SRX_REQUIRE(x && y && n > 0, "lrelu_fwd: bad argument");
+  hipLaunchKernelGGL(leaky_fwd_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, srx_stream(stream), x,
+                     (const float*)nullptr, slope, y, n);
+  SRX_CHECK_LAUNCH("leaky_fwd_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx, float* dslope, int64_t n,
+                             float* ws, void* stream) {
+  SRX_REQUIRE(dy && x && slope && dx && dslope && ws && n > 0, "prelu_bwd: bad argument");
+  unsigned nb = stream_grid(n / 4);
+  if (nb > 1024) nb = 1024;
+  hipStream_t st = srx_stream(stream);
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nb), dim3(256), 0, st, dy, x, slope, dx, ws, n);
+  SRX_CHECK_LAUNCH("prelu_bwd_kernel");
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, ws, (int)nb, 1.0f, dslope);
+  SRX_CHECK_LAUNCH("sum_partials_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_axpby(const float* x, const float* z, float* y, int64_t n, float a, float b, void* stream) {
+  SRX_REQUIRE(x && z && y && n > 0, "axpby: bad argument");
+  hipLaunchKernelGGL(axpby_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, srx_stream(stream), x, z, y, n, a, b);
+  SRX_CHECK_LAUNCH("axpby_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream) {
+  SRX_REQUIRE(x && y && n > 0, "sigmoid_fwd: bad argument");
+  hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(stream_grid(n)), dim3(256), 0, srx_stream(stream), x, y, n);
+  SRX_CHECK_LAUNCH("sigmoid_fwd_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+  SRX_REQUIRE(dy && y && dx && n > 0, "sigmoid_bwd: bad argument");
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(stream_grid(n)), dim3(256), 0, srx_stream(stream), dy, y, dx, n);
+  SRX_CHECK_LAUNCH("sigmoid_bwd_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  SRX_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "maxpool2x2_fwd: bad argument");
+  SRX_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2x2_fwd: H, W must be even and C a multiple of 4");
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid((int64_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                     srx_stream(stream), x, y, N, H, W, C);
+  SRX_CHECK_LAUNCH("maxpool_fwd_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_maxpool2x2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C,
+                                  void* stream) {
+  SRX_REQUIRE(dy && x && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool2x2_bwd: bad argument");
+  SRX_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2x2_bwd: H, W must be even and C a multiple of 4");
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid((int64_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                     srx_stream(stream), dy, x, dx, N, H, W, C);
+  SRX_CHECK_LAUNCH("maxpool_bwd_kernel");
+  return SRX_OK;
+}

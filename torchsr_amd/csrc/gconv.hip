@@ -1,0 +1,802 @@
+// Convolution as a gather-GEMM on the fp32 matrix cores of gfx950 (MI355X).
+//
+//   out[opix(m)][n] = epilogue( sum_k A(m,k) * B[n][k] ),   A(m,k) = in[ipix(m)+tap(k)][chan(k)]  (0 outside)
+//
+// One kernel serves nn.Conv2d forward (any kernel size / stride / padding), the
+// data gradient (run per stride-parity class with flipped taps, so stride-2
+// layers do no wasted work) and -- through in_shuffle / out_shuffle addressing --
+// the PixelShuffle(2) of the SRGAN sub-pixel layer (srgan/residual.py:27-28).
+// A second kernel computes the weight gradient dW[n][k] = sum_m dy[m][n] A(m,k).
+//
+// Data layout: activations NHWC fp32 (channel stride multiple of 4), packed
+// weights [N_pad][K_pad] with K = (tap, channel) contiguous, so both MFMA
+// operands are "k-contiguous rows" and are staged into XOR-swizzled LDS rows of
+// 32 floats read back with conflict-free ds_read_b128.
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak).
+#include "srx_common.h"
+#include <mutex>
+
+namespace {
+
+struct GArgs {
+  const float* in; const float* w; const float* bias; float* out; float* part;
+  int N, Hi, Wi, Ci;
+  int Hm, Wm, M, HmWm;
+  float inv_HmWm, inv_Wm;
+  int in_stride, nth, ntw, dh0, dw0, Ck, K, Kp;
+  int Cn, Cs;
+  int Ho, Wo, Co;
+  int out_stride, oh_off, ow_off;
+  int out_shuffle, in_shuffle;
+  int act; float slope;
+  int linear_out;
+  int mtiles;
+  int kchunks, kc_per_split, nsplit;
+};
+
+constexpr int BK = 32;           // floats per k-chunk (one 128-byte LDS row)
+constexpr int INVALID = -20000;  // coordinate that fails every bounds check
+
+// ---------------------------------------------------------------------------
+// forward / data-gradient gather-GEMM.  256 threads = 4 waves, wave tile WMxWN.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gconv_kernel(const GArgs a) {
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int WAVES_M = BM / WM;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int RA = BM / 32, RB = BN / 32;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sA = reinterpret_cast<float*>(smem);
+  float* sB = sA + 2 * BM * BK;
+  int2* ktab = reinterpret_cast<int2*>(sB + 2 * BN * BK);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int mt = blockIdx.x % a.mtiles, nt = blockIdx.x / a.mtiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int q = tid & 7, r0 = tid >> 3;
+
+  const int kc_beg = blockIdx.z * a.kc_per_split;
+  const int kc_end = min(a.kchunks, kc_beg + a.kc_per_split);
+
+  // ---- k table: (dh, dw) and linear input offset for every float4 of K in range
+  for (int e = kc_beg * 8 + tid; e < kc_end * 8; e += 256) {
+    const int k = 4 * e;
+    int2 ent;
+    if (k < a.K) {
+      const int tap = k / a.Ck, c = k - tap * a.Ck;
+      const int th = tap / a.ntw, tw = tap - th * a.ntw;
+      const int dh = a.dh0 + th, dw = a.dw0 + tw;
+      int koff;
+      if (a.in_shuffle) {
+        const int ij = c / a.in_shuffle, cc = c - ij * a.in_shuffle;
+        koff = ((2 * dh + (ij >> 1)) * (2 * a.Wi) + 2 * dw + (ij & 1)) * a.Ci + cc;
+      } else {
+        koff = (dh * a.Wi + dw) * a.Ci + c;
+      }
+      ent.x = (int)((unsigned)(dh & 0xffff) | ((unsigned)dw << 16));
+      ent.y = koff;
+    } else {
+      ent.x = (INVALID & 0xffff);
+      ent.y = 0;
+    }
+    ktab[e - kc_beg * 8] = ent;
+  }
+
+  // ---- per-thread rows of the A tile (fixed for the whole k loop)
+  int rbase[RA], rih[RA], riw[RA];
+#pragma unroll
+  for (int p = 0; p < RA; ++p) {
+    const int m = m0 + r0 + 32 * p;
+    if (m < a.M) {
+      int n, rem, mh, mw;
+      srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
+      srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
+      const int ih0 = mh * a.in_stride, iw0 = mw * a.in_stride;
+      rih[p] = ih0;
+      riw[p] = iw0;
+      rbase[p] = a.in_shuffle ? ((n * 2 * a.Hi + 2 * ih0) * (2 * a.Wi) + 2 * iw0) * a.Ci
+                              : ((n * a.Hi + ih0) * a.Wi + iw0) * a.Ci;
+    } else {
+      rih[p] = INVALID; riw[p] = 0; rbase[p] = 0;
+    }
+  }
+  const float* wrow = a.w + (size_t)(n0 + r0) * a.Kp + q * 4;
+  __syncthreads();
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[RA], rb[RB];
+  auto gload = [&](int kc) {
+    const int2 kt = ktab[(kc - kc_beg) * 8 + q];
+    const int dh = (int)(short)(kt.x & 0xffff), dw = kt.x >> 16;
+#pragma unroll
+    for (int p = 0; p < RA; ++p) {
+      const int ih = rih[p] + dh, iw = riw[p] + dw;
+      const bool ok = ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
+      const int off = ok ? rbase[p] + kt.y : 0;
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.in + off);
+      ra[p] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int p = 0; p < RB; ++p)
+      rb[p] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(32 * p) * a.Kp + kc * BK);
+  };
+  const int wchunk = (q ^ ((r0 >> 1) & 7)) * 4;
+  auto swrite = [&](int buf) {
+    float* dA = sA + buf * BM * BK;
+    float* dB = sB + buf * BN * BK;
+#pragma unroll
+    for (int p = 0; p < RA; ++p) *reinterpret_cast<f32x4*>(dA + (r0 + 32 * p) * BK + wchunk) = ra[p];
+#pragma unroll
+    for (int p = 0; p < RB; ++p) *reinterpret_cast<f32x4*>(dB + (r0 + 32 * p) * BK + wchunk) = rb[p];
+  };
+
+  const int h = lane >> 5, l31 = lane & 31;
+  const int xr = (l31 >> 1) & 7;
+  const int arow = (wm * WM + l31) * BK, brow = (wn * WN + l31) * BK;
+
+  if (kc_beg < kc_end) {
+    gload(kc_beg);
+    swrite(0);
+  }
+  __syncthreads();
+
+  for (int kc = kc_beg; kc < kc_end; ++kc) {
+    const int cur = (kc - kc_beg) & 1;
+    const bool more = (kc + 1 < kc_end);
+    if (more) gload(kc + 1);
+    const float* cA = sA + cur * BM * BK + arow;
+    const float* cB = sB + cur * BN * BK + brow;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ch = ((2 * s + h) ^ xr) * 4;
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * BK + ch);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * BK + ch);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (more) swrite(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------- epilogue
+  // accumulator map (32x32 MFMA): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool raw = a.nsplit > 1;
+  float* outp = raw ? a.out + (size_t)blockIdx.z * a.M * a.Cs : a.out;
+
+  float bv[TN];
+  int colv[TN], ocol[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WN + j * 32 + l31;
+    colv[j] = col;
+    int bidx = col, oc = col;
+    if (a.out_shuffle) {
+      const int ij = col / a.out_shuffle, cc = col - ij * a.out_shuffle;
+      bidx = cc * 4 + ij;
+      oc = (((ij >> 1) * a.Wo) + (ij & 1)) * a.Co + cc;  // offset inside the 2x2 output block
+    }
+    ocol[j] = oc;
+    bv[j] = (!raw && a.bias && col < a.Cn) ? a.bias[bidx] : 0.f;
+  }
+  float csum[TN], csq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const bool mok = m < a.M;
+      size_t obase;
+      if (a.linear_out || raw) {
+        obase = (size_t)m * a.Cs;
+      } else {
+        int n, rem, mh, mw;
+        srx_divmod(mok ? m : 0, a.HmWm, a.inv_HmWm, n, rem);
+        srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
+        const int oh = mh * a.out_stride + a.oh_off, ow = mw * a.out_stride + a.ow_off;
+        obase = ((size_t)(n * a.Ho + oh) * a.Wo + ow) * a.Co;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float v = acc[i][j][r] + bv[j];
+        if (mok) { csum[j] += v; csq[j] += v * v; }
+        if (!raw) {
+          if (a.act == SRX_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (a.act == SRX_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+        }
+        if (mok && colv[j] < a.Cs) outp[obase + ocol[j]] = v;
+      }
+    }
+  }
+
+  if (a.part) {  // per-channel sum / sum of squares of this row block (training-mode BatchNorm)
+    __syncthreads();  // everyone is done with the staging buffers
+    float* red = sA;  // [WAVES_M][BN][2]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = csum[j] + __shfl_xor(csum[j], 32, 64);
+      float s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+      if (h == 0) {
+        const int c = wn * WN + j * 32 + l31;
+        red[(wm * BN + c) * 2 + 0] = s;
+        red[(wm * BN + c) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) { s += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
+      const int col = n0 + tid;
+      if (col < a.Cn) {
+        a.part[((size_t)mt * a.Cn + col) * 2 + 0] = s;
+        a.part[((size_t)mt * a.Cn + col) * 2 + 1] = s2;
+      }
+    }
+  }
+}
+
+// split-K tail: out = act(sum_z slab[z] + bias)
+__global__ void splitk_epilogue_kernel(const float* __restrict__ slab, int nsplit, int64_t MC, int Cs, int Cn,
+                                       const float* __restrict__ bias, int act, float slope, float* __restrict__ out) {
+  const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 * 4 >= MC) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(slab + i4 * 4);
+  for (int z = 1; z < nsplit; ++z) s += *reinterpret_cast<const f32x4*>(slab + (size_t)z * MC + i4 * 4);
+  const int c = (int)((i4 * 4) % Cs);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v = s[e] + ((bias && c + e < Cn) ? bias[c + e] : 0.f);
+    if (act == SRX_ACT_RELU) v = fmaxf(v, 0.f);
+    else if (act == SRX_ACT_LRELU) v = v > 0.f ? v : v * slope;
+    s[e] = v;
+  }
+  *reinterpret_cast<f32x4*>(out + i4 * 4) = s;
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient: slab[z][n][k] = sum_{m in split z} dy[m][n] * A(m,k)
+// workgroup tile 64(n) x 64(k), 4 waves of 32x32, m consumed 32 rows at a time.
+// ---------------------------------------------------------------------------
+struct WArgs {
+  const float* in; const float* dy; float* slab;
+  int N, Hi, Wi, Ci, Hm, Wm, M, HmWm;
+  float inv_HmWm, inv_Wm;
+  int in_stride, nth, ntw, dh0, dw0, Ck, K, Kw;
+  int Cd, Cdv, dy_shuffle, Cnw;
+  int rows_per_split, ktiles;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
+  __shared__ __attribute__((aligned(16))) float sD[2][32 * 64];
+  __shared__ __attribute__((aligned(16))) float sX[2][32 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kt = blockIdx.x % a.ktiles, ntile = blockIdx.x / a.ktiles;
+  const int k0 = kt * 64, n0 = ntile * 64;
+  const int q = tid & 15, r0 = tid >> 4;
+
+  // this thread's fixed k (A gather) and fixed dy column
+  const int k = k0 + 4 * q;
+  const bool kvalid = k < a.K;
+  int dh = 0, dw = 0, kc = 0;
+  if (kvalid) {
+    const int tap = k / a.Ck;
+    kc = k - tap * a.Ck;
+    const int th = tap / a.ntw, tw = tap - th * a.ntw;
+    dh = a.dh0 + th;
+    dw = a.dw0 + tw;
+  }
+  const int col = n0 + 4 * q;
+  const bool cvalid = col < a.Cdv;
+  int sh_i = 0, sh_j = 0, sh_c = col;
+  if (a.dy_shuffle) {
+    const int ij = col / a.dy_shuffle;
+    sh_c = col - ij * a.dy_shuffle;
+    sh_i = ij >> 1;
+    sh_j = ij & 1;
+  }
+
+  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mend = min(a.M, mbeg + a.rows_per_split);
+
+  f32x4 rd[2], rx[2];
+  auto gload = [&](int mb) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int m = mb + r0 + 16 * p;
+      const bool valid = m < mend;
+      int n, rem, mh, mw;
+      srx_divmod(valid ? m : 0, a.HmWm, a.inv_HmWm, n, rem);
+      srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
+      const int ih = mh * a.in_stride + dh, iw = mw * a.in_stride + dw;
+      const bool okx = valid && kvalid && ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
+      const size_t offx = okx ? ((size_t)(n * a.Hi + ih) * a.Wi + iw) * a.Ci + kc : 0;
+      f32x4 vx = *reinterpret_cast<const f32x4*>(a.in + offx);
+      rx[p] = okx ? vx : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const bool okd = valid && cvalid;
+      size_t offd = 0;
+      if (okd) {
+        if (a.dy_shuffle) offd = ((size_t)(n * 2 * a.Hm + 2 * mh + sh_i) * (2 * a.Wm) + 2 * mw + sh_j) * a.Cd + sh_c;
+        else offd = (size_t)m * a.Cd + col;
+      }
+      f32x4 vd = *reinterpret_cast<const f32x4*>(a.dy + offd);
+      rd[p] = okd ? vd : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      *reinterpret_cast<f32x4*>(&sD[buf][(r0 + 16 * p) * 64 + q * 4]) = rd[p];
+      *reinterpret_cast<f32x4*>(&sX[buf][(r0 + 16 * p) * 64 + q * 4]) = rx[p];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wn = wave >> 1, wk = wave & 1;
+
+  if (mbeg < mend) { gload(mbeg); swrite(0); }
+  __syncthreads();
+  int cur = 0;
+  for (int mb = mbeg; mb < mend; mb += 32) {
+    const bool more = mb + 32 < mend;
+    if (more) gload(mb + 32);
+    const float* cD = &sD[cur][h * 64 + wn * 32 + l31];
+    const float* cX = &sX[cur][h * 64 + wk * 32 + l31];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cD[s * 128], cX[s * 128], acc, 0, 0, 0);
+    if (more) swrite(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  float* slab = a.slab + (size_t)blockIdx.z * a.Cnw * a.Kw;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    slab[(size_t)row * a.Kw + k0 + wk * 32 + l31] = acc[r];
+  }
+}
+
+// slab sums -> OIHW gradient
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int Cnw, int Kw, int K, int Ck,
+                                    int Cout, int Cin, int KH, int KW, int shuffle_cps, float* __restrict__ dw) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)Cout * K) return;
+  const int np = (int)(idx / K), k = (int)(idx - (int64_t)np * K);
+  const int tap = k / Ck, ci = k - tap * Ck;
+  if (ci >= Cin) return;
+  float s = 0.f;
+  for (int z = 0; z < nsplit; ++z) s += slab[((size_t)z * Cnw + np) * Kw + k];
+  int co = np;
+  if (shuffle_cps) { const int ij = np / shuffle_cps, cc = np - ij * shuffle_cps; co = cc * 4 + ij; }
+  const int kh = tap / KW, kw = tap - kh * KW;
+  dw[(((size_t)co * Cin + ci) * KH + kh) * KW + kw] = s;
+}
+
+// ---------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------
+__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int KH, int KW,
+                                int Ck, int K, int Kp, int Cnp, int shuffle_cps) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)Cnp * Kp) return;
+  const int np = (int)(idx / Kp), k = (int)(idx - (int64_t)np * Kp);
+  float v = 0.f;
+  if (np < Cout && k < K) {
+    const int tap = k / Ck, ci = k - tap * Ck;
+    if (ci < Cin) {
+      int co = np;
+      if (shuffle_cps) { const int ij = np / shuffle_cps, cc = np - ij * shuffle_cps; co = cc * 4 + ij; }
+      const int kh = tap / KW, kw = tap - kh * KW;
+      v = w[(((size_t)co * Cin + ci) * KH + kh) * KW + kw];
+    }
+  }
+  p[idx] = v;
+}
+
+// one stride-parity class of the data gradient: B[ci][(th,tw,c)] = W[co(c)][ci][kh(th)][kw(tw)]
+__global__ void pack_bwd_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int KH, int KW,
+                                int stride, int pad, int ph, int pw, int dminh, int dminw, int ntw, int Ck, int K,
+                                int Kp, int Cnp, int shuffle_cps) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)Cnp * Kp) return;
+  const int ci = (int)(idx / Kp), k = (int)(idx - (int64_t)ci * Kp);
+  float v = 0.f;
+  if (ci < Cin && k < K) {
+    const int tap = k / Ck, c = k - tap * Ck;
+    if (c < Cout) {
+      const int th = tap / ntw, tw = tap - th * ntw;
+      const int kh = ph + pad - stride * (dminh + th), kw = pw + pad - stride * (dminw + tw);
+      int co = c;
+      if (shuffle_cps) { const int ij = c / shuffle_cps, cc = c - ij * shuffle_cps; co = cc * 4 + ij; }
+      v = w[(((size_t)co * Cin + ci) * KH + kh) * KW + kw];
+    }
+  }
+  p[idx] = v;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct Geo {  // derived sizes of one conv
+  int Ho, Wo, Ck, K, Kp, Cnp, cps;
+};
+
+int check_desc(const srx_conv2d_t* d) {
+  SRX_REQUIRE(d, "conv2d: null descriptor");
+  SRX_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv2d: non-positive size");
+  SRX_REQUIRE(d->Cin_s >= d->Cin && d->Cin_s % 4 == 0, "conv2d: Cin_s must be a multiple of 4 and >= Cin");
+  SRX_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
+  SRX_REQUIRE(d->shuffle == 0 || d->shuffle == 2, "conv2d: shuffle must be 0 or 2");
+  if (d->up != 0 && d->up != 1) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: fused nearest upsample not implemented");
+  if (d->shuffle) {
+    SRX_REQUIRE(d->Cout % 16 == 0, "conv2d: shuffle needs Cout multiple of 16");
+    SRX_REQUIRE(d->Cout_s >= d->Cout / 4 && d->Cout_s % 4 == 0, "conv2d: bad Cout_s for shuffle");
+    SRX_REQUIRE(d->stride == 1, "conv2d: shuffle needs stride 1");
+  } else {
+    SRX_REQUIRE(d->Cout_s >= d->Cout && d->Cout_s % 4 == 0, "conv2d: Cout_s must be a multiple of 4 and >= Cout");
+  }
+  SRX_REQUIRE(d->act == SRX_ACT_NONE || d->act == SRX_ACT_RELU || d->act == SRX_ACT_LRELU, "conv2d: bad act");
+  const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  SRX_REQUIRE(Ho > 0 && Wo > 0, "conv2d: empty output");
+  SRX_REQUIRE((int64_t)d->N * d->H * d->W < (1 << 24) && (int64_t)d->N * Ho * Wo < (1 << 24),
+              "conv2d: more than 2^24 pixels per call; tile the image");
+  SRX_REQUIRE((int64_t)d->N * d->H * d->W * d->Cin_s < 2147483647LL, "conv2d: input too large for 32-bit offsets");
+  SRX_REQUIRE(d->pad < 16000 && d->KH < 16000, "conv2d: kernel too large");
+  return SRX_OK;
+}
+
+int pad_rows(int c) { return c <= 32 ? 32 : (c <= 64 ? 64 : (int)srx_roundup(c, 128)); }
+
+Geo fwd_geo(const srx_conv2d_t* d) {
+  Geo g;
+  g.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+  g.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  g.Ck = d->Cin_s;
+  g.K = d->KH * d->KW * g.Ck;
+  g.Kp = (int)srx_roundup(g.K, BK);
+  g.Cnp = pad_rows(d->Cout);
+  g.cps = d->shuffle ? d->Cout / 4 : 0;
+  return g;
+}
+
+struct BwdClass {  // one stride-parity class of the data gradient
+  int ph, pw, nth, ntw, dminh, dminw, Hm, Wm, K, Kp;
+  size_t woff;  // offset (floats) into the packed bwd buffer
+};
+
+// taps of class `par` along one axis: kernel size Kd; returns count, sets dmin
+int class_taps(int par, int pad, int stride, int Kd, int& dmin) {
+  const int kfirst = (par + pad) % stride;
+  if (kfirst >= Kd) { dmin = 0; return 0; }
+  const int cnt = (Kd - 1 - kfirst) / stride + 1;
+  const int dmax = (par + pad - kfirst) / stride;
+  dmin = dmax - (cnt - 1);
+  return cnt;
+}
+
+int bwd_classes(const srx_conv2d_t* d, BwdClass* cls, size_t& total_floats) {
+  const int Ck = d->shuffle ? d->Cout : d->Cout_s;
+  const int Cnp = pad_rows(d->Cin);
+  int n = 0;
+  total_floats = 0;
+  for (int ph = 0; ph < d->stride; ++ph)
+    for (int pw = 0; pw < d->stride; ++pw) {
+      BwdClass c;
+      c.ph = ph; c.pw = pw;
+      c.nth = class_taps(ph, d->pad, d->stride, d->KH, c.dminh);
+      c.ntw = class_taps(pw, d->pad, d->stride, d->KW, c.dminw);
+      c.Hm = (d->H - ph + d->stride - 1) / d->stride;
+      c.Wm = (d->W - pw + d->stride - 1) / d->stride;
+      c.K = c.nth * c.ntw * Ck;
+      c.Kp = (int)srx_roundup(c.K > 0 ? c.K : 1, BK);
+      c.woff = total_floats;
+      total_floats += (size_t)Cnp * c.Kp;
+      cls[n++] = c;
+    }
+  return n;
+}
+
+struct Plan { int BM, BN, mtiles, ntiles, nsplit, kc_per_split; };
+
+Plan make_plan(int M, int Cnp, int kchunks, bool can_split) {
+  static int cus = 0;
+  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
+  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+  Plan best{0, 0, 0, 0, 1, kchunks};
+  for (int i = 0; i < 4; ++i) {
+    const int bm = cand[i][0], bn = cand[i][1];
+    if (Cnp == 32) { if (bn != 32) continue; }
+    else if (bn == 32 || Cnp % bn != 0) continue;
+    const int mt = (int)srx_cdiv(M, bm), ntl = Cnp / bn;
+    best = Plan{bm, bn, mt, ntl, 1, kchunks};
+    if ((int64_t)mt * ntl >= 2 * cus) break;  // largest tile that still gives two workgroups per CU
+  }
+  const int64_t wgs = (int64_t)best.mtiles * best.ntiles;
+  if (can_split && wgs < cus && kchunks >= 8) {
+    int s = (int)srx_cdiv(2 * cus, wgs);
+    if (s > kchunks / 4) s = kchunks / 4;
+    if (s > 16) s = 16;
+    if (s > 1) {
+      best.kc_per_split = (int)srx_cdiv(kchunks, s);
+      best.nsplit = (int)srx_cdiv(kchunks, best.kc_per_split);
+    }
+  }
+  return best;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
+  const size_t lds = (size_t)(2 * (BM + BN) * BK) * sizeof(float) + (size_t)p.kc_per_split * 8 * sizeof(int2);
+  if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit);
+  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, st, a);
+  SRX_CHECK_LAUNCH("gconv_kernel");
+  return SRX_OK;
+}
+
+int run_gconv(GArgs& a, Plan p, float* final_out, float* ws, size_t ws_floats, hipStream_t st) {
+  a.kchunks = a.Kp / BK;
+  if (p.nsplit > 1) {
+    const size_t need = (size_t)p.nsplit * a.M * a.Cs;
+    if (!ws || need > ws_floats) SRX_FAIL(SRX_E_WORKSPACE, "conv2d: split-K workspace %zu < %zu floats", ws_floats, need);
+  }
+  a.mtiles = p.mtiles;
+  a.kc_per_split = p.kc_per_split;
+  a.nsplit = p.nsplit;
+  a.out = p.nsplit > 1 ? ws : final_out;
+  int rc;
+  if (p.BM == 128 && p.BN == 128) rc = launch_gconv<128, 128, 64, 64>(a, p, st);
+  else if (p.BM == 128 && p.BN == 64) rc = launch_gconv<128, 64, 64, 32>(a, p, st);
+  else if (p.BM == 64 && p.BN == 64) rc = launch_gconv<64, 64, 32, 32>(a, p, st);
+  else rc = launch_gconv<128, 32, 32, 32>(a, p, st);
+  if (rc) return rc;
+  if (p.nsplit > 1) {
+    const int64_t MC = (int64_t)a.M * a.Cs;
+    const int threads = 256;
+    const int64_t blocks = srx_cdiv(MC / 4, threads);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, ws, p.nsplit, MC, a.Cs,
+                       a.Cn, a.bias, a.act, a.slope, final_out);
+    SRX_CHECK_LAUNCH("splitk_epilogue_kernel");
+  }
+  return SRX_OK;
+}
+
+void set_mgrid(GArgs& a, int N, int Hm, int Wm) {
+  a.N = N; a.Hm = Hm; a.Wm = Wm; a.HmWm = Hm * Wm; a.M = N * Hm * Wm;
+  a.inv_HmWm = 1.0f / (float)a.HmWm;
+  a.inv_Wm = 1.0f / (float)Wm;
+}
+
+Plan fwd_plan(const srx_conv2d_t* d, const Geo& g) {
+  return make_plan(d->N * g.Ho * g.Wo, g.Cnp, g.Kp / BK, !d->shuffle);
+}
+
+Plan bwd_plan(const srx_conv2d_t* d, const BwdClass& c) {
+  return make_plan(d->N * c.Hm * c.Wm, pad_rows(d->Cin), c.Kp / BK, d->stride == 1);
+}
+
+int stat_rows_for(const srx_conv2d_t* d) {
+  const Geo g = fwd_geo(d);
+  const Plan p = fwd_plan(d, g);
+  if (p.nsplit > 1) return srx_bn_stat_rows((int64_t)d->N * g.Ho * g.Wo);
+  return p.mtiles;
+}
+
+}  // namespace
+
+extern "C" size_t srx_conv2d_packed_fwd_floats(const srx_conv2d_t* d) {
+  if (check_desc(d)) return 0;
+  const Geo g = fwd_geo(d);
+  return (size_t)g.Cnp * g.Kp;
+}
+
+extern "C" size_t srx_conv2d_packed_bwd_floats(const srx_conv2d_t* d) {
+  if (check_desc(d)) return 0;
+  if (d->stride > 4) return 0;
+  BwdClass cls[16];
+  size_t total;
+  bwd_classes(d, cls, total);
+  return total;
+}
+
+extern "C" size_t srx_conv2d_fwd_ws_floats(const srx_conv2d_t* d) {
+  if (check_desc(d)) return 0;
+  const Geo g = fwd_geo(d);
+  const Plan p = fwd_plan(d, g);
+  return p.nsplit > 1 ? (size_t)p.nsplit * d->N * g.Ho * g.Wo * d->Cout_s : 0;
+}
+
+extern "C" size_t srx_conv2d_bwd_data_ws_floats(const srx_conv2d_t* d) {
+  if (check_desc(d)) return 0;
+  if (d->stride != 1) return 0;
+  BwdClass cls[16];
+  size_t total;
+  bwd_classes(d, cls, total);
+  const Plan p = bwd_plan(d, cls[0]);
+  return p.nsplit > 1 ? (size_t)p.nsplit * d->N * d->H * d->W * d->Cin_s : 0;
+}
+
+extern "C" size_t srx_conv2d_bwd_weight_ws_floats(const srx_conv2d_t* d) {
+  if (check_desc(d)) return 0;
+  const Geo g = fwd_geo(d);
+  const size_t Cnw = (size_t)srx_roundup(d->Cout, 64), Kw = (size_t)srx_roundup(g.K, 64);
+  return Cnw * Kw * 64;  // up to 64 row splits
+}
+
+extern "C" int srx_conv2d_stat_rows(const srx_conv2d_t* d) {
+  if (check_desc(d)) return 0;
+  return stat_rows_for(d);
+}
+
+extern "C" int srx_conv2d_pack(const srx_conv2d_t* d, const float* w, float* wpk_fwd, float* wpk_bwd, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRX_REQUIRE(w && wpk_fwd, "conv2d_pack: null pointer");
+  hipStream_t st = srx_stream(stream);
+  const Geo g = fwd_geo(d);
+  {
+    const int64_t n = (int64_t)g.Cnp * g.Kp;
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, st, w, wpk_fwd, d->Cout,
+                       d->Cin, d->KH, d->KW, g.Ck, g.K, g.Kp, g.Cnp, g.cps);
+    SRX_CHECK_LAUNCH("pack_fwd_kernel");
+  }
+  if (wpk_bwd) {
+    SRX_REQUIRE(d->stride <= 4, "conv2d_pack: stride > 4 unsupported for the data gradient");
+    BwdClass cls[16];
+    size_t total;
+    const int nc = bwd_classes(d, cls, total);
+    const int Ck = d->shuffle ? d->Cout : d->Cout_s;
+    const int Cnp = pad_rows(d->Cin);
+    for (int i = 0; i < nc; ++i) {
+      const BwdClass& c = cls[i];
+      const int64_t n = (int64_t)Cnp * c.Kp;
+      hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, st, w, wpk_bwd + c.woff,
+                         d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, c.ph, c.pw, c.dminh, c.dminw,
+                         c.ntw > 0 ? c.ntw : 1, Ck, c.K, c.Kp, Cnp, g.cps);
+      SRX_CHECK_LAUNCH("pack_bwd_kernel");
+    }
+  }
+  return SRX_OK;
+}
+
+extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float* wpk, const float* bias, float* y,
+                              float* bn_partials, float* ws, size_t ws_floats, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRX_REQUIRE(x && wpk && y, "conv2d_fwd: null pointer");
+  hipStream_t st = srx_stream(stream);
+  const Geo g = fwd_geo(d);
+  GArgs a{};
+  a.in = x; a.w = wpk; a.bias = bias; a.part = nullptr;
+  set_mgrid(a, d->N, g.Ho, g.Wo);
+  a.Hi = d->H; a.Wi = d->W; a.Ci = d->Cin_s;
+  a.in_stride = d->stride; a.nth = d->KH; a.ntw = d->KW; a.dh0 = -d->pad; a.dw0 = -d->pad;
+  a.Ck = g.Ck; a.K = g.K; a.Kp = g.Kp;
+  a.Cn = d->Cout;
+  a.act = d->act; a.slope = d->slope;
+  a.in_shuffle = 0;
+  if (d->shuffle) {
+    a.out_shuffle = g.cps; a.Cs = d->Cout; a.Ho = 2 * g.Ho; a.Wo = 2 * g.Wo; a.Co = d->Cout_s;
+    a.out_stride = 2; a.oh_off = 0; a.ow_off = 0; a.linear_out = 0;
+  } else {
+    a.out_shuffle = 0; a.Cs = d->Cout_s; a.Ho = g.Ho; a.Wo = g.Wo; a.Co = d->Cout_s;
+    a.out_stride = 1; a.oh_off = 0; a.ow_off = 0; a.linear_out = 1;
+  }
+  const Plan p = fwd_plan(d, g);
+  const bool split = p.nsplit > 1;
+  if (bn_partials && !split) a.part = bn_partials;
+  if (int rc = run_gconv(a, p, y, ws, ws_floats, st)) return rc;
+  if (bn_partials && split) {
+    SRX_REQUIRE(d->Cout_s == d->Cout, "conv2d_fwd: BN statistics need Cout_s == Cout");
+    return srx_bn_partial_stats(y, bn_partials, a.M, d->Cout, stream);
+  }
+  return SRX_OK;
+}
+
+extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx, float* ws,
+                                   size_t ws_floats, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRX_REQUIRE(dy && wpk_bwd && dx, "conv2d_bwd_data: null pointer");
+  SRX_REQUIRE(d->stride <= 4, "conv2d_bwd_data: stride > 4 unsupported");
+  hipStream_t st = srx_stream(stream);
+  const Geo g = fwd_geo(d);
+  BwdClass cls[16];
+  size_t total;
+  const int nc = bwd_classes(d, cls, total);
+  bool any_empty = false;
+  for (int i = 0; i < nc; ++i) any_empty |= (cls[i].K == 0);
+  if (any_empty) {
+    if (hipMemsetAsync(dx, 0, (size_t)d->N * d->H * d->W * d->Cin_s * sizeof(float), st) != hipSuccess)
+      SRX_FAIL(SRX_E_HIP, "conv2d_bwd_data: memset failed");
+  }
+  for (int i = 0; i < nc; ++i) {
+    const BwdClass& c = cls[i];
+    if (c.K == 0 || c.Hm <= 0 || c.Wm <= 0) continue;
+    GArgs a{};
+    a.in = dy; a.w = wpk_bwd + c.woff; a.bias = nullptr; a.part = nullptr;
+    set_mgrid(a, d->N, c.Hm, c.Wm);
+    a.Hi = g.Ho; a.Wi = g.Wo; a.Ci = d->Cout_s;
+    a.in_stride = 1; a.nth = c.nth; a.ntw = c.ntw; a.dh0 = c.dminh; a.dw0 = c.dminw;
+    a.Ck = d->shuffle ? d->Cout : d->Cout_s;
+    a.K = c.K; a.Kp = c.Kp;
+    a.in_shuffle = g.cps;
+    a.Cn = d->Cin; a.Cs = d->Cin_s;
+    a.Ho = d->H; a.Wo = d->W; a.Co = d->Cin_s;
+    a.out_stride = d->stride; a.oh_off = c.ph; a.ow_off = c.pw;
+    a.out_shuffle = 0;
+    a.act = SRX_ACT_NONE; a.slope = 0.f;
+    a.linear_out = (d->stride == 1);
+    if (int rc = run_gconv(a, bwd_plan(d, c), dx, ws, ws_floats, st)) return rc;
+  }
+  return SRX_OK;
+}
+
+extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, const float* dy, float* dw, float* ws,
+                                     size_t ws_floats, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRX_REQUIRE(x && dy && dw && ws, "conv2d_bwd_weight: null pointer");
+  hipStream_t st = srx_stream(stream);
+  const Geo g = fwd_geo(d);
+  WArgs a{};
+  a.in = x; a.dy = dy; a.slab = ws;
+  a.N = d->N; a.Hi = d->H; a.Wi = d->W; a.Ci = d->Cin_s;
+  a.Hm = g.Ho; a.Wm = g.Wo; a.HmWm = g.Ho * g.Wo; a.M = d->N * g.Ho * g.Wo;
+  a.inv_HmWm = 1.0f / (float)a.HmWm; a.inv_Wm = 1.0f / (float)g.Wo;
+  a.in_stride = d->stride; a.nth = d->KH; a.ntw = d->KW; a.dh0 = -d->pad; a.dw0 = -d->pad;
+  a.Ck = g.Ck; a.K = g.K;
+  a.Kw = (int)srx_roundup(g.K, 64);
+  a.Cnw = (int)srx_roundup(d->Cout, 64);
+  a.Cd = d->Cout_s;
+  a.dy_shuffle = g.cps;
+  a.Cdv = d->shuffle ? d->Cout : d->Cout_s;
+  a.ktiles = a.Kw / 64;
+  const int ntiles = a.Cnw / 64;
+  static int cus = 0;
+  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
+  const int64_t tiles = (int64_t)a.ktiles * ntiles;
+  int nsplit = (int)srx_cdiv(4 * cus, tiles);
+  const int max_by_rows = (int)srx_cdiv(a.M, 128);  // at least 128 rows per split
+  if (nsplit > max_by_rows) nsplit = max_by_rows;
+  if (nsplit > 64) nsplit = 64;
+  if (nsplit < 1) nsplit = 1;
+  a.rows_per_split = (int)srx_roundup(srx_cdiv(a.M, nsplit), 32);
+  nsplit = (int)srx_cdiv(a.M, a.rows_per_split);
+  const size_t need = (size_t)nsplit * a.Cnw * a.Kw;
+  if (need > ws_floats) SRX_FAIL(SRX_E_WORKSPACE, "conv2d_bwd_weight: workspace %zu < %zu floats", ws_floats, need);
+  dim3 grid((unsigned)tiles, 1, nsplit);
+  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, a);
+  SRX_CHECK_LAUNCH("wgrad_kernel");
+  const int64_t n = (int64_t)d->Cout * g.K;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, st, ws, nsplit, a.Cnw, a.Kw,
+                     g.K, g.Ck, d->Cout, d->Cin, d->KH, d->KW, g.cps, dw);
+  SRX_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return SRX_OK;
+}

@@ -1,0 +1,236 @@
+// nn.Linear of the discriminator head (srgan/discriminator.py:65-67): batch 16 against a
+// [1024][18432] fp32 weight (75.5 MB).  Every pass streams the weight exactly once, so all
+// three kernels are HBM-bound; the arithmetic rides on v_mfma_f32_16x16x4_f32 with the batch
+// as the 16-wide M (forward / data gradient) or as the contraction (weight gradient), which
+// keeps the VALU free for address generation.  Each lane loads 16 contiguous bytes, a row's
+// 64 or 256 bytes are contiguous across the lanes of one instruction.
+//
+// MFMA 16x16x4 maps: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D: col=l&15, row=4*(l>>4)+reg.
+#include "srx_common.h"
+
+namespace {
+
+// y_partial[z][b][j] = sum_{k in split z} x[b][k] w[j][k]
+// block = 4 waves, one 16-wide j tile; the waves interleave 64-wide k slices.
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ part, int B, int K, int J, int b0,
+                                                         int kper) {
+  __shared__ f32x4 red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, h = lane >> 4;
+  const int j0 = blockIdx.x * 16;
+  const int kbeg = blockIdx.y * kper, kend = min(K, kbeg + kper);
+  const int b = b0 + r, j = j0 + r;
+  const bool bok = b < B, jok = j < J;
+  const float* xr = x + (size_t)(bok ? b : 0) * K;
+  const float* wr = w + (size_t)(jok ? j : 0) * K;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = kbeg + wave * 64; kb < kend; kb += 256) {
+    f32x4 xa[4], wa[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = kb + 16 * t + 4 * h;
+      const bool ok = k < kend;
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + (ok ? k : 0));
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (ok ? k : 0));
+      xa[t] = (ok && bok) ? xv : (f32x4){0.f, 0.f, 0.f, 0.f};
+      wa[t] = (ok && jok) ? wv : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t][e], wa[t][e], acc, 0, 0, 0);
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    f32x4 s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    // D: col = j0 + (lane&15), rows b0 + 4*(lane>>4) + reg
+    const int jj = j0 + r;
+    if (jj < J) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int bb = b0 + 4 * h + e;
+        if (bb < B) part[((size_t)blockIdx.y * B + bb) * J + jj] = s[e];
+      }
+    }
+  }
+}
+
+__global__ void linear_fwd_final_kernel(const float* __restrict__ part, int nsplit, int B, int J,
+                                        const float* __restrict__ bias, int act, float slope, float* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * J) return;
+  float s = 0.f;
+  for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * B * J + i];
+  if (bias) s += bias[i % J];
+  if (act == SRX_ACT_RELU) s = fmaxf(s, 0.f);
+  else if (act == SRX_ACT_LRELU) s = s > 0.f ? s : s * slope;
+  y[i] = s;
+}
+
+// dx_partial[z][b][k] = sum_{j in split z} dy[b][j] w[j][k];  wave = 64 k columns (4 accumulators)
+__global__ __launch_bounds__(256) void linear_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                              float* __restrict__ part, int B, int K, int J, int b0,
+                                                              int jper) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, h = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * 64;
+  if (n0 >= K) return;
+  const int jbeg = blockIdx.y * jper, jend = min(J, jbeg + jper);
+  const int kcol = n0 + 4 * r;
+  const bool kok = kcol < K;
+  const int b = b0 + r;
+  const bool bok = b < B;
+  f32x4 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int jb = jbeg; jb < jend; jb += 16) {
+    float av[4];
+    f32x4 wv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = jb + 4 * t + h;
+      const bool jok = j < jend;
+      const float a = dy[(size_t)(bok ? b : 0) * J + (jok ? j : 0)];
+      av[t] = (jok && bok) ? a : 0.f;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)(jok ? j : 0) * K + (kok ? kcol : 0));
+      wv[t] = (jok && kok) ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], wv[t][e], acc[e], 0, 0, 0);
+  }
+  // acc[e][reg]: row b0 + 4h + reg, column n0 + 4*r + e  -> one float4 per row
+  if (kok) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int bb = b0 + 4 * h + g;
+      if (bb < B) {
+        f32x4 o = {acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.y * B + bb) * K + kcol) = o;
+      }
+    }
+  }
+}
+
+__global__ void sum_slabs_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i * 4 >= n) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(part + i * 4);
+  for (int z = 1; z < nsplit; ++z) s += *reinterpret_cast<const f32x4*>(part + (size_t)z * n + i * 4);
+  *reinterpret_cast<f32x4*>(out + i * 4) = s;
+}
+
+// dw[j][k] = sum_b dy[b][j] x[b][k];  wave = 16 j rows x 64 k columns
+__global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ dy, float* __restrict__ dw,
+                                                                int B, int K, int J) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, h = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * 64;
+  if (n0 >= K) return;
+  const int j0 = blockIdx.y * 16;
+  const int kcol = n0 + 4 * r;
+  const bool kok = kcol < K;
+  const int j = j0 + r;
+  const bool jok = j < J;
+  f32x4 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int bb = 0; bb < B; bb += 4) {
+    const int b = bb + h;
+    const bool bok = b < B;
+    const float a = dy[(size_t)(bok ? b : 0) * J + (jok ? j : 0)];
+    const float av = (bok && jok) ? a : 0.f;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)(bok ? b : 0) * K + (kok ? kcol : 0));
+    const f32x4 xv = (bok && kok) ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xv[e], acc[e], 0, 0, 0);
+  }
+  if (kok) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int jj = j0 + 4 * h + g;
+      if (jj < J) {
+        f32x4 o = {acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
+        *reinterpret_cast<f32x4*>(dw + (size_t)jj * K + kcol) = o;
+      }
+    }
+  }
+}
+
+int fwd_splits(int K, int J, int B) {
+  const int64_t tiles = srx_cdiv(J, 16) * srx_cdiv(B, 16);
+  int64_t s = srx_cdiv(1024, tiles);
+  const int64_t maxs = srx_cdiv(K, 256);
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+int bwd_splits(int K, int J, int B) {
+  const int64_t blocks = srx_cdiv(K, 256) * srx_cdiv(B, 16);
+  int64_t s = srx_cdiv(1024, blocks);
+  const int64_t maxs = srx_cdiv(J, 64);
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+}  // namespace
+
+extern "C" size_t srx_linear_ws_floats(int B, int K, int J) {
+  const size_t f = (size_t)fwd_splits(K, J, B) * B * J;
+  const size_t b = (size_t)bwd_splits(K, J, B) * B * K;
+  return f > b ? f : b;
+}
+
+extern "C" int srx_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int J, int act,
+                              float slope, float* ws, size_t ws_floats, void* stream) {
+  SRX_REQUIRE(x && w && y && ws && B > 0 && K > 0 && J > 0, "linear_fwd: bad argument");
+  SRX_REQUIRE(K % 4 == 0, "linear_fwd: in_features must be a multiple of 4");
+  const int ns = fwd_splits(K, J, B);
+  if ((size_t)ns * B * J > ws_floats) SRX_FAIL(SRX_E_WORKSPACE, "linear_fwd: workspace too small");
+  const int kper = (int)srx_roundup(srx_cdiv(K, ns), 256);
+  const int nsplit = (int)srx_cdiv(K, kper);
+  hipStream_t st = srx_stream(stream);
+  for (int b0 = 0; b0 < B; b0 += 16) {
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)srx_cdiv(J, 16), nsplit), dim3(256), 0, st, x, w, ws, B, K, J,
+                       b0, kper);
+    SRX_CHECK_LAUNCH("linear_fwd_kernel");
+  }
+  hipLaunchKernelGGL(linear_fwd_final_kernel, dim3((unsigned)srx_cdiv((int64_t)B * J, 256)), dim3(256), 0, st, ws,
+                     nsplit, B, J, bias, act, slope, y);
+  SRX_CHECK_LAUNCH("linear_fwd_final_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int K, int J, float* ws,
+                                   size_t ws_floats, void* stream) {
+  SRX_REQUIRE(dy && w && dx && ws && B > 0 && K > 0 && J > 0, "linear_bwd_data: bad argument");
+  SRX_REQUIRE(K % 4 == 0, "linear_bwd_data: in_features must be a multiple of 4");
+  const int ns = bwd_splits(K, J, B);
+  if ((size_t)ns * B * K > ws_floats) SRX_FAIL(SRX_E_WORKSPACE, "linear_bwd_data: workspace too small");
+  const int jper = (int)srx_roundup(srx_cdiv(J, ns), 16);
+  const int nsplit = (int)srx_cdiv(J, jper);
+  hipStream_t st = srx_stream(stream);
+  for (int b0 = 0; b0 < B; b0 += 16) {
+    hipLaunchKernelGGL(linear_bwd_data_kernel, dim3((unsigned)srx_cdiv(K, 256), nsplit), dim3(256), 0, st, dy, w, ws, B,
+                       K, J, b0, jper);
+    SRX_CHECK_LAUNCH("linear_bwd_data_kernel");
+  }
+  const int64_t n = (int64_t)B * K;
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)srx_cdiv(n / 4, 256)), dim3(256), 0, st, ws, nsplit, n, dx);
+  SRX_CHECK_LAUNCH("sum_slabs_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_linear_bwd_weight(const float* x, const float* dy, float* dw, int B, int K, int J, void* stream) {
+  SRX_REQUIRE(x && dy && dw && B > 0 && K > 0 && J > 0, "linear_bwd_weight: bad argument");
+  SRX_REQUIRE(K % 4 == 0, "linear_bwd_weight: in_features must be a multiple of 4");
+  hipLaunchKernelGGL(linear_bwd_weight_kernel, dim3((unsigned)srx_cdiv(K, 256), (unsigned)srx_cdiv(J, 16)), dim3(256),
+                     0, srx_stream(stream), x, dy, dw, B, K, J);
+  SRX_CHECK_LAUNCH("linear_bwd_weight_kernel");
+  return SRX_OK;
+}

@@ -1,0 +1,294 @@
+// Training / eval BatchNorm2d on NHWC fp32 activations, fused with the activation
+// (PReLU / LeakyReLU) and the residual add that follow it in the reference graphs
+// (srgan/residual.py:64-68,86-91; srgan/generator.py:48-49,77-78;
+//  srgan/discriminator.py:35-61).  All kernels are HBM-bound streaming passes with
+// 16-byte accesses; reductions are two-stage (per row block, then a tiny finalize)
+// so results are bitwise reproducible -- no float atomics.
+#include "srx_common.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 256;
+
+__device__ __forceinline__ float act_fwd(float z, int act, float slope) {
+  if (act == SRX_ACT_NONE) return z;
+  if (act == SRX_ACT_RELU) return fmaxf(z, 0.f);
+  return z > 0.f ? z : z * slope;  // LRELU / PRELU
+}
+__device__ __forceinline__ float act_grad(float z, int act, float slope) {
+  if (act == SRX_ACT_NONE) return 1.f;
+  if (act == SRX_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  return z > 0.f ? 1.f : slope;
+}
+
+// per row block: partial[b][c][0] = sum, partial[b][c][1] = sum of squares
+__global__ __launch_bounds__(256) void bn_partial_stats_kernel(const float* __restrict__ y, float* __restrict__ part,
+                                                               int64_t M, int C) {
+  __shared__ f32x4 red[2][256];
+  const int cq = C / 4, nrl = 256 / cq;
+  const int tid = threadIdx.x;
+  const int q = tid % cq, rl = tid / cq;
+  const int64_t rbeg = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  const int64_t rend = min(M, rbeg + ROWS_PER_BLOCK);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  if (rl < nrl) {
+    for (int64_t r = rbeg + rl; r < rend; r += nrl) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + q * 4);
+      s += v;
+      s2 += v * v;
+    }
+  }
+  red[0][tid] = s;
+  red[1][tid] = s2;
+  __syncthreads();
+  if (tid < cq) {
+    f32x4 t = red[0][tid], t2 = red[1][tid];
+    for (int k = 1; k < nrl; ++k) { t += red[0][tid + k * cq]; t2 += red[1][tid + k * cq]; }
+    float* o = part + ((size_t)blockIdx.x * C + tid * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] = t[e]; o[2 * e + 1] = t2[e]; }
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int rows, int64_t M, int C, float eps, float mom,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, int64_t* __restrict__ nbt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double s = 0.0, s2 = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    s += (double)part[((size_t)r * C + c) * 2];
+    s2 += (double)part[((size_t)r * C + c) * 2 + 1];
+  }
+  const double mu = s / (double)M;
+  double var = s2 / (double)M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    rmean[c] = (float)((1.0 - mom) * (double)rmean[c] + mom * mu);
+    rvar[c] = (float)((1.0 - mom) * (double)rvar[c] + mom * unbiased);
+  }
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, int C, float eps,
+                                     float* __restrict__ mean, float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rmean[c];
+  invstd[c] = 1.0f / sqrtf(rvar[c] + eps);
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ res,
+                                                         float* __restrict__ out, int64_t n4, int cq, int act,
+                                                         float slope, const float* __restrict__ prelu) {
+  if (act == SRX_ACT_PRELU) slope = prelu[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cq) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = act_fwd((v[e] - mu[e]) * (is[e] * g[e]) + b[e], act, slope);
+    if (res) o += *reinterpret_cast<const f32x4*>(res + i * 4);
+    *reinterpret_cast<f32x4*>(out + i * 4) = o;
+  }
+}
+
+// backward pass 1: per row block partial sums of dz, dz*xhat (per channel) and of the PReLU slope gradient
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ ws,
+                                                            int64_t M, int C, int act, float slope,
+                                                            const float* __restrict__ prelu) {
+  __shared__ f32x4 red[2][256];
+  __shared__ float redp[256];
+  if (act == SRX_ACT_PRELU) slope = prelu[0];
+  const int cq = C / 4, nrl = 256 / cq;
+  const int tid = threadIdx.x;
+  const int q = tid % cq, rl = tid / cq;
+  const int64_t rbeg = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  const int64_t rend = min(M, rbeg + ROWS_PER_BLOCK);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  float sp = 0.f;
+  if (rl < nrl) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + q * 4);
+    for (int64_t r = rbeg + rl; r < rend; r += nrl) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + q * 4);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dout + r * C + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (v[e] - mu[e]) * is[e];
+        const float z = xh * g[e] + b[e];
+        const float dz = d[e] * act_grad(z, act, slope);
+        s[e] += dz;
+        s2[e] += dz * xh;
+        if (act == SRX_ACT_PRELU && !(z > 0.f)) sp += d[e] * z;
+      }
+    }
+  }
+  red[0][tid] = s;
+  red[1][tid] = s2;
+  redp[tid] = sp;
+  __syncthreads();
+  float* o = ws + (size_t)blockIdx.x * (2 * C + 4);
+  if (tid < cq) {
+    f32x4 t = red[0][tid], t2 = red[1][tid];
+    for (int k = 1; k < nrl; ++k) { t += red[0][tid + k * cq]; t2 += red[1][tid + k * cq]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[tid * 4 + e] = t[e]; o[C + tid * 4 + e] = t2[e]; }
+  }
+  if (tid == 0) {
+    float t = 0.f;
+    for (int k = 0; k < 256; ++k) t += redp[k];
+    o[2 * C] = t;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ ws, int rows, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > 2 * C) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)ws[(size_t)r * (2 * C + 4) + c];
+  sums[c] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ sums, float* __restrict__ dy,
+                                                           int64_t n4, int C, float invM, int act, float slope,
+                                                           const float* __restrict__ prelu, int training) {
+  if (act == SRX_ACT_PRELU) slope = prelu[0];
+  const int cq = C / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cq) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dout + i * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 sd = {0.f, 0.f, 0.f, 0.f}, sx = {0.f, 0.f, 0.f, 0.f};
+    if (training) {
+      sd = *reinterpret_cast<const f32x4*>(sums + c);
+      sx = *reinterpret_cast<const f32x4*>(sums + C + c);
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (v[e] - mu[e]) * is[e];
+      const float z = xh * g[e] + b[e];
+      const float dz = d[e] * act_grad(z, act, slope);
+      o[e] = g[e] * is[e] * (dz - sd[e] * invM - xh * sx[e] * invM);
+    }
+    *reinterpret_cast<f32x4*>(dy + i * 4) = o;
+  }
+}
+
+int check_c(int C, const char* who) {
+  SRX_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024, "%s: C must be a multiple of 4 in [4,1024]", who);
+  return SRX_OK;
+}
+
+unsigned stream_grid(int64_t n4) {
+  int64_t b = srx_cdiv(n4, 256);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int srx_bn_stat_rows(int64_t M) { return (int)srx_cdiv(M, ROWS_PER_BLOCK); }
+
+extern "C" int srx_bn_partial_stats(const float* y, float* partials, int64_t M, int C, void* stream) {
+  if (int rc = check_c(C, "bn_partial_stats")) return rc;
+  SRX_REQUIRE(y && partials && M > 0, "bn_partial_stats: bad argument");
+  hipLaunchKernelGGL(bn_partial_stats_kernel, dim3((unsigned)srx_bn_stat_rows(M)), dim3(256), 0, srx_stream(stream), y,
+                     partials, M, C);
+  SRX_CHECK_LAUNCH("bn_partial_stats_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_bn_finalize(const float* partials, int rows, int64_t M, int C, float eps, float momentum,
+                               float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                               int64_t* nbt, void* stream) {
+  SRX_REQUIRE(partials && save_mean && save_invstd && rows > 0 && M > 0 && C > 0, "bn_finalize: bad argument");
+  SRX_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)srx_cdiv(C, 64)), dim3(64), 0, srx_stream(stream), partials,
+                     rows, M, C, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
+  SRX_CHECK_LAUNCH("bn_finalize_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps,
+                                 float* save_mean, float* save_invstd, void* stream) {
+  SRX_REQUIRE(running_mean && running_var && save_mean && save_invstd && C > 0, "bn_eval_stats: bad argument");
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((unsigned)srx_cdiv(C, 64)), dim3(64), 0, srx_stream(stream),
+                     running_mean, running_var, C, eps, save_mean, save_invstd);
+  SRX_CHECK_LAUNCH("bn_eval_stats_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_bn_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, const float* residual, float* out, int64_t M, int C, int act,
+                              float slope, const float* prelu, void* stream) {
+  if (int rc = check_c(C, "bn_act_fwd")) return rc;
+  SRX_REQUIRE(y && mean && invstd && gamma && beta && out && M > 0, "bn_act_fwd: bad argument");
+  SRX_REQUIRE(act != SRX_ACT_PRELU || prelu, "bn_act_fwd: PReLU needs its slope pointer");
+  const int64_t n4 = M * C / 4;
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_grid(n4)), dim3(256), 0, srx_stream(stream), y, mean, invstd, gamma,
+                     beta, residual, out, n4, C / 4, act, slope, prelu);
+  SRX_CHECK_LAUNCH("bn_act_fwd_kernel");
+  return SRX_OK;
+}
+
+extern "C" size_t srx_bn_bwd_ws_floats(int64_t M, int C) { return (size_t)srx_bn_stat_rows(M) * (2 * C + 4); }
+
+extern "C" int srx_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, float* sums, int64_t M, int C, int act,
+                                     float slope, const float* prelu, float* ws, size_t ws_floats, void* stream) {
+  if (int rc = check_c(C, "bn_act_bwd_reduce")) return rc;
+  SRX_REQUIRE(dout && y && mean && invstd && gamma && beta && sums && ws && M > 0, "bn_act_bwd_reduce: bad argument");
+  SRX_REQUIRE(act != SRX_ACT_PRELU || prelu, "bn_act_bwd_reduce: PReLU needs its slope pointer");
+  if (ws_floats < srx_bn_bwd_ws_floats(M, C)) SRX_FAIL(SRX_E_WORKSPACE, "bn_act_bwd_reduce: workspace too small");
+  const int rows = srx_bn_stat_rows(M);
+  hipStream_t st = srx_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, dout, y, mean, invstd, gamma, beta,
+                     ws, M, C, act, slope, prelu);
+  SRX_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)srx_cdiv(2 * C + 1, 64)), dim3(64), 0, st, ws, rows, C,
+                     sums);
+  SRX_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* invstd,
+                                    const float* gamma, const float* beta, const float* sums, float* dy, int64_t M,
+                                    int C, int act, float slope, const float* prelu, int training, void* stream) {
+  if (int rc = check_c(C, "bn_act_bwd_apply")) return rc;
+  SRX_REQUIRE(dout && y && mean && invstd && gamma && beta && dy && M > 0, "bn_act_bwd_apply: bad argument");
+  SRX_REQUIRE(!training || sums, "bn_act_bwd_apply: training mode needs the reduced sums");
+  SRX_REQUIRE(act != SRX_ACT_PRELU || prelu, "bn_act_bwd_apply: PReLU needs its slope pointer");
+  const int64_t n4 = M * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, srx_stream(stream), dout, y, mean,
+                     invstd, gamma, beta, sums, dy, n4, C, 1.0f / (float)M, act, slope, prelu, training);
+  SRX_CHECK_LAUNCH("bn_bwd_apply_kernel");
+  return SRX_OK;
+}

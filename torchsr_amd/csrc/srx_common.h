@@ -1,0 +1,47 @@
+// Internal helpers shared by the HIP translation units of libsrx_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/srx.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// thread-local error message (srx_last_error)
+void srx_set_error(const char* fmt, ...);
+
+#define SRX_FAIL(code, ...)      \
+  do {                           \
+    srx_set_error(__VA_ARGS__);  \
+    return (code);               \
+  } while (0)
+
+#define SRX_REQUIRE(cond, ...) \
+  do {                         \
+    if (!(cond)) SRX_FAIL(SRX_E_BADARG, __VA_ARGS__); \
+  } while (0)
+
+#define SRX_CHECK_LAUNCH(name)                                                        \
+  do {                                                                                \
+    hipError_t e__ = hipGetLastError();                                               \
+    if (e__ != hipSuccess) SRX_FAIL(SRX_E_HIP, "%s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline hipStream_t srx_stream(void* s) { return (hipStream_t)s; }
+static inline int64_t srx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t srx_roundup(int64_t a, int64_t b) { return srx_cdiv(a, b) * b; }
+
+// m < 2^24 assumed (checked on the host).  q = m / d, r = m % d with one float multiply.
+__device__ __forceinline__ void srx_divmod(int m, int d, float inv_d, int& q, int& r) {
+  q = __float2int_rz(__int2float_rn(m) * inv_d);
+  r = m - q * d;
+  if (r < 0) { q -= 1; r += d; }
+  if (r >= d) { q += 1; r -= d; }
+}
+
+__device__ __forceinline__ float srx_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

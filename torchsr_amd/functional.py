@@ -1,0 +1,550 @@
+"""Host-side operators: ``torch.autograd.Function`` wrappers around the C-ABI HIP kernels.
+
+PyTorch is plumbing here (device memory via the caching allocator, the current
+stream, the autograd tape); every device computation on the hot path is a
+hand-written gfx950 kernel reached through ``_lib.call``.  Activations are NHWC
+fp32 tensors ``[N, H, W, C_s]``; parameters keep the reference's layouts.
+
+Nothing in this module falls back to CPU or to ATen kernels for the hot ops:
+non-CUDA inputs raise.
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, Conv2dDesc, call
+
+import ctypes as C
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: Tensor, what: str) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f'{what}: expected a tensor on the MI355X (cuda) device, got {t.device}; '
+                           'torchsr_amd has no CPU fallback')
+    if t.dtype != torch.float32:
+        raise RuntimeError(f'{what}: expected float32, got {t.dtype}')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(n: int, like: Tensor) -> Tensor:
+    return torch.empty(max(int(n), 4), dtype=torch.float32, device=like.device)
+
+
+def round4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+# --------------------------------------------------------------------------- layout
+class _ToNHWC(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, cs: int) -> Tensor:
+        x = _chk(x, 'to_nhwc')
+        n, c, h, w = x.shape
+        ctx.c = c
+        y = torch.empty((n, h, w, cs), dtype=torch.float32, device=x.device)
+        call('srx_nchw_to_nhwc', _p(x), _p(y), n, c, h, w, cs, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        dy = _chk(dy, 'to_nhwc.bwd')
+        n, h, w, cs = dy.shape
+        dx = torch.empty((n, ctx.c, h, w), dtype=torch.float32, device=dy.device)
+        call('srx_nhwc_to_nchw', _p(dy), _p(dx), n, ctx.c, h, w, cs, _stream())
+        return dx, None
+
+
+class _ToNCHW(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, c: int) -> Tensor:
+        x = _chk(x, 'to_nchw')
+        n, h, w, cs = x.shape
+        ctx.cs = cs
+        y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        call('srx_nhwc_to_nchw', _p(x), _p(y), n, c, h, w, cs, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        dy = _chk(dy, 'to_nchw.bwd')
+        n, c, h, w = dy.shape
+        dx = torch.empty((n, h, w, ctx.cs), dtype=torch.float32, device=dy.device)
+        call('srx_nchw_to_nhwc', _p(dy), _p(dx), n, c, h, w, ctx.cs, _stream())
+        return dx, None
+
+
+def to_nhwc(x: Tensor, cs: Optional[int] = None) -> Tensor:
+    """NCHW ``[N,C,H,W]`` -> NHWC ``[N,H,W,cs]`` (extra channels zero)."""
+    return _ToNHWC.apply(x, round4(x.shape[1]) if cs is None else cs)
+
+
+def to_nchw(x: Tensor, c: Optional[int] = None) -> Tensor:
+    """NHWC ``[N,H,W,cs]`` -> NCHW ``[N,c,H,W]`` (drops padding channels)."""
+    return _ToNCHW.apply(x, x.shape[3] if c is None else c)
+
+
+def flatten_nchw(x: Tensor) -> Tensor:
+    """``torch.flatten(out, 1)`` of the reference (srgan/discriminator.py:86): (c,h,w) order."""
+    return to_nchw(x).reshape(x.shape[0], -1)
+
+
+# --------------------------------------------------------------------------- conv2d
+class ConvState:
+    """Per-layer host state: geometry descriptors and packed weight copies."""
+
+    def __init__(self, cin, cout, k, stride, pad, shuffle=0, act=ACT_NONE, slope=0.0):
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        self.shuffle, self.act, self.slope = shuffle, act, float(slope)
+        self.cin_s = round4(cin)
+        self.cout_s = round4(cout // 4) if shuffle else round4(cout)
+        self._descs = {}
+        self.wpk_fwd = None
+        self.wpk_bwd = None
+        self._key = None
+
+    def desc(self, n, h, w) -> Conv2dDesc:
+        d = self._descs.get((n, h, w))
+        if d is None:
+            d = Conv2dDesc(n, h, w, self.cin, self.cin_s, self.cout, self.cout_s, self.k, self.k, self.stride,
+                           self.pad, self.shuffle, self.act, self.slope, 0)
+            self._descs[(n, h, w)] = d
+        return d
+
+    def out_shape(self, n, h, w):
+        ho = (h + 2 * self.pad - self.k) // self.stride + 1
+        wo = (w + 2 * self.pad - self.k) // self.stride + 1
+        if self.shuffle:
+            return (n, 2 * ho, 2 * wo, self.cout_s)
+        return (n, ho, wo, self.cout_s)
+
+    def pack(self, weight: Tensor, d: Conv2dDesc, force: bool = False) -> None:
+        """(Re)build the packed copies when the master OIHW weight changed."""
+        key = (weight.data_ptr(), weight._version, _pack_epoch[0])
+        if not force and key == self._key and self.wpk_fwd is not None:
+            return
+        dref = C.byref(d)
+        if self.wpk_fwd is None or self.wpk_fwd.device != weight.device:
+            self.wpk_fwd = torch.empty(_lib.lib().srx_conv2d_packed_fwd_floats(dref), dtype=torch.float32,
+                                       device=weight.device)
+            self.wpk_bwd = torch.empty(max(_lib.lib().srx_conv2d_packed_bwd_floats(dref), 4), dtype=torch.float32,
+                                       device=weight.device)
+        w = _chk(weight.detach(), 'conv2d.weight')
+        call('srx_conv2d_pack', dref, _p(w), _p(self.wpk_fwd), _p(self.wpk_bwd), _stream())
+        self._key = key
+
+
+# bumped by the optimiser (optim.FlatAdam.step) because a raw-pointer update does not
+# touch ``Tensor._version``
+_pack_epoch = [0]
+
+
+def bump_pack_epoch() -> None:
+    _pack_epoch[0] += 1
+
+
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], st: ConvState, want_stats: bool):
+        x = _chk(x, 'conv2d.input')
+        n, h, w, cs = x.shape
+        if cs != st.cin_s:
+            raise RuntimeError(f'conv2d: input has {cs} channels (stride), layer expects {st.cin_s}')
+        d = st.desc(n, h, w)
+        dref = C.byref(d)
+        st.pack(weight, d)
+        L = _lib.lib()
+        y = torch.empty(st.out_shape(n, h, w), dtype=torch.float32, device=x.device)
+        part = None
+        if want_stats:
+            rows = L.srx_conv2d_stat_rows(dref)
+            part = torch.empty((rows, st.cout, 2), dtype=torch.float32, device=x.device)
+        nws = L.srx_conv2d_fwd_ws_floats(dref)
+        ws = _ws(nws, x) if nws else None
+        b = None if bias is None else _chk(bias.detach(), 'conv2d.bias')
+        call('srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(b), _p(y), _p(part), _p(ws), nws, _stream())
+        ctx.st, ctx.d = st, d
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, y if st.act != ACT_NONE else None)
+        ctx.wpk_bwd = st.wpk_bwd
+        if want_stats:
+            ctx.mark_non_differentiable(part)
+            return y, part
+        return y, None
+
+    @staticmethod
+    def backward(ctx, dy: Tensor, _dpart):
+        st, d = ctx.st, ctx.d
+        dref = C.byref(d)
+        L = _lib.lib()
+        x, y = ctx.saved_tensors
+        dy = _chk(dy, 'conv2d.grad')
+        s = _stream()
+        if st.act != ACT_NONE:
+            g = torch.empty_like(dy)
+            call('srx_act_bwd_from_out', _p(dy), _p(y), _p(g), dy.numel(), st.act, st.slope, s)
+            dy = g
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            nws = L.srx_conv2d_bwd_data_ws_floats(dref)
+            ws = _ws(nws, x) if nws else None
+            call('srx_conv2d_bwd_data', dref, _p(dy), _p(ctx.wpk_bwd), _p(dx), _p(ws), nws, s)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((st.cout, st.cin, st.k, st.k), dtype=torch.float32, device=x.device)
+            nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
+            ws = _ws(nws, x)
+            call('srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw), _p(ws), nws, s)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if st.shuffle:
+                # dy is [N, 2Ho, 2Wo, cps]; bias index co = c*4 + i*2 + j
+                n, h2, w2, cps = dy.shape
+                rows, cols = n * (h2 // 2), 2 * w2 * cps
+                t = torch.empty(cols, dtype=torch.float32, device=dy.device)
+                nws = L.srx_colsum_ws_floats(rows, cols)
+                call('srx_colsum', _p(dy), _p(t), rows, cols, cols, _p(_ws(nws, dy)), nws, s)
+                # t is [i][wo][j][c]; fold wo (tiny tensor, plumbing) and permute to (c,i,j)
+                db = t.view(2, w2 // 2, 2, cps).sum(1).permute(2, 0, 1).reshape(-1)[:st.cout].contiguous()
+            else:
+                m = dy.numel() // st.cout_s
+                db = torch.empty(st.cout, dtype=torch.float32, device=dy.device)
+                nws = L.srx_colsum_ws_floats(m, st.cout)
+                call('srx_colsum', _p(dy), _p(db), m, st.cout, st.cout_s, _p(_ws(nws, dy)), nws, s)
+        return dx, dw, db, None, None
+
+
+def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], st: ConvState,
+           want_stats: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """NHWC conv.  Returns ``(y, bn_partials)``; ``bn_partials`` is ``None`` unless requested."""
+    return _Conv2d.apply(x, weight, bias, st, want_stats)
+
+
+# --------------------------------------------------------------------------- batch norm (+act, +residual)
+class _BNAct(Function):
+    @staticmethod
+    def forward(ctx, y: Tensor, part: Optional[Tensor], gamma: Tensor, beta: Tensor, prelu: Optional[Tensor],
+                residual: Optional[Tensor], running_mean: Tensor, running_var: Tensor, nbt: Optional[Tensor],
+                training: bool, eps: float, momentum: float, act: int, slope: float):
+        y = _chk(y, 'bn.input')
+        c = y.shape[-1]
+        m = y.numel() // c
+        s = _stream()
+        mean = torch.empty(c, dtype=torch.float32, device=y.device)
+        invstd = torch.empty(c, dtype=torch.float32, device=y.device)
+        if training:
+            if part is None:
+                rows = _lib.lib().srx_bn_stat_rows(m)
+                part = torch.empty((rows, c, 2), dtype=torch.float32, device=y.device)
+                call('srx_bn_partial_stats', _p(y), _p(part), m, c, s)
+            call('srx_bn_finalize', _p(part), part.shape[0], m, c, eps, momentum, _p(mean), _p(invstd),
+                 _p(running_mean), _p(running_var), _p(nbt), s)
+        else:
+            call('srx_bn_eval_stats', _p(running_mean), _p(running_var), c, eps, _p(mean), _p(invstd), s)
+        g = _chk(gamma.detach(), 'bn.weight')
+        b = _chk(beta.detach(), 'bn.bias')
+        pw = None if prelu is None else _chk(prelu.detach(), 'prelu.weight')
+        res = None if residual is None else _chk(residual, 'bn.residual')
+        out = torch.empty_like(y)
+        call('srx_bn_act_fwd', _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), m, c, act, slope, _p(pw), s)
+        ctx.save_for_backward(y, mean, invstd, g, b, pw)
+        ctx.cfg = (m, c, act, slope, training, residual is not None, prelu is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        y, mean, invstd, g, b, pw = ctx.saved_tensors
+        m, c, act, slope, training, has_res, has_prelu = ctx.cfg
+        dout = _chk(dout, 'bn.grad')
+        s = _stream()
+        sums = torch.empty(2 * c + 4, dtype=torch.float32, device=y.device)
+        nws = _lib.lib().srx_bn_bwd_ws_floats(m, c)
+        call('srx_bn_act_bwd_reduce', _p(dout), _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(sums), m, c, act, slope,
+             _p(pw), _p(_ws(nws, y)), nws, s)
+        dy = None
+        if ctx.needs_input_grad[0]:
+            dy = torch.empty_like(y)
+            call('srx_bn_act_bwd_apply', _p(dout), _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(sums), _p(dy), m, c,
+                 act, slope, _p(pw), 1 if training else 0, s)
+        dgamma = sums[c:2 * c] if ctx.needs_input_grad[2] else None
+        dbeta = sums[:c] if ctx.needs_input_grad[3] else None
+        dprelu = sums[2 * c:2 * c + 1] if (has_prelu and ctx.needs_input_grad[4]) else None
+        dres = dout if (has_res and ctx.needs_input_grad[5]) else None
+        return dy, None, dgamma, dbeta, dprelu, dres, None, None, None, None, None, None, None, None
+
+
+def bn_act(y, part, bn, act=ACT_NONE, slope=0.0, prelu: Optional[Tensor] = None,
+           residual: Optional[Tensor] = None) -> Tensor:
+    """``act(BatchNorm2d(y)) [+ residual]`` with ``bn`` an ``nn.BatchNorm2d``-compatible module."""
+    training = bn.training or bn.running_mean is None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _BNAct.apply(y, part, bn.weight, bn.bias, prelu, residual, bn.running_mean, bn.running_var,
+                        bn.num_batches_tracked if training else None, training, bn.eps, momentum, act, float(slope))
+
+
+# --------------------------------------------------------------------------- activations
+class _PReLU(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor):
+        x = _chk(x, 'prelu.input')
+        wd = _chk(w.detach(), 'prelu.weight')
+        y = torch.empty_like(x)
+        call('srx_prelu_fwd', _p(x), _p(wd), _p(y), x.numel(), _stream())
+        ctx.save_for_backward(x, wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, w = ctx.saved_tensors
+        dy = _chk(dy, 'prelu.grad')
+        dx = torch.empty_like(x)
+        dw = torch.empty(1, dtype=torch.float32, device=x.device)
+        call('srx_prelu_bwd', _p(dy), _p(x), _p(w), _p(dx), _p(dw), x.numel(), _p(_ws(1024, x)), _stream())
+        return dx, dw
+
+
+def prelu(x: Tensor, w: Tensor) -> Tensor:
+    if w.numel() != 1:
+        raise RuntimeError('prelu: only the single-slope nn.PReLU() of the reference is implemented')
+    return _PReLU.apply(x, w)
+
+
+class _LReLU(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, slope: float):
+        x = _chk(x, 'lrelu.input')
+        y = torch.empty_like(x)
+        call('srx_lrelu_fwd', _p(x), _p(y), x.numel(), slope, _stream())
+        ctx.slope = slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        (y,) = ctx.saved_tensors
+        dy = _chk(dy, 'lrelu.grad')
+        dx = torch.empty_like(dy)
+        call('srx_act_bwd_from_out', _p(dy), _p(y), _p(dx), dy.numel(), ACT_LRELU, ctx.slope, _stream())
+        return dx, None
+
+
+def leaky_relu(x: Tensor, slope: float) -> Tensor:
+    return _LReLU.apply(x, float(slope))
+
+
+class _Sigmoid(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        x = _chk(x, 'sigmoid.input')
+        y = torch.empty_like(x)
+        call('srx_sigmoid_fwd', _p(x), _p(y), x.numel(), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        (y,) = ctx.saved_tensors
+        dy = _chk(dy, 'sigmoid.grad')
+        dx = torch.empty_like(y)
+        call('srx_sigmoid_bwd', _p(dy), _p(y), _p(dx), y.numel(), _stream())
+        return dx
+
+
+def sigmoid(x: Tensor) -> Tensor:
+    return _Sigmoid.apply(x)
+
+
+class _Axpby(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, z: Tensor, a: float, b: float):
+        x, z = _chk(x, 'axpby.x'), _chk(z, 'axpby.z')
+        y = torch.empty_like(x)
+        call('srx_axpby', _p(x), _p(z), _p(y), x.numel(), a, b, _stream())
+        ctx.ab = (a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        a, b = ctx.ab
+        dy = _chk(dy, 'axpby.grad')
+        s = _stream()
+        dx = dz = None
+        if ctx.needs_input_grad[0]:
+            dx = dy if a == 1.0 else torch.empty_like(dy)
+            if a != 1.0:
+                call('srx_axpby', _p(dy), _p(dy), _p(dx), dy.numel(), a, 0.0, s)
+        if ctx.needs_input_grad[1]:
+            dz = dy if b == 1.0 else torch.empty_like(dy)
+            if b != 1.0:
+                call('srx_axpby', _p(dy), _p(dy), _p(dz), dy.numel(), b, 0.0, s)
+        return dx, dz, None, None
+
+
+def axpby(x: Tensor, z: Tensor, a: float = 1.0, b: float = 1.0) -> Tensor:
+    """``a*x + b*z`` (residual adds / scalings)."""
+    return _Axpby.apply(x, z, float(a), float(b))
+
+
+# --------------------------------------------------------------------------- pooling
+class _MaxPool(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        x = _chk(x, 'maxpool.input')
+        n, h, w, c = x.shape
+        y = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+        call('srx_maxpool2x2_fwd', _p(x), _p(y), n, h, w, c, _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        (x,) = ctx.saved_tensors
+        dy = _chk(dy, 'maxpool.grad')
+        n, h, w, c = x.shape
+        dx = torch.empty_like(x)
+        call('srx_maxpool2x2_bwd', _p(dy), _p(x), _p(dx), n, h, w, c, _stream())
+        return dx
+
+
+def maxpool2x2(x: Tensor) -> Tensor:
+    return _MaxPool.apply(x)
+
+
+# --------------------------------------------------------------------------- linear
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, bias: Optional[Tensor], act: int, slope: float):
+        x = _chk(x, 'linear.input')
+        wd = _chk(w.detach(), 'linear.weight')
+        bsz, k = x.shape
+        j = wd.shape[0]
+        y = torch.empty((bsz, j), dtype=torch.float32, device=x.device)
+        nws = _lib.lib().srx_linear_ws_floats(bsz, k, j)
+        b = None if bias is None else _chk(bias.detach(), 'linear.bias')
+        call('srx_linear_fwd', _p(x), _p(wd), _p(b), _p(y), bsz, k, j, act, slope, _p(_ws(nws, x)), nws, _stream())
+        ctx.cfg = (bsz, k, j, act, slope, bias is not None, nws)
+        ctx.save_for_backward(x, wd, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, w, y = ctx.saved_tensors
+        bsz, k, j, act, slope, has_bias, nws = ctx.cfg
+        dy = _chk(dy, 'linear.grad')
+        s = _stream()
+        if act != ACT_NONE:
+            g = torch.empty_like(dy)
+            call('srx_act_bwd_from_out', _p(dy), _p(y), _p(g), dy.numel(), act, slope, s)
+            dy = g
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call('srx_linear_bwd_data', _p(dy), _p(w), _p(dx), bsz, k, j, _p(_ws(nws, x)), nws, s)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            call('srx_linear_bwd_weight', _p(x), _p(dy), _p(dw), bsz, k, j, s)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(j, dtype=torch.float32, device=x.device)
+            n2 = _lib.lib().srx_colsum_ws_floats(bsz, j)
+            call('srx_colsum', _p(dy), _p(db), bsz, j, j, _p(_ws(n2, x)), n2, s)
+        return dx, dw, db, None, None
+
+
+def linear(x: Tensor, w: Tensor, bias: Optional[Tensor], act: int = ACT_NONE, slope: float = 0.0) -> Tensor:
+    return _Linear.apply(x, w, bias, act, float(slope))
+
+
+# --------------------------------------------------------------------------- losses
+class _PairLoss(Function):
+    """mean((a-b)^2) / mean(|a-b|)"""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor, kind: str):
+        a, b = _chk(a, f'{kind}.input'), _chk(b, f'{kind}.target')
+        if a.shape != b.shape:
+            raise RuntimeError(f'{kind}_loss: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}')
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        call(f'srx_{kind}_fwd', _p(a), _p(b), _p(loss), a.numel(), _p(_ws(2048, a)), _stream())
+        ctx.kind = kind
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        a, b = ctx.saved_tensors
+        g = _chk(g, 'loss.grad')
+        da = torch.empty_like(a)
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        call(f'srx_{ctx.kind}_bwd', _p(a), _p(b), _p(g), _p(da), _p(db), a.numel(), _stream())
+        return (da if ctx.needs_input_grad[0] else None), db, None
+
+
+def mse_loss(a: Tensor, b: Tensor) -> Tensor:
+    """nn.MSELoss() (srgan/trainer.py:163)."""
+    return _PairLoss.apply(a, b, 'mse')
+
+
+def l1_loss(a: Tensor, b: Tensor) -> Tensor:
+    """F.l1_loss / nn.L1Loss() (srgan/loss.py:52)."""
+    return _PairLoss.apply(a, b, 'l1')
+
+
+class _BCE(Function):
+    @staticmethod
+    def forward(ctx, p: Tensor, target: float):
+        p = _chk(p, 'bce.input')
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        call('srx_bce_fwd', _p(p), target, _p(loss), p.numel(), _p(_ws(2048, p)), _stream())
+        ctx.target = target
+        ctx.save_for_backward(p)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (p,) = ctx.saved_tensors
+        g = _chk(g, 'bce.grad')
+        dp = torch.empty_like(p)
+        call('srx_bce_bwd', _p(p), ctx.target, _p(g), _p(dp), p.numel(), _stream())
+        return dp, None
+
+
+def bce_loss(p: Tensor, target: float) -> Tensor:
+    """nn.BCELoss() against a constant label tensor (srgan/trainer.py:439-447)."""
+    return _BCE.apply(p, float(target))
+
+
+class _BCELogits(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, shift: Optional[Tensor], target: float):
+        x = _chk(x, 'bce_logits.input')
+        sh = None if shift is None else _chk(shift.detach().reshape(1), 'bce_logits.shift')
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        call('srx_bce_logits_fwd', _p(x), _p(sh), target, _p(loss), x.numel(), _p(_ws(2048, x)), _stream())
+        ctx.target = target
+        ctx.save_for_backward(x, sh)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, sh = ctx.saved_tensors
+        g = _chk(g, 'bce_logits.grad')
+        dx = torch.empty_like(x)
+        call('srx_bce_logits_bwd', _p(x), _p(sh), ctx.target, _p(g), _p(dx), x.numel(), _stream())
+        dsh = None
+        if sh is not None and ctx.needs_input_grad[1]:
+            dsh = -dx.sum()  # one scalar; plumbing
+        return dx, dsh, None
+
+
+def bce_with_logits(x: Tensor, target: float, shift: Optional[Tensor] = None) -> Tensor:
+    """nn.BCEWithLogitsLoss()(x - shift, full(target)) (esrgan/trainer.py:451-453)."""
+    return _BCELogits.apply(x, shift, float(target))

@@ -1,0 +1,40 @@
+"""SRGAN generator (SRResNet) -- interface of torchsr/srgan/generator.py:33-81."""
+import math
+
+from torch import nn, Tensor
+
+from .. import functional as F
+from ..layers import BatchNorm2d, Conv2d, PReLU
+from .residual import ResidualBlock, SubpixelConvolutionLayer
+
+NUM_RESIDUAL = 16  # torchsr/srgan/generator.py:20
+
+
+class Generator(nn.Module):
+    """``Generator(scale_factor=4)``; ``forward([N,3,h,w]) -> [N,3,s*h,s*w]`` (unclamped).
+
+    Same submodule names and ``state_dict`` schema as the reference; internally
+    NHWC fp32 on hand-written gfx950 kernels.
+    """
+
+    def __init__(self, scale_factor: int = 4) -> None:
+        super().__init__()
+        num_conv_layers = int(math.log(scale_factor, 2))
+        self.conv1 = nn.Sequential(Conv2d(3, 64, kernel_size=9, stride=1, padding=4), PReLU())
+        self.blocks = nn.Sequential(*[ResidualBlock(channels=64) for _ in range(NUM_RESIDUAL)])
+        self.conv2 = nn.Sequential(Conv2d(64, 64, kernel_size=3, stride=1, padding=1, bias=False), BatchNorm2d(64))
+        self.conv_layers = nn.Sequential(*[SubpixelConvolutionLayer(64) for _ in range(num_conv_layers)])
+        self.conv3 = Conv2d(64, 3, kernel_size=9, stride=1, padding=4)
+
+    def forward_nhwc(self, x4: Tensor) -> Tensor:
+        """NHWC ``[N,h,w,4]`` -> NHWC ``[N,s*h,s*w,4]`` (4th channel zero)."""
+        conv1 = self.conv1[1](self.conv1[0](x4))
+        block = self.blocks(conv1)
+        bn = self.conv2[1]
+        y, part = self.conv2[0](block, want_stats=True) if bn.training else (self.conv2[0](block), None)
+        out = bn(y, part, residual=conv1)  # torch.add(conv1, conv2), generator.py:78
+        out = self.conv_layers(out)
+        return self.conv3(out)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return F.to_nchw(self.forward_nhwc(F.to_nhwc(x, 4)), 3)
