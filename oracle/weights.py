@@ -1,0 +1,64 @@
+"""ORACLE helper: closed-form, key-addressed parameter values.
+
+Golden fixtures must not depend on ``torch.manual_seed`` streams or on module
+construction order, and full-size weights (SRGAN D 94 MB, VGG19 80 MB) must cost
+nothing to store.  Every ``state_dict`` entry is therefore filled, by key name, from
+
+    value[i] = offset(key) + amp(key, shape) * sin(0.37 * i + phase(crc32(key)))
+
+evaluated in float64 and rounded to float32.  The same function fills the imported
+reference modules (``gen_golden.py``) and the modules under test.
+"""
+import zlib
+from typing import Dict
+
+import numpy as np
+import torch
+
+
+def _wave(n: int, key: str, freq: float = 0.37) -> np.ndarray:
+    phase = (zlib.crc32(key.encode()) % 6283) / 1000.0
+    return np.sin(freq * np.arange(n, dtype=np.float64) + phase)
+
+
+def closed_form_tensor(key: str, like: torch.Tensor) -> torch.Tensor:
+    n, shape = like.numel(), tuple(like.shape)
+    leaf = key.split('.')[-1]
+    if leaf == 'num_batches_tracked':
+        return torch.zeros(shape, dtype=like.dtype)
+    w = _wave(n, key)
+    if leaf == 'running_var':
+        v = 1.0 + 0.3 * w
+    elif leaf == 'running_mean':
+        v = 0.1 * w
+    elif leaf == 'weight' and len(shape) == 1 and n == 1:      # nn.PReLU()
+        v = np.full(n, 0.25)
+    elif leaf == 'weight' and len(shape) == 1:                  # BatchNorm gamma
+        v = 1.0 + 0.1 * w
+    elif leaf == 'bias':
+        v = 0.05 * w
+    elif leaf == 'weight':                                      # conv OIHW / linear [out][in]
+        fan_in = int(np.prod(shape[1:]))
+        v = np.sqrt(3.0 / fan_in) * w * 1.4142
+    else:
+        v = 0.1 * w
+    return torch.from_numpy(v.astype(np.float32)).reshape(shape).to(like.dtype)
+
+
+def closed_form_state(template: Dict[str, torch.Tensor], prefix: str = '') -> Dict[str, torch.Tensor]:
+    """A state_dict with the same keys/shapes as ``template`` and closed-form values."""
+    return {k: closed_form_tensor(prefix + k, v) for k, v in template.items()}
+
+
+def seeded_input(shape, seed: int) -> torch.Tensor:
+    """Uniform [0,1) fp32 from a numpy PCG64 stream (stable across torch versions)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(rng.random(shape, dtype=np.float32))
+
+
+def tensor_digest(t: torch.Tensor):
+    """Small order-sensitive summary used for gradients / post-step parameters."""
+    f = t.detach().double().flatten()
+    idx = torch.arange(1, f.numel() + 1, dtype=torch.float64)
+    return np.array([f.sum().item(), f.abs().sum().item(), (f * torch.cos(idx * 0.001)).sum().item(),
+                     f[0].item(), f[-1].item()], dtype=np.float64)

@@ -1,0 +1,300 @@
+"""Parity of every HIP kernel (through the C ABI) against stock torch fp32/fp64 ops on CPU.
+
+Tolerance: north_star asks for 1e-3 relative fp32; the kernels are exact-fp32 MFMA chains,
+so these tests hold them to 2e-4 of the tensor's scale (1e-5 for pure data movement).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+
+def nhwc(x, cs=None):  # cpu NCHW -> cpu NHWC padded
+    n, c, h, w = x.shape
+    cs = cs or (c + 3) // 4 * 4
+    y = torch.zeros(n, h, w, cs)
+    y[..., :c] = x.permute(0, 2, 3, 1)
+    return y.contiguous()
+
+
+def nchw(y, c):
+    return y[..., :c].permute(0, 3, 1, 2).contiguous()
+
+
+def test_layout_roundtrip(dev):
+    from torchsr_amd import functional as F
+    x = rnd((3, 3, 10, 14), 0)
+    y = F.to_nhwc(x.to(dev), 4)
+    assert y.shape == (3, 10, 14, 4)
+    assert torch.equal(y.cpu(), nhwc(x, 4))
+    z = F.to_nchw(y, 3)
+    assert torch.equal(z.cpu(), x)
+    f = F.flatten_nchw(F.to_nhwc(rnd((2, 8, 3, 5), 1).to(dev)))
+    assert torch.equal(f.cpu(), rnd((2, 8, 3, 5), 1).flatten(1))
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, s, p, bias, act, shuffle
+    (2, 24, 24, 64, 64, 3, 1, 1, False, 0, 0),     # SRGAN residual conv (srgan/residual.py:64)
+    (2, 24, 24, 3, 64, 9, 1, 4, True, 0, 0),       # generator conv1 (generator.py:38)
+    (2, 12, 12, 64, 256, 3, 1, 1, True, 0, 2),     # sub-pixel conv + PixelShuffle (residual.py:27-28)
+    (1, 40, 40, 64, 3, 9, 1, 4, True, 0, 0),       # generator conv3 (generator.py:58)
+    (2, 32, 32, 3, 64, 3, 1, 1, True, 2, 0),       # discriminator conv + LeakyReLU (discriminator.py:32-33)
+    (2, 32, 32, 64, 64, 3, 2, 1, False, 0, 0),     # stride 2 (discriminator.py:35)
+    (2, 16, 16, 128, 256, 3, 1, 1, True, 1, 0),    # VGG conv + ReLU
+    (2, 12, 12, 256, 512, 3, 1, 1, False, 0, 0),
+    (2, 6, 6, 512, 512, 3, 1, 1, True, 1, 0),      # small M, deep K: split-K path
+    (2, 12, 12, 512, 512, 3, 2, 1, False, 0, 0),   # last discriminator conv: split-K + BN stats
+    (1, 5, 7, 8, 12, 3, 1, 1, True, 0, 0),         # ragged everything
+    (3, 9, 11, 4, 8, 3, 2, 1, False, 0, 0),        # odd sizes, stride 2
+    (2, 7, 9, 16, 20, 5, 1, 2, True, 0, 0),        # 5x5
+    (1, 8, 8, 32, 32, 1, 1, 0, True, 1, 0),        # 1x1
+    (4, 96, 96, 16, 128, 3, 1, 1, False, 0, 0),    # large M: 128x128 tile
+    (2, 11, 13, 24, 40, 3, 3, 1, True, 0, 0),      # stride 3
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv2d_fwd_bwd(dev, case):
+    from torchsr_amd import functional as F
+    from torchsr_amd.layers import Conv2d
+    n, h, w, cin, cout, k, s, p, bias, act, shuffle = case
+    seed = hash(case) % 1000
+    x = rnd((n, cin, h, w), seed)
+    conv = Conv2d(cin, cout, k, s, p, bias=bias, act=act, slope=0.2, shuffle=shuffle)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(conv.weight.shape, seed + 1) * (2.0 / (cin * k * k)) ** 0.5 * 1.7)
+        if bias:
+            conv.bias.copy_(rnd(conv.bias.shape, seed + 2) * 0.3)
+    wc = conv.weight.detach().clone().requires_grad_(True)
+    bc = conv.bias.detach().clone().requires_grad_(True) if bias else None
+    xc = x.clone().requires_grad_(True)
+    yc = TF.conv2d(xc, wc, bc, s, p)
+    pre = yc
+    if act == 1:
+        yc = TF.relu(yc)
+    elif act == 2:
+        yc = TF.leaky_relu(yc, 0.2)
+    if shuffle:
+        yc = TF.pixel_shuffle(yc, 2)
+    gy = rnd(yc.shape, seed + 3)
+    yc.backward(gy)
+
+    conv = conv.to(dev)
+    xg = nhwc(x).to(dev).requires_grad_(True)
+    want_stats = (not bias) and act == 0 and not shuffle
+    out = conv(xg, want_stats=want_stats)
+    yg, part = out if want_stats else (out, None)
+    cout_l = cout // 4 if shuffle else cout
+    assert rel_err(nchw(yg.cpu(), cout_l), yc) < 2e-4
+    if cout_l % 4:
+        assert float(yg[..., cout_l:].abs().max()) == 0.0
+    if want_stats:
+        m = pre.numel() // cout
+        s1 = part[:, :, 0].sum(0).cpu().double()
+        s2 = part[:, :, 1].sum(0).cpu().double()
+        ref1 = pre.detach().double().sum((0, 2, 3))
+        ref2 = pre.detach().double().square().sum((0, 2, 3))
+        assert ((s1 - ref1).abs().max() / ref2.sqrt().max()).item() < 1e-4
+        assert rel_err(s2, ref2) < 2e-4
+    yg.backward(nhwc(gy, yg.shape[-1]).to(dev))
+    assert rel_err(nchw(xg.grad.cpu(), cin), xc.grad) < 2e-4
+    if cin % 4:
+        assert float(xg.grad[..., cin:].abs().max()) == 0.0
+    assert rel_err(conv.weight.grad, wc.grad) < 2e-4
+    if bias:
+        assert rel_err(conv.bias.grad, bc.grad) < 2e-4
+
+
+@pytest.mark.parametrize('cfg', [(2, 24, 24, 64, 'prelu', True), (2, 12, 12, 128, 'lrelu', False),
+                                 (3, 5, 7, 8, 'none', True), (2, 6, 6, 512, 'lrelu', False)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+@pytest.mark.parametrize('training', [True, False])
+def test_bn_act(dev, cfg, training):
+    from torchsr_amd import functional as F
+    from torchsr_amd.layers import BatchNorm2d
+    from torchsr_amd._lib import ACT_LRELU, ACT_NONE, ACT_PRELU
+    n, h, w, c, act, with_res = cfg
+    y = rnd((n, c, h, w), 5) * 2 + 0.3
+    res = rnd((n, c, h, w), 6) if with_res else None
+    bn_ref = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn_ref.weight.copy_(1 + 0.2 * rnd((c,), 7))
+        bn_ref.bias.copy_(0.1 * rnd((c,), 8))
+        bn_ref.running_mean.copy_(0.1 * rnd((c,), 9))
+        bn_ref.running_var.copy_(1 + 0.3 * rnd((c,), 10))
+    bn = BatchNorm2d(c)
+    bn.load_state_dict(bn_ref.state_dict())
+    slope = torch.tensor([0.25], requires_grad=True)
+    bn_ref.train(training)
+    bn.train(training)
+    yc = y.clone().requires_grad_(True)
+    rc = res.clone().requires_grad_(True) if with_res else None
+    o = bn_ref(yc)
+    if act == 'prelu':
+        o = TF.prelu(o, slope)
+    elif act == 'lrelu':
+        o = TF.leaky_relu(o, 0.2)
+    if with_res:
+        o = o + rc
+    go = rnd(o.shape, 11)
+    o.backward(go)
+
+    bn = bn.to(dev)
+    yg = nhwc(y).to(dev).requires_grad_(True)
+    rg = nhwc(res).to(dev).requires_grad_(True) if with_res else None
+    sg = torch.tensor([0.25], device=dev, requires_grad=True)
+    code = {'prelu': ACT_PRELU, 'lrelu': ACT_LRELU, 'none': ACT_NONE}[act]
+    og = bn(yg, None, act=code, slope=0.2, prelu=sg if act == 'prelu' else None, residual=rg)
+    assert rel_err(nchw(og.cpu(), c), o) < 2e-4
+    og.backward(nhwc(go).to(dev))
+    assert rel_err(nchw(yg.grad.cpu(), c), yc.grad) < 5e-4
+    assert rel_err(bn.weight.grad, bn_ref.weight.grad) < 5e-4
+    assert rel_err(bn.bias.grad, bn_ref.bias.grad) < 5e-4
+    if act == 'prelu':
+        assert rel_err(sg.grad, slope.grad) < 5e-4
+    if with_res:
+        assert rel_err(nchw(rg.grad.cpu(), c), rc.grad) < 1e-6
+    assert rel_err(bn.running_mean, bn_ref.running_mean) < 1e-5
+    assert rel_err(bn.running_var, bn_ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+
+
+def test_activations_and_pool(dev):
+    from torchsr_amd import functional as F
+    x = rnd((2, 16, 10, 12), 20)
+    xg = nhwc(x).to(dev).requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    a = torch.tensor([0.3], requires_grad=True)
+    ag = torch.tensor([0.3], device=dev, requires_grad=True)
+    g = rnd(x.shape, 21)
+    TF.prelu(xc, a).backward(g)
+    y = F.prelu(xg, ag)
+    y.backward(nhwc(g).to(dev))
+    assert rel_err(nchw(y.cpu(), 16), TF.prelu(x, a)) < 1e-6
+    assert rel_err(nchw(xg.grad.cpu(), 16), xc.grad) < 1e-6
+    assert rel_err(ag.grad, a.grad) < 1e-4
+    # leaky relu, sigmoid on an odd-sized tensor
+    v = rnd((7, 1), 22) * 4
+    vg = v.to(dev).requires_grad_(True)
+    vc = v.clone().requires_grad_(True)
+    torch.sigmoid(TF.leaky_relu(vc, 0.2)).sum().backward()
+    F.sigmoid(F.leaky_relu(vg, 0.2)).backward(torch.ones(7, 1, device=dev))
+    assert rel_err(vg.grad, vc.grad) < 1e-5
+    # axpby
+    z = rnd((5, 3), 23)
+    assert rel_err(F.axpby(v[:5].expand(5, 3).contiguous().to(dev), z.to(dev), 0.2, 1.0),
+                   0.2 * v[:5].expand(5, 3) + z) < 1e-6
+    # maxpool
+    xc2 = x.clone().requires_grad_(True)
+    pc = TF.max_pool2d(xc2, 2, 2)
+    gp = rnd(pc.shape, 24)
+    pc.backward(gp)
+    xg2 = nhwc(x).to(dev).requires_grad_(True)
+    pg = F.maxpool2x2(xg2)
+    pg.backward(nhwc(gp).to(dev))
+    assert torch.equal(nchw(pg.cpu(), 16), pc.detach())
+    assert torch.equal(nchw(xg2.grad.cpu(), 16), xc2.grad)
+
+
+@pytest.mark.parametrize('cfg', [(16, 18432, 1024, 2), (16, 1024, 1, 0), (3, 20, 5, 1), (16, 2048, 100, 2),
+                                 (33, 256, 40, 0)], ids=lambda c: 'x'.join(map(str, c)))
+def test_linear(dev, cfg):
+    from torchsr_amd import functional as F
+    b, k, j, act = cfg
+    x = rnd((b, k), 30)
+    w = rnd((j, k), 31) * (1.0 / k) ** 0.5
+    bias = rnd((j,), 32) * 0.1
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yc = TF.linear(xc, wc, bc)
+    if act == 1:
+        yc = TF.relu(yc)
+    elif act == 2:
+        yc = TF.leaky_relu(yc, 0.2)
+    g = rnd(yc.shape, 33)
+    yc.backward(g)
+    xg, wg, bg = (t.clone().to(dev).requires_grad_(True) for t in (x, w, bias))
+    yg = F.linear(xg, wg, bg, act, 0.2)
+    yg.backward(g.to(dev))
+    assert rel_err(yg, yc) < 2e-4
+    assert rel_err(xg.grad, xc.grad) < 2e-4
+    assert rel_err(wg.grad, wc.grad) < 2e-4
+    assert rel_err(bg.grad, bc.grad) < 2e-4
+
+
+def test_losses(dev):
+    from torchsr_amd import functional as F
+    a, b = rnd((2, 3, 17, 19), 40), rnd((2, 3, 17, 19), 41)
+    for ours, ref in [(F.mse_loss, TF.mse_loss), (F.l1_loss, TF.l1_loss)]:
+        ac, bc = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        lc = ref(ac, bc)
+        (lc * 1.7).backward()
+        ag, bgp = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        lg = ours(ag, bgp)
+        F.axpby(lg, lg, 1.7, 0.0).backward()
+        assert rel_err(lg, lc) < 1e-5
+        assert rel_err(ag.grad, ac.grad) < 1e-5
+        assert rel_err(bgp.grad, bc.grad) < 1e-5
+    p = torch.sigmoid(rnd((16, 1), 42) * 6)
+    p[0] = 1.0   # saturated probabilities hit the -100 clamp
+    p[1] = 0.0
+    for t in (0.0, 1.0):
+        pc = p.clone().requires_grad_(True)
+        lc = TF.binary_cross_entropy(pc, torch.full_like(p, t))
+        lc.backward()
+        pg = p.to(dev).requires_grad_(True)
+        lg = F.bce_loss(pg, t)
+        lg.backward()
+        assert rel_err(lg, lc) < 1e-5
+        assert rel_err(pg.grad, pc.grad) < 1e-5
+    x = rnd((16, 1), 43) * 8
+    sh = torch.tensor(0.37)
+    for t in (0.0, 1.0):
+        xc, sc = x.clone().requires_grad_(True), sh.clone().requires_grad_(True)
+        lc = TF.binary_cross_entropy_with_logits(xc - sc, torch.full_like(x, t))
+        lc.backward()
+        xg, sg = x.to(dev).requires_grad_(True), sh.to(dev).requires_grad_(True)
+        lg = F.bce_with_logits(xg, t, sg)
+        lg.backward()
+        assert rel_err(lg, lc) < 1e-5
+        assert rel_err(xg.grad, xc.grad) < 1e-5
+        assert rel_err(sg.grad, sc.grad) < 1e-5
+
+
+def test_adam_matches_torch(dev):
+    from torchsr_amd._lib import call
+    n = 1003
+    p0, g_all = rnd((n,), 50), [rnd((n,), 51 + i) * (10.0 ** -(i % 3)) for i in range(5)]
+    pc = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pc], lr=1e-4, betas=(0.9, 0.999))
+    pad = 1004
+    p = torch.zeros(pad, device=dev)
+    p[:n] = p0.to(dev)
+    g = torch.zeros(pad, device=dev)
+    m, v = torch.zeros(pad, device=dev), torch.zeros(pad, device=dev)
+    step = torch.zeros((), dtype=torch.int64, device=dev)
+    lr = torch.tensor(1e-4, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    for gi in g_all:
+        pc.grad = gi.clone()
+        opt.step()
+        g[:n] = gi.to(dev)
+        call('srx_adam_step', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr.data_ptr(), 0.9, 0.999,
+             1e-8, 1.0, step.data_ptr(), s)
+    assert int(step) == 5
+    assert (p[:n].cpu() - pc.detach()).abs().max().item() < 2e-7
+    assert float(p[n:].abs().max()) == 0.0

@@ -1,0 +1,82 @@
+"""Developer micro-benchmark: time the conv kernels on the layer shapes of the SRGAN step.
+
+    python tools/bench_kernels.py [--reps 20]
+
+Prints per-shape forward / data-gradient / weight-gradient time and TFLOP/s against the
+157.3 TFLOP/s fp32 MFMA peak of MI355X.  Not part of the product or of the judged bench.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torchsr_amd.layers import Conv2d  # noqa: E402
+
+SHAPES = [
+    # name, N, H, W, Cin, Cout, k, s, p, shuffle
+    ('G.res 64->64 @24', 16, 24, 24, 64, 64, 3, 1, 1, 0),
+    ('G.conv1 9x9 3->64 @24', 16, 24, 24, 3, 64, 9, 1, 4, 0),
+    ('G.sub1 64->256 @24', 16, 24, 24, 64, 256, 3, 1, 1, 2),
+    ('G.sub2 64->256 @48', 16, 48, 48, 64, 256, 3, 1, 1, 2),
+    ('G.conv3 9x9 64->3 @96', 16, 96, 96, 64, 3, 9, 1, 4, 0),
+    ('D.c1 3->64 @96', 16, 96, 96, 3, 64, 3, 1, 1, 0),
+    ('D.c2 64->64 s2 @96', 16, 96, 96, 64, 64, 3, 2, 1, 0),
+    ('D.c3 64->128 @48', 16, 48, 48, 64, 128, 3, 1, 1, 0),
+    ('D.c4 128->128 s2 @48', 16, 48, 48, 128, 128, 3, 2, 1, 0),
+    ('D.c5 128->256 @24', 16, 24, 24, 128, 256, 3, 1, 1, 0),
+    ('D.c6 256->256 s2 @24', 16, 24, 24, 256, 256, 3, 2, 1, 0),
+    ('D.c7 256->512 @12', 16, 12, 12, 256, 512, 3, 1, 1, 0),
+    ('D.c8 512->512 s2 @12', 16, 12, 12, 512, 512, 3, 2, 1, 0),
+    ('V.1_2 64->64 @96', 16, 96, 96, 64, 64, 3, 1, 1, 0),
+    ('V.2_2 128->128 @48', 16, 48, 48, 128, 128, 3, 1, 1, 0),
+    ('V.3_2 256->256 @24', 16, 24, 24, 256, 256, 3, 1, 1, 0),
+    ('V.4_2 512->512 @12', 16, 12, 12, 512, 512, 3, 1, 1, 0),
+    ('V.5_2 512->512 @6', 16, 6, 6, 512, 512, 3, 1, 1, 0),
+    ('V.1_2 N=32', 32, 96, 96, 64, 64, 3, 1, 1, 0),
+    ('V.5_2 N=32', 32, 6, 6, 512, 512, 3, 1, 1, 0),
+]
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    print(f'{"layer":26s} {"GF":>7s} | {"fwd us":>8s} {"TF/s":>6s} | {"dgrad us":>8s} {"TF/s":>6s} | {"wgrad us":>8s} {"TF/s":>6s}')
+    for name, n, h, w, cin, cout, k, s, p, sh in SHAPES:
+        conv = Conv2d(cin, cout, k, s, p, bias=False, shuffle=sh).to(dev)
+        cin_s = (cin + 3) // 4 * 4
+        x = torch.rand(n, h, w, cin_s, device=dev).requires_grad_(True)
+        y = conv(x)
+        gy = torch.rand_like(y)
+        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        gf = 2.0 * n * ho * wo * cout * cin * k * k / 1e9
+        t_f = timeit(lambda: conv(x.detach()), args.reps)
+        xd = x.detach().requires_grad_(True)
+        conv.weight.requires_grad_(False)
+        yd = conv(xd)
+        t_d = timeit(lambda: torch.autograd.grad(yd, xd, gy, retain_graph=True), args.reps)
+        conv.weight.requires_grad_(True)
+        yw = conv(x.detach())
+        t_w = timeit(lambda: torch.autograd.grad(yw, conv.weight, gy, retain_graph=True), args.reps)
+        print(f'{name:26s} {gf:7.3f} | {t_f:8.1f} {gf / t_f * 1e3:6.1f} | {t_d:8.1f} {gf / t_d * 1e3:6.1f} | '
+              f'{t_w:8.1f} {gf / t_w * 1e3:6.1f}', flush=True)
+
+
+if __name__ == '__main__':
+    main()
