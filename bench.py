@@ -1,0 +1,214 @@
+"""Headline benchmark: 96x96 HR crops/sec of the SRGAN GAN train step on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] / [2]): full SRGAN GAN step -- generator forward, three
+discriminator forwards, discriminator backward + Adam, VGG19 perceptual loss (two forwards, one
+data-gradient backward), generator backward + Adam -- on a batch of 16 synthetic 96x96 HR crops
+per GPU, fp32, random-init weights (VGG19 features seeded-random: the pretrained file is not
+available offline).  Inputs are resident in HBM before the timed region.  One process per GPU;
+at N > 1 the two flat gradient buffers are all-reduced over RCCL (weak scaling).
+
+Rank 0 prints ONE JSON line.  At N = 1 it also carries
+  "roofline":     the dominant kernel (by device time) measured live with HIP events on the
+                  launch stream in an instrumented pass of the same step: algorithmic FLOPs of
+                  its launches / their event-measured duration, against the 157.3 TFLOP/s fp32
+                  MFMA peak of MI355X;
+  "cpu_baseline": the CPU oracle (oracle/srgan.py, stock torch ops) running the identical step
+                  on the host cores -- a reported baseline, not the target.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH = 16          # per GPU (BASELINE.json configs[1])
+CROP = 96
+GF_PER_CROP = 43.23  # necessary algorithmic GFLOP per crop of the GAN step
+PEAK_TFLOPS = 157.3  # fp32 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def synth_batch(device, rank):
+    g = torch.Generator().manual_seed(1234 + rank)
+    hr = torch.rand(BATCH, 3, CROP, CROP, generator=g)
+    lr = torch.nn.functional.interpolate(hr, scale_factor=0.25, mode='bicubic', align_corners=False,
+                                         antialias=True).clamp(0, 1)
+    return lr.to(device), hr.to(device)
+
+
+def conv_flops(d) -> float:
+    ho = (d.H + 2 * d.pad - d.KH) // d.stride + 1
+    wo = (d.W + 2 * d.pad - d.KW) // d.stride + 1
+    return 2.0 * d.N * ho * wo * d.Cout * d.Cin * d.KH * d.KW
+
+
+def roofline_pass(trainer, lr, hr, reps=2):
+    """Instrumented eager pass: every conv launch bracketed by HIP events on its stream."""
+    from torchsr_amd import _lib, functional as F
+    lib = _lib.lib()
+    was = trainer.use_graphs
+    trainer.use_graphs = False
+    trainer.gan_step(lr, hr)  # eager warm-up (repacks, allocator)
+    torch.cuda.synchronize()
+    rec = []
+    F._conv_prof[0] = rec
+    try:
+        for _ in range(reps):
+            torch.cuda._sleep(int(2.0e8))  # let the host run ahead so events do not time launch gaps
+            trainer.gan_step(lr, hr)
+        torch.cuda.synchronize()
+    finally:
+        F._conv_prof[0] = None
+        trainer.use_graphs = was
+    groups = {}
+    plan = (C.c_int * 4)()
+    for kind, d, e0, e1 in rec:
+        ms = e0.elapsed_time(e1)
+        if kind == 'wgrad':
+            name = 'wgrad_kernel'
+        else:
+            lib.srx_conv2d_plan(C.byref(d), 0 if kind == 'fwd' else 1, plan)
+            wm, wn = {(128, 128): (64, 64), (128, 64): (64, 32), (64, 64): (32, 32), (128, 32): (32, 32)}[
+                (plan[0], plan[1])]
+            name = f'gconv_kernel<{plan[0]},{plan[1]},{wm},{wn}>'
+        gsum = groups.setdefault(name, [0.0, 0.0, 0])
+        gsum[0] += ms
+        gsum[1] += conv_flops(d)
+        gsum[2] += 1
+    total_ms = sum(v[0] for v in groups.values())
+    name, (ms, fl, cnt) = max(groups.items(), key=lambda kv: kv[1][0])
+    achieved = fl / (ms * 1e-3) / 1e12
+    table = {k: {'ms_per_step': v[0] / reps, 'gflop_per_step': v[1] / reps / 1e9, 'launches_per_step': v[2] // reps,
+                 'tflops': v[1] / (v[0] * 1e-3) / 1e12} for k, v in groups.items()}
+    return {
+        'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': round(achieved / PEAK_TFLOPS, 4), 'traffic': None,
+        'avg_launch_us': round(ms / cnt * 1e3, 2), 'launches_per_step': cnt // reps,
+        'gflop_per_launch': round(fl / cnt / 1e9, 4),
+        'conv_ms_per_step': round(total_ms / reps, 3), 'by_kernel': table,
+    }
+
+
+def cpu_baseline(trainer, lr, hr, steps=2):
+    """The oracle's GAN step on the host cores, same weights, same batch."""
+    from oracle import srgan as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}  # noqa: E731
+    orc = O.SRGANStepOracle(cpu(trainer.generator.state_dict()), cpu(trainer.discriminator.state_dict()),
+                            cpu(trainer.vgg_loss.features.state_dict()))
+    lrc, hrc = lr.cpu(), hr.cpu()
+    orc.gan_step(lrc, hrc)  # warm-up
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        orc.gan_step(lrc, hrc)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': round(BATCH / med, 3), 'unit': 'crops/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{steps} GAN steps of batch {BATCH} after 1 warm-up (oracle/srgan.py, torch {torch.__version__} CPU ops), '
+                      f'median {med:.2f} s/step'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-graphs', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=device)
+
+    import warnings
+    warnings.filterwarnings('ignore', message='.*seeded random features.*')
+    from torchsr_amd.srgan.trainer import SRGANTrainer
+
+    torch.manual_seed(0)  # identical init on every rank (and an explicit broadcast in the trainer)
+    targs = Namespace(disable_amp=True, batch_size=BATCH, epochs=8, gan_checkpoint=None, local_rank=local_rank,
+                      pretrain_epochs=1, psnr_checkpoint=None, skip_image_save=True, world_size=world,
+                      rank=rank if distributed else -1, use_graphs=not args.no_graphs)
+    trainer = SRGANTrainer(device, targs, [], [], BATCH, BATCH, distributed=distributed)
+    trainer.generator.train()
+    trainer.discriminator.train()
+    lr, hr = synth_batch(device, rank)
+
+    for _ in range(3):  # set-up: two eager passes + hipGraph capture (not warm-up, not timed)
+        trainer.gan_step(lr, hr)
+    for _ in range(args.warmup):
+        trainer.gan_step(lr, hr)
+
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = trainer.gan_step(lr, hr)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    gen_loss = float(losses['gan/train-loss'])
+    if not (gen_loss == gen_loss):
+        sys.exit('bench.py: generator loss is NaN')
+
+    if rank == 0:
+        value = world * BATCH * args.steps / elapsed
+        out = {
+            'metric': '96x96 HR crops/sec (SRGAN GAN train step)', 'value': round(value, 2), 'unit': 'crops/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'SRGAN full GAN step (Generator + Discriminator + VGG19 perceptual loss), '
+                                   '96x96 HR crops, batch 16 per GPU, fp32',
+                       'per_gpu_batch': BATCH, 'global_batch': BATCH * world, 'crop': CROP,
+                       'parallelism': f'dp{world}', 'hip_graph': not args.no_graphs,
+                       'vgg19_weights': 'pretrained' if trainer.vgg_loss.pretrained else 'seeded-random'},
+            'step_tflops': round(value * GF_PER_CROP / 1e3, 2),
+            'step_frac_of_fp32_mfma_peak': round(value * GF_PER_CROP / 1e3 / (PEAK_TFLOPS * world), 4),
+            'final_gen_loss': round(gen_loss, 6),
+        }
+        if world == 1:
+            if not args.no_roofline:
+                out['roofline'] = roofline_pass(trainer, lr, hr)
+            if not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline(trainer, lr, hr)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -92,6 +92,11 @@ size_t srx_conv2d_bwd_weight_ws_floats(const srx_conv2d_t* d);
  * srx_conv2d_fwd when `bn_partials` is non-NULL: table is [rows][Cout][2] */
 int srx_conv2d_stat_rows(const srx_conv2d_t* d);
 
+/* launch plan the library will use (for profiling / the bench's roofline bookkeeping):
+ * which = 0 forward, 1 data gradient; out[4] = {tile rows BM, tile cols BN, split-K factor, workgroups}.
+ * The kernel launched is `gconv_kernel<BM,BN,..>`. */
+int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out);
+
 /* OIHW master weights -> packed forward ([Cout_p][K_p], K=(kh,kw,ci)) and, when
  * wpk_bwd != NULL, packed data-gradient operands (per stride-parity class,
  * taps flipped, [Cin_p][K'_p], K'=(tap,co)). */

@@ -1,0 +1,177 @@
+"""CPU-side tests (no GPU): the oracle against the golden vectors captured from the reference,
+the C-ABI library's exports, host logic (registry, flat buffers, schedulers, schema)."""
+import ctypes
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from oracle import srgan as O
+from oracle.weights import closed_form_state, tensor_digest
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+# ------------------------------------------------------------------ oracle pinned by the goldens
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_oracle_generator_matches_reference_golden(tag):
+    from torchsr_amd.srgan.generator import Generator
+    gold = np.load(os.path.join(GOLDEN, 'srgan_generator.npz'))
+    sd = closed_form_state(Generator().state_dict())
+    leaves = O._leaves(sd)
+    x = torch.from_numpy(gold[f'{tag}_x']).requires_grad_(True)
+    y = O.generator_forward(sd, x, True)
+    assert rel(y, gold[f'{tag}_y_train']) < 1e-5
+    y.square().mean().backward()
+    assert rel(x.grad, gold[f'{tag}_dx']) < 1e-4
+    names = [k for k, v in sd.items() if v.is_floating_point() and 'running_' not in k]
+    dig = dict(zip((str(k) for k in gold[f'{tag}_grad_keys']), gold[f'{tag}_grad_digest']))
+    for k, leaf in zip(names, leaves):
+        d = tensor_digest(leaf.grad)
+        assert abs(d[0] - dig[k][0]) <= 1e-4 * max(dig[k][1], 1e-12), k
+    ye = O.generator_forward(sd, x.detach(), False)
+    assert rel(ye, gold[f'{tag}_y_eval']) < 1e-5
+
+
+@pytest.mark.parametrize('tag,size', [('s32', 32), ('s96', 96)])
+def test_oracle_discriminator_matches_reference_golden(tag, size):
+    from torchsr_amd.srgan.discriminator import Discriminator
+    gold = np.load(os.path.join(GOLDEN, 'srgan_discriminator.npz'))
+    sd = closed_form_state(Discriminator(image_size=size).state_dict())
+    p = O.discriminator_forward(sd, torch.from_numpy(gold[f'{tag}_x']), True)
+    assert rel(p, gold[f'{tag}_p_train']) < 1e-5
+    pe = O.discriminator_forward(sd, torch.from_numpy(gold[f'{tag}_x']), False)
+    assert rel(pe, gold[f'{tag}_p_eval']) < 1e-5
+
+
+def test_oracle_vgg_matches_reference_golden():
+    from torchsr_amd.srgan.loss import make_vgg19_features
+    gold = np.load(os.path.join(GOLDEN, 'vgg19.npz'))
+    sd = closed_form_state(make_vgg19_features().state_dict(), prefix='features.')
+    feat = O.vgg_features(sd, torch.from_numpy(gold['src']))
+    assert rel(feat, gold['features']) < 1e-5
+    loss = O.vgg_loss(sd, torch.from_numpy(gold['src']), torch.from_numpy(gold['tgt']))
+    assert abs(loss.item() - float(gold['loss'])) < 1e-5 * float(gold['loss'])
+
+
+def test_oracle_first_gan_step_matches_reference_trainer_golden():
+    from torchsr_amd.srgan.discriminator import Discriminator
+    from torchsr_amd.srgan.generator import Generator
+    from torchsr_amd.srgan.loss import make_vgg19_features
+    gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
+    torch.set_num_threads(8)
+    orc = O.SRGANStepOracle(closed_form_state(Generator().state_dict()),
+                            closed_form_state(Discriminator().state_dict()),
+                            closed_form_state(make_vgg19_features().state_dict(), prefix='features.'))
+    out = orc.gan_step(torch.from_numpy(gold['low_res']), torch.from_numpy(gold['high_res']))
+    assert np.allclose(out, gold['gan_losses'][0], rtol=1e-5)
+    assert abs(out[3] - gold['gan_ref_gen_losses'][0]) < 1e-5 * out[3]
+    keys = [str(k) for k in gold['g_keys']]
+    for k, dg in zip(keys, gold['gan_g_digest'][0]):
+        d = tensor_digest(orc.g[k].detach())
+        assert abs(d[1] - dg[1]) <= 1e-5 * max(dg[1], 1e-9), k
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    from torchsr_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    header = open(os.path.join(ROOT, 'include', 'srx.h')).read()
+    declared = set(re.findall(r'\b(srx_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations found'
+    for name in declared:
+        assert hasattr(handle, name), f'{name} declared in include/srx.h but not exported'
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert handle.srx_version() == 100
+
+
+def test_size_queries_and_error_reporting_without_gpu():
+    from torchsr_amd import _lib
+    L = _lib.lib()
+    d = _lib.Conv2dDesc(16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0)
+    assert L.srx_conv2d_packed_fwd_floats(ctypes.byref(d)) == 64 * 576
+    assert L.srx_conv2d_packed_bwd_floats(ctypes.byref(d)) == 64 * 576
+    d2 = _lib.Conv2dDesc(16, 96, 96, 64, 64, 64, 64, 3, 3, 2, 1, 0, 0, 0.0, 0)
+    # stride 2: four parity classes with 1+2+2+4 = 9 taps in total, no wasted work
+    assert L.srx_conv2d_packed_bwd_floats(ctypes.byref(d2)) == 64 * 64 * 9
+    bad = _lib.Conv2dDesc(16, 24, 24, 64, 62, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0)
+    assert L.srx_conv2d_packed_fwd_floats(ctypes.byref(bad)) == 0
+    assert 'Cin_s' in _lib.last_error()
+    with pytest.raises(RuntimeError, match='bad argument'):
+        _lib.call('srx_nchw_to_nhwc', None, None, 1, 3, 4, 4, 4, None)
+
+
+def test_ops_refuse_cpu_tensors():
+    from torchsr_amd import functional as F
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        F.to_nhwc(torch.rand(1, 3, 4, 4))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        F.mse_loss(torch.rand(4), torch.rand(4))
+
+
+# ------------------------------------------------------------------ host logic
+def test_state_dict_schema_and_seeded_init_match_reference_counts():
+    from torchsr_amd.srgan.discriminator import Discriminator
+    from torchsr_amd.srgan.generator import Generator
+    g, d = Generator(), Discriminator()
+    assert len(g.state_dict()) == 225 and len(d.state_dict()) == 48
+    assert sum(p.numel() for p in g.parameters()) == 1547350
+    assert sum(p.numel() for p in d.parameters()) == 23563649
+    assert g.state_dict()['conv_layers.1.conv.weight'].shape == (256, 64, 3, 3)
+    assert d.state_dict()['classifier.0.weight'].shape == (1024, 18432)
+    assert Discriminator(image_size=32).classifier[0].in_features == 2048
+    assert len(Generator(scale_factor=2).conv_layers) == 1
+
+
+def test_vgg_layout_and_freeze():
+    from torchsr_amd.srgan.loss import VGGLoss, make_vgg19_features
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        v = VGGLoss()
+    keys = list(v.features.state_dict().keys())
+    convs = [0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 23, 25, 28, 30, 32, 34]
+    assert keys == [f'{i}.{p}' for i in convs for p in ('weight', 'bias')]
+    assert len(v.features) == 36 and sum(p.numel() for p in v.parameters()) == 20024384
+    assert not any(p.requires_grad for p in v.parameters()) and not v.features.training
+    assert [i for i, k in O.vgg_feature_layout() if k == 'conv'] == convs
+    with pytest.raises(RuntimeError):
+        make_vgg19_features(1)
+
+
+def test_flat_params_views_and_zero_grad():
+    from torchsr_amd.optim import FlatParams
+    m = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    f = FlatParams(m)
+    assert f.numel == 16 + 4 + 8 + 4  # each tensor padded to 4 floats
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    m(torch.rand(4, 5)).sum().backward()
+    assert f.grad.abs().sum() > 0 and m[0].weight.grad.data_ptr() == f.grad.data_ptr()
+    f.zero_grad()
+    assert f.grad.abs().sum() == 0
+    with torch.no_grad():
+        f.data.add_(1.0)
+    assert torch.allclose(m[1].bias, before['1.bias'] + 1.0)
+    m.load_state_dict(before)
+    assert torch.equal(f.data[:15], before['0.weight'].flatten())
+
+
+def test_steplr_and_registry():
+    from argparse import Namespace
+    from torchsr_amd import models
+    cls, crop = models.select_trainer_model(Namespace(model='SRGAN'))
+    assert crop == 96 and cls.__name__ == 'SRGANTrainer'
+    assert models.select_test_model(Namespace(model='srgan')).__name__ == 'Generator'
+    with pytest.raises(RuntimeError, match='not supported'):
+        models.select_trainer_model(Namespace(model='nope'))
+    assert set(models.MODELS) == {'esrgan', 'srgan'} and models.CROP_SIZE == {'esrgan': 128, 'srgan': 96}

@@ -1,0 +1,137 @@
+"""SRGAN Generator / Discriminator / VGGLoss on the HIP path vs (a) the golden vectors captured
+from the imported reference and (b) the CPU oracle.  Tolerance: north_star's 1e-3 relative fp32
+(these usually land near 1e-5)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import srgan as O
+from oracle.weights import closed_form_state, tensor_digest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-9)).item()
+
+
+def digest_rel(t, ref_digest):
+    """Compare a tensor against a stored digest (sum, abs-sum, cos-weighted sum, first, last)."""
+    d = tensor_digest(t.detach().cpu())
+    scale = max(abs(ref_digest[1]), 1e-12)
+    return max(abs(d[0] - ref_digest[0]), abs(d[1] - ref_digest[1]), abs(d[2] - ref_digest[2])) / scale
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_generator_vs_golden(dev, tag):
+    from torchsr_amd.srgan.generator import Generator
+    gold = np.load(os.path.join(GOLDEN, 'srgan_generator.npz'))
+    gen = Generator()
+    gen.load_state_dict(closed_form_state(gen.state_dict()))
+    gen = gen.to(dev).train()
+    x = torch.from_numpy(gold[f'{tag}_x']).to(dev).requires_grad_(True)
+    y = gen(x)
+    assert rel(y, gold[f'{tag}_y_train']) < TOL
+    loss = y.square().mean()
+    assert abs(loss.item() - float(gold[f'{tag}_loss'])) < TOL * float(gold[f'{tag}_loss'])
+    loss.backward()
+    assert rel(x.grad, gold[f'{tag}_dx']) < TOL
+    grads = dict(gen.named_parameters())
+    for k, dg in zip(gold[f'{tag}_grad_keys'], gold[f'{tag}_grad_digest']):
+        assert digest_rel(grads[str(k)].grad, dg) < TOL, k
+    sd = gen.state_dict()
+    for k, dg in zip(gold[f'{tag}_running_keys'], gold[f'{tag}_running_digest']):
+        assert digest_rel(sd[str(k)], dg) < TOL, k
+    assert int(sd['blocks.3.bn1.num_batches_tracked']) == 1
+    gen.eval()
+    with torch.no_grad():
+        ye = gen(x.detach())
+    assert rel(ye, gold[f'{tag}_y_eval']) < TOL
+
+
+@pytest.mark.parametrize('tag,size', [('s32', 32), ('s96', 96)])
+def test_discriminator_vs_golden(dev, tag, size):
+    from torchsr_amd import functional as F
+    from torchsr_amd.srgan.discriminator import Discriminator
+    gold = np.load(os.path.join(GOLDEN, 'srgan_discriminator.npz'))
+    disc = Discriminator(image_size=size)
+    disc.load_state_dict(closed_form_state(disc.state_dict()))
+    disc = disc.to(dev).train()
+    x = torch.from_numpy(gold[f'{tag}_x']).to(dev).requires_grad_(True)
+    p = disc(x)
+    assert p.shape == (2, 1)
+    assert rel(p, gold[f'{tag}_p_train']) < TOL
+    loss = F.bce_loss(p, 1.0)
+    assert abs(loss.item() - float(gold[f'{tag}_loss'])) < TOL * float(gold[f'{tag}_loss'])
+    loss.backward()
+    assert digest_rel(x.grad, gold[f'{tag}_dx_digest']) < TOL
+    if tag == 's32':
+        assert rel(x.grad, gold['s32_dx']) < TOL
+    grads = dict(disc.named_parameters())
+    for k, dg in zip(gold[f'{tag}_grad_keys'], gold[f'{tag}_grad_digest']):
+        assert digest_rel(grads[str(k)].grad, dg) < TOL, k
+    sd = disc.state_dict()
+    for k, dg in zip(gold[f'{tag}_running_keys'], gold[f'{tag}_running_digest']):
+        assert digest_rel(sd[str(k)], dg) < TOL, k
+    disc.eval()
+    with torch.no_grad():
+        pe = disc(x.detach())
+    assert rel(pe, gold[f'{tag}_p_eval']) < TOL
+
+
+def test_vgg_loss_vs_golden(dev):
+    from torchsr_amd import functional as F
+    from torchsr_amd.srgan.loss import VGGLoss
+    gold = np.load(os.path.join(GOLDEN, 'vgg19.npz'))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        vgg = VGGLoss()
+    vgg.features.load_state_dict(closed_form_state(vgg.features.state_dict(), prefix='features.'))
+    vgg = vgg.to(dev)
+    assert not any(p.requires_grad for p in vgg.parameters()) and not vgg.features.training
+    src = torch.from_numpy(gold['src']).to(dev).requires_grad_(True)
+    tgt = torch.from_numpy(gold['tgt']).to(dev)
+    with torch.no_grad():
+        feat = F.to_nchw(vgg.features_nhwc(F.to_nhwc(src.detach(), 4)))
+    assert rel(feat, gold['features']) < TOL
+    loss = vgg(src, tgt)
+    assert abs(loss.item() - float(gold['loss'])) < TOL * float(gold['loss'])
+    loss.backward()
+    assert rel(src.grad, gold['dsrc']) < TOL
+
+
+def test_generator_vs_oracle_fresh_inputs(dev):
+    """Default (seeded) init + fresh random input, batch 3, non-square 13x9."""
+    from torchsr_amd.srgan.generator import Generator
+    torch.manual_seed(5)
+    gen = Generator()
+    sd = {k: v.clone() for k, v in gen.state_dict().items()}
+    x = torch.rand(3, 3, 13, 9)
+    yo = O.generator_forward(sd, x, True)
+    gen = gen.to(dev).train()
+    y = gen(x.to(dev))
+    assert rel(y, yo) < TOL
+    assert y.shape == (3, 3, 52, 36)
+
+
+def test_psnr_parity(dev):
+    """PSNR of the trainer's formula (srgan/trainer.py:296) within 0.01 dB of the oracle."""
+    from math import log10
+    from torchsr_amd import functional as F
+    from torchsr_amd.srgan.generator import Generator
+    gen = Generator()
+    sd = closed_form_state(gen.state_dict())
+    gen.load_state_dict(sd)
+    lr, hr = torch.rand(2, 3, 16, 16), torch.rand(2, 3, 64, 64)
+    sr_o = O.generator_forward({k: v.clone() for k, v in sd.items()}, lr, False)
+    gen = gen.to(dev).eval()
+    with torch.no_grad():
+        sr = gen(lr.to(dev))
+        psnr = 10 * log10(1 / F.mse_loss(sr, hr.to(dev)).item())
+    assert abs(psnr - O.psnr(sr_o, hr)) < 0.01

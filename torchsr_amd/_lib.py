@@ -63,6 +63,7 @@ _SIGS = {
     'srx_conv2d_bwd_data_ws_floats': (_Z, [_D]),
     'srx_conv2d_bwd_weight_ws_floats': (_Z, [_D]),
     'srx_conv2d_stat_rows': (_I, [_D]),
+    'srx_conv2d_plan': (_I, [_D, _I, C.POINTER(C.c_int)]),
     'srx_conv2d_pack': (_I, [_D, _P, _P, _P, _P]),
     'srx_conv2d_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_data': (_I, [_D, _P, _P, _P, _P, _Z, _P]),

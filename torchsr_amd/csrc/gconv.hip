@@ -658,6 +658,24 @@ extern "C" int srx_conv2d_stat_rows(const srx_conv2d_t* d) {
   return stat_rows_for(d);
 }
 
+// which: 0 = forward, 1 = data gradient (first stride-parity class).  out = {BM, BN, nsplit, workgroups}
+extern "C" int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out) {
+  if (int rc = check_desc(d)) return rc;
+  SRX_REQUIRE(out, "conv2d_plan: null pointer");
+  Plan p;
+  if (which == 0) {
+    p = fwd_plan(d, fwd_geo(d));
+  } else {
+    SRX_REQUIRE(d->stride <= 4, "conv2d_plan: stride > 4 unsupported");
+    BwdClass cls[16];
+    size_t total;
+    bwd_classes(d, cls, total);
+    p = bwd_plan(d, cls[0]);
+  }
+  out[0] = p.BM; out[1] = p.BN; out[2] = p.nsplit; out[3] = p.mtiles * p.ntiles * p.nsplit;
+  return SRX_OK;
+}
+
 extern "C" int srx_conv2d_pack(const srx_conv2d_t* d, const float* w, float* wpk_fwd, float* wpk_bwd, void* stream) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(w && wpk_fwd, "conv2d_pack: null pointer");

@@ -20,6 +20,23 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, Conv2dDesc, call
 import ctypes as C
 
 
+# developer / bench hook: when set to a list, every conv launch is bracketed with events and
+# appended as (kind, desc, start_event, end_event)
+_conv_prof = [None]
+
+
+def _prof_call(kind, d, name, *args):
+    rec = _conv_prof[0]
+    if rec is None:
+        return call(name, *args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = call(name, *args)
+    e1.record()
+    rec.append((kind, d, e0, e1))
+    return r
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -129,8 +146,12 @@ class ConvState:
         return (n, ho, wo, self.cout_s)
 
     def pack(self, weight: Tensor, d: Conv2dDesc, force: bool = False) -> None:
-        """(Re)build the packed copies when the master OIHW weight changed."""
-        key = (weight.data_ptr(), weight._version, _pack_epoch[0])
+        """(Re)build the packed copies when the master OIHW weight changed.
+
+        ``weight`` is the module's Parameter: its ``_version`` catches in-place torch updates,
+        the optimiser epoch catches raw-pointer updates by ``srx_adam_step`` (frozen parameters
+        such as VGG19's never repack)."""
+        key = (weight.data_ptr(), weight._version, _pack_epoch[0] if weight.requires_grad else -1)
         if not force and key == self._key and self.wpk_fwd is not None:
             return
         dref = C.byref(d)
@@ -155,14 +176,15 @@ def bump_pack_epoch() -> None:
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], st: ConvState, want_stats: bool):
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], st: ConvState, want_stats: bool,
+                master: Tensor):
         x = _chk(x, 'conv2d.input')
         n, h, w, cs = x.shape
         if cs != st.cin_s:
             raise RuntimeError(f'conv2d: input has {cs} channels (stride), layer expects {st.cin_s}')
         d = st.desc(n, h, w)
         dref = C.byref(d)
-        st.pack(weight, d)
+        st.pack(master, d)
         L = _lib.lib()
         y = torch.empty(st.out_shape(n, h, w), dtype=torch.float32, device=x.device)
         part = None
@@ -172,7 +194,7 @@ class _Conv2d(Function):
         nws = L.srx_conv2d_fwd_ws_floats(dref)
         ws = _ws(nws, x) if nws else None
         b = None if bias is None else _chk(bias.detach(), 'conv2d.bias')
-        call('srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(b), _p(y), _p(part), _p(ws), nws, _stream())
+        _prof_call('fwd', d, 'srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(b), _p(y), _p(part), _p(ws), nws, _stream())
         ctx.st, ctx.d = st, d
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, y if st.act != ACT_NONE else None)
@@ -199,12 +221,12 @@ class _Conv2d(Function):
             dx = torch.empty_like(x)
             nws = L.srx_conv2d_bwd_data_ws_floats(dref)
             ws = _ws(nws, x) if nws else None
-            call('srx_conv2d_bwd_data', dref, _p(dy), _p(ctx.wpk_bwd), _p(dx), _p(ws), nws, s)
+            _prof_call('dgrad', d, 'srx_conv2d_bwd_data', dref, _p(dy), _p(ctx.wpk_bwd), _p(dx), _p(ws), nws, s)
         if ctx.needs_input_grad[1]:
             dw = torch.empty((st.cout, st.cin, st.k, st.k), dtype=torch.float32, device=x.device)
             nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
             ws = _ws(nws, x)
-            call('srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw), _p(ws), nws, s)
+            _prof_call('wgrad', d, 'srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw), _p(ws), nws, s)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if st.shuffle:
                 # dy is [N, 2Ho, 2Wo, cps]; bias index co = c*4 + i*2 + j
@@ -220,13 +242,13 @@ class _Conv2d(Function):
                 db = torch.empty(st.cout, dtype=torch.float32, device=dy.device)
                 nws = L.srx_colsum_ws_floats(m, st.cout)
                 call('srx_colsum', _p(dy), _p(db), m, st.cout, st.cout_s, _p(_ws(nws, dy)), nws, s)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], st: ConvState,
-           want_stats: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], st: ConvState, want_stats: bool = False,
+           master: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """NHWC conv.  Returns ``(y, bn_partials)``; ``bn_partials`` is ``None`` unless requested."""
-    return _Conv2d.apply(x, weight, bias, st, want_stats)
+    return _Conv2d.apply(x, weight, bias, st, want_stats, weight if master is None else master)
 
 
 # --------------------------------------------------------------------------- batch norm (+act, +residual)
@@ -283,11 +305,12 @@ class _BNAct(Function):
 
 
 def bn_act(y, part, bn, act=ACT_NONE, slope=0.0, prelu: Optional[Tensor] = None,
-           residual: Optional[Tensor] = None) -> Tensor:
+           residual: Optional[Tensor] = None, frozen: bool = False) -> Tensor:
     """``act(BatchNorm2d(y)) [+ residual]`` with ``bn`` an ``nn.BatchNorm2d``-compatible module."""
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    return _BNAct.apply(y, part, bn.weight, bn.bias, prelu, residual, bn.running_mean, bn.running_var,
+    gamma, beta = (bn.weight.detach(), bn.bias.detach()) if frozen else (bn.weight, bn.bias)
+    return _BNAct.apply(y, part, gamma, beta, prelu, residual, bn.running_mean, bn.running_var,
                         bn.num_batches_tracked if training else None, training, bn.eps, momentum, act, float(slope))
 
 

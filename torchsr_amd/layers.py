@@ -7,10 +7,36 @@ activations.  These layers are the internal (NHWC) building blocks; the public
 ``Generator`` / ``Discriminator`` / ``VGGLoss`` modules accept and return NCHW like
 the reference.
 """
+import contextlib
+
 from torch import nn, Tensor
 
 from . import functional as F
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU
+
+
+_frozen = [False]
+
+
+@contextlib.contextmanager
+def no_weight_grad():
+    """Run forwards whose parameters take no gradient while activations still do.
+
+    Used for the discriminator pass inside the generator update (torchsr/srgan/trainer.py:456):
+    the reference lets autograd compute -- and DDP all-reduce -- discriminator weight gradients
+    there that are zeroed before anyone reads them.  Skipping them
+    changes no result and removes 28 GFLOP and 94 MB of all-reduce per step.
+    """
+    old = _frozen[0]
+    _frozen[0] = True
+    try:
+        yield
+    finally:
+        _frozen[0] = old
+
+
+def _w(p):
+    return p.detach() if (_frozen[0] and p is not None) else p
 
 
 class Conv2d(nn.Conv2d):
@@ -28,7 +54,7 @@ class Conv2d(nn.Conv2d):
                                slope=slope)
 
     def forward(self, x: Tensor, want_stats: bool = False):
-        y, part = F.conv2d(x, self.weight, self.bias, self._st, want_stats)
+        y, part = F.conv2d(x, _w(self.weight), _w(self.bias), self._st, want_stats, self.weight)
         return (y, part) if want_stats else y
 
     def repack(self) -> None:
@@ -48,12 +74,12 @@ class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d parameter holder; applied through ``functional.bn_act``."""
 
     def forward(self, y: Tensor, part=None, act=ACT_NONE, slope=0.0, prelu=None, residual=None) -> Tensor:
-        return F.bn_act(y, part, self, act=act, slope=slope, prelu=prelu, residual=residual)
+        return F.bn_act(y, part, self, act=act, slope=slope, prelu=_w(prelu), residual=residual, frozen=_frozen[0])
 
 
 class PReLU(nn.PReLU):
     def forward(self, x: Tensor) -> Tensor:
-        return F.prelu(x, self.weight)
+        return F.prelu(x, _w(self.weight))
 
 
 class LeakyReLU(nn.LeakyReLU):
@@ -63,7 +89,7 @@ class LeakyReLU(nn.LeakyReLU):
 
 class Linear(nn.Linear):
     def forward(self, x: Tensor, act=ACT_NONE, slope=0.0) -> Tensor:
-        return F.linear(x, self.weight, self.bias, act, slope)
+        return F.linear(x, _w(self.weight), _w(self.bias), act, slope)
 
 
 class Marker(nn.Module):
@@ -87,5 +113,5 @@ def repack_module(module: nn.Module) -> None:
             m.repack()
 
 
-__all__ = ['Conv2d', 'BatchNorm2d', 'PReLU', 'LeakyReLU', 'Linear', 'Marker', 'repack_module', 'ACT_NONE',
+__all__ = ['no_weight_grad', 'Conv2d', 'BatchNorm2d', 'PReLU', 'LeakyReLU', 'Linear', 'Marker', 'repack_module', 'ACT_NONE',
            'ACT_RELU', 'ACT_LRELU']
