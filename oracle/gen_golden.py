@@ -107,12 +107,38 @@ def check(name, a, b, tol=1e-6):
     print(f'  oracle == reference  {name:40s} max|diff| {err:.3e}')
 
 
+def well_conditioned_seed(fn64, fn32, shape, seeds, tol=2e-5):
+    """PReLU / LeakyReLU / ReLU / max-pool are not differentiable at 0: a pre-activation that lands
+    within rounding of 0 makes the fp32 reference's own gradient differ from its fp64 evaluation by
+    ~1e-3 (seen with seed 11).  Such an input pins nothing, so pick the first seed for which the
+    reference agrees with an fp64 evaluation of itself."""
+    for seed in seeds:
+        x = seeded_input(shape, seed)
+        a, b = fn32(x), fn64(x)
+        err = ((a.double() - b).abs().max() / b.abs().max()).item()
+        if err < tol:
+            return seed
+        print(f'  seed {seed} skipped: fp32 vs fp64 gradient differ by {err:.2e} (activation kink)')
+    raise RuntimeError('no well conditioned seed found')
+
+
+def _dx_of(forward, sd0, dtype):
+    def fn(x):
+        sd = {k: (v.to(dtype).clone() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        xo = x.to(dtype).clone().requires_grad_(True)
+        forward(sd, xo).square().mean().backward()
+        return xo.grad
+    return fn
+
+
 def gen_generator():
     from torchsr.srgan.generator import Generator
     ref = Generator()
     sd0 = closed_form_state(ref.state_dict())
     out = {}
-    for tag, shape, seed in [('a', (2, 3, 12, 12), 11), ('b', (1, 3, 10, 14), 12)]:
+    gfwd = lambda sd, x: O.generator_forward(sd, x, True)  # noqa: E731
+    for tag, shape, seeds in [('a', (2, 3, 12, 12), range(11, 20)), ('b', (1, 3, 10, 14), range(21, 30))]:
+        seed = well_conditioned_seed(_dx_of(gfwd, sd0, torch.float64), _dx_of(gfwd, sd0, torch.float32), shape, seeds)
         ref.load_state_dict(sd0)
         x = seeded_input(shape, seed).requires_grad_(True)
         ref.train()
@@ -151,9 +177,12 @@ def gen_generator():
 def gen_discriminator():
     from torchsr.srgan.discriminator import Discriminator
     out = {}
-    for tag, size, seed in [('s32', 32, 21), ('s96', 96, 22)]:
+    dfwd = lambda sd, x: O.discriminator_forward(sd, x, True)  # noqa: E731
+    for tag, size, seeds in [('s32', 32, range(31, 40)), ('s96', 96, range(41, 50))]:
         ref = Discriminator(image_size=size)
         sd0 = closed_form_state(ref.state_dict())
+        seed = well_conditioned_seed(_dx_of(dfwd, sd0, torch.float64), _dx_of(dfwd, sd0, torch.float32),
+                                     (2, 3, size, size), seeds)
         ref.load_state_dict(sd0)
         x = seeded_input((2, 3, size, size), seed).requires_grad_(True)
         ref.train()
@@ -189,8 +218,11 @@ def gen_vgg():
     from torchsr.srgan.loss import VGGLoss
     ref = VGGLoss()  # stubbed torchvision.models.vgg19 with closed-form weights
     sd = {k: v.clone() for k, v in ref.features.state_dict().items()}
-    src = seeded_input((2, 3, 32, 32), 31).requires_grad_(True)
-    tgt = seeded_input((2, 3, 32, 32), 32)
+    vfwd = lambda sd_, x: O.vgg_features(sd_, x)  # noqa: E731
+    seed = well_conditioned_seed(_dx_of(vfwd, sd, torch.float64), _dx_of(vfwd, sd, torch.float32), (2, 3, 32, 32),
+                                 range(51, 60))
+    src = seeded_input((2, 3, 32, 32), seed).requires_grad_(True)
+    tgt = seeded_input((2, 3, 32, 32), 99)
     loss = ref(src, tgt)
     loss.backward()
     so = src.detach().clone().requires_grad_(True)

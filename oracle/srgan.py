@@ -187,7 +187,7 @@ class SRGANStepOracle:
         loss = F.mse_loss(super_res, high_res)                       # :384
         loss.backward()                                              # :386
         self.psnr_optimizer.step()                                   # :387
-        return float(loss)
+        return float(loss.detach())
 
     def gan_step(self, low_res: Tensor, high_res: Tensor) -> Tuple[float, float, float, float]:
         batch = low_res.size(0)
@@ -206,7 +206,7 @@ class SRGANStepOracle:
         gen_loss = content + 0.001 * adversarial                     # :457
         gen_loss.backward()                                          # :468
         self.gen_optimizer.step()                                    # :469
-        return float(disc_loss), float(content), float(adversarial), float(gen_loss)
+        return tuple(float(v.detach()) for v in (disc_loss, content, adversarial, gen_loss))
 
     def state(self, which: str) -> State:
         return {k: v.detach() for k, v in getattr(self, which).items()}

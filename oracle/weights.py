@@ -4,9 +4,9 @@ Golden fixtures must not depend on ``torch.manual_seed`` streams or on module
 construction order, and full-size weights (SRGAN D 94 MB, VGG19 80 MB) must cost
 nothing to store.  Every ``state_dict`` entry is therefore filled, by key name, from
 
-    value[i] = offset(key) + amp(key, shape) * sin(0.37 * i + phase(crc32(key)))
+    value[i] = offset(key) + amp(key, shape) * u(crc32(key), i),   u = splitmix64 hash -> [-1, 1)
 
-evaluated in float64 and rounded to float32.  The same function fills the imported
+evaluated in integer / float64 arithmetic and rounded to float32.  The same function fills the imported
 reference modules (``gen_golden.py``) and the modules under test.
 """
 import zlib
@@ -16,9 +16,19 @@ import numpy as np
 import torch
 
 
-def _wave(n: int, key: str, freq: float = 0.37) -> np.ndarray:
-    phase = (zlib.crc32(key.encode()) % 6283) / 1000.0
-    return np.sin(freq * np.arange(n, dtype=np.float64) + phase)
+def _wave(n: int, key: str) -> np.ndarray:
+    """Deterministic uniform [-1, 1) values: splitmix64 of (crc32(key), index).
+
+    (A smooth sin() fill was tried first: it makes the conv stacks nearly rank deficient and the
+    fp32 reference itself then sits 1e-2 away from an fp64 evaluation of its own gradients.)"""
+    with np.errstate(over='ignore'):
+        z = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(zlib.crc32(key.encode()))
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return (z >> np.uint64(11)).astype(np.float64) / float(1 << 53) * 2.0 - 1.0
 
 
 def closed_form_tensor(key: str, like: torch.Tensor) -> torch.Tensor:
@@ -39,7 +49,7 @@ def closed_form_tensor(key: str, like: torch.Tensor) -> torch.Tensor:
         v = 0.05 * w
     elif leaf == 'weight':                                      # conv OIHW / linear [out][in]
         fan_in = int(np.prod(shape[1:]))
-        v = np.sqrt(3.0 / fan_in) * w * 1.4142
+        v = np.sqrt(6.0 / fan_in) * w
     else:
         v = 0.1 * w
     return torch.from_numpy(v.astype(np.float32)).reshape(shape).to(like.dtype)
