@@ -131,14 +131,49 @@ def _dx_of(forward, sd0, dtype):
     return fn
 
 
+def kink_margin(module, x):
+    """Smallest |pre-activation| / rms over every PReLU / LeakyReLU / ReLU input of ``module`` for
+    input ``x``: how far the closest activation is from its non-differentiable point."""
+    margins, hooks = [], []
+
+    def pre(_m, inp):
+        t = inp[0].detach().double()
+        margins.append((t.abs().min() / t.square().mean().sqrt()).item())
+
+    for m in module.modules():
+        if isinstance(m, (nn.PReLU, nn.LeakyReLU, nn.ReLU)):
+            hooks.append(m.register_forward_pre_hook(pre))
+    with torch.no_grad():
+        module(x)
+    for h in hooks:
+        h.remove()
+    return min(margins)
+
+
+def widest_margin_seed(module, sd0, shape, seeds):
+    """Any two fp32 implementations disagree on the sign of a pre-activation that is within rounding
+    of zero, and one flipped PReLU moves the input gradient by ~1e-3 -- more than the parity
+    tolerance.  Golden inputs are therefore chosen so that the reference keeps every activation at
+    least ~1e-5 rms away from its kink (forward agreement is ~1e-6)."""
+    best, best_m = None, -1.0
+    for seed in seeds:
+        module.load_state_dict(sd0)
+        module.train()
+        m = kink_margin(module, seeded_input(shape, seed))
+        if m > best_m:
+            best, best_m = seed, m
+    print(f'  input {shape}: seed {best} keeps activations >= {best_m:.2e} rms from their kinks')
+    assert best_m > 5e-6, 'no input with a usable kink margin'
+    return best
+
+
 def gen_generator():
     from torchsr.srgan.generator import Generator
     ref = Generator()
     sd0 = closed_form_state(ref.state_dict())
     out = {}
-    gfwd = lambda sd, x: O.generator_forward(sd, x, True)  # noqa: E731
-    for tag, shape, seeds in [('a', (2, 3, 12, 12), range(11, 20)), ('b', (1, 3, 10, 14), range(21, 30))]:
-        seed = well_conditioned_seed(_dx_of(gfwd, sd0, torch.float64), _dx_of(gfwd, sd0, torch.float32), shape, seeds)
+    for tag, shape, seeds in [('a', (2, 3, 8, 8), range(100, 140)), ('b', (1, 3, 6, 10), range(200, 240))]:
+        seed = widest_margin_seed(ref, sd0, shape, seeds)
         ref.load_state_dict(sd0)
         x = seeded_input(shape, seed).requires_grad_(True)
         ref.train()

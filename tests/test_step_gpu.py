@@ -83,9 +83,12 @@ def test_first_adam_step_matches_oracle_elementwise(dev):
             if 'running_' in k:
                 assert (diff.max() / ref[k].detach().abs().max().clamp_min(1e-6)).item() < 1e-3, (name, k)
             else:
-                # elements whose gradient is at the fp32 noise floor may step the other way (2*lr)
-                frac_bad = (diff > 2e-6).float().mean().item()
-                assert frac_bad < 2e-3, (name, k, frac_bad, diff.max().item())
+                # Adam's first step is lr*g/(|g|+eps): an element whose gradient sits near eps=1e-8
+                # (or at the fp32 noise floor) moves by a different fraction of lr in any two fp32
+                # implementations; allow 0.2 % of a tensor (at least one element) to do so
+                n_bad = int((diff > 2e-6).sum())
+                assert n_bad <= max(1, int(2e-3 * diff.numel())), (name, k, n_bad, diff.max().item())
+                assert diff.max().item() <= 2.1e-4, (name, k, diff.max().item())
 
 
 def test_pretrain_steps_vs_golden(dev):

@@ -148,23 +148,51 @@ __global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __
 }
 
 // ------------------------------------------------------------------ colsum
-constexpr int CS_ROWS = 256;
+// stage 1: grid (row blocks, column chunks of 64 float4 quads); a block is qpb quads x (256/qpb) row lanes,
+// every lane streams float4s down its rows, LDS folds the row lanes.  C4 = C rounded up to 4 (<= Cs).
+constexpr int CS_MAX_PART_ROWS = 256;
+__host__ __device__ inline int64_t colsum_rows_per_block(int64_t M) {
+  int64_t rpb = (M + CS_MAX_PART_ROWS - 1) / CS_MAX_PART_ROWS;
+  return rpb < 16 ? 16 : rpb;
+}
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
-                                                             int64_t M, int C, int Cs) {
-  // one thread per channel (strided over C), rows of this block summed serially: simple and coalesced for C >= 64
-  const int64_t rbeg = (int64_t)blockIdx.x * CS_ROWS;
-  const int64_t rend = min(M, rbeg + CS_ROWS);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    for (int64_t r = rbeg; r < rend; ++r) s += x[r * Cs + c];
-    part[(size_t)blockIdx.x * C + c] = s;
+                                                             int64_t M, int C4, int Cs, int qpb, int64_t rpb) {
+  __shared__ f32x4 red[256];
+  const int cq = C4 / 4;
+  const int nrl = 256 / qpb;
+  const int tid = threadIdx.x;
+  const int ql = tid % qpb, rl = tid / qpb;
+  const int q = blockIdx.y * qpb + ql;
+  const int64_t rbeg = (int64_t)blockIdx.x * rpb;
+  const int64_t rend = min(M, rbeg + rpb);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (rl < nrl && q < cq)
+    for (int64_t r = rbeg + rl; r < rend; r += nrl) s += *reinterpret_cast<const f32x4*>(x + r * Cs + q * 4);
+  red[tid] = s;
+  __syncthreads();
+  if (tid < qpb && q < cq) {
+    f32x4 t = red[tid];
+    for (int k = 1; k < nrl; ++k) t += red[tid + k * qpb];
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C4 + q * 4) = t;
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out) {
+__global__ void colsum_final_kernel(const float* __restrict__ part, int rows, int C, int C4, float* __restrict__ out) {
+  // one wave per column, lanes over the (<= 256) partial rows
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = lane; r < rows; r += 64) s += (double)part[(size_t)r * C4 + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[c] = (float)s;
+}
+// fallback for a channel stride that is not a multiple of 4 (e.g. the [B][1] output of the last Linear)
+__global__ void colsum_scalar_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t M, int C, int Cs) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)part[(size_t)r * C + c];
+  for (int64_t r = 0; r < M; ++r) s += (double)x[r * Cs + c];
   out[c] = (float)s;
 }
 
@@ -247,17 +275,31 @@ extern "C" int srx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int 
   return SRX_OK;
 }
 
-extern "C" size_t srx_colsum_ws_floats(int64_t M, int C) { return (size_t)srx_cdiv(M, CS_ROWS) * C; }
+extern "C" size_t srx_colsum_ws_floats(int64_t M, int C) {
+  const int64_t rpb = colsum_rows_per_block(M);
+  return (size_t)srx_cdiv(M, rpb) * (size_t)srx_roundup(C, 4);
+}
 
 extern "C" int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, float* ws, size_t ws_floats,
                           void* stream) {
   SRX_REQUIRE(x && out && ws && M > 0 && C > 0 && Cs >= C, "colsum: bad argument");
-  if (ws_floats < srx_colsum_ws_floats(M, C)) SRX_FAIL(SRX_E_WORKSPACE, "colsum: workspace too small");
-  const int rows = (int)srx_cdiv(M, CS_ROWS);
   hipStream_t st = srx_stream(stream);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, ws, M, C, Cs);
+  if (Cs % 4 != 0 || ((uintptr_t)x % 16) != 0) {
+    SRX_REQUIRE(M <= 65536, "colsum: unaligned input only supported for small M");
+    hipLaunchKernelGGL(colsum_scalar_kernel, dim3((unsigned)srx_cdiv(C, 64)), dim3(64), 0, st, x, out, M, C, Cs);
+    SRX_CHECK_LAUNCH("colsum_scalar_kernel");
+    return SRX_OK;
+  }
+  if (ws_floats < srx_colsum_ws_floats(M, C)) SRX_FAIL(SRX_E_WORKSPACE, "colsum: workspace too small");
+  const int C4 = (int)srx_roundup(C, 4), cq = C4 / 4;
+  int qpb = 1;
+  while (qpb < cq && qpb < 64) qpb *= 2;  // power of two <= 64 so it divides 256
+  const int64_t rpb = colsum_rows_per_block(M);
+  const int rows = (int)srx_cdiv(M, rpb);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)rows, (unsigned)srx_cdiv(cq, qpb)), dim3(256), 0, st, x, ws,
+                     M, C4, Cs, qpb, rpb);
   SRX_CHECK_LAUNCH("colsum_partial_kernel");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)srx_cdiv(C, 64)), dim3(64), 0, st, ws, rows, C, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)srx_cdiv(C, 4)), dim3(256), 0, st, ws, rows, C, C4, out);
   SRX_CHECK_LAUNCH("colsum_final_kernel");
   return SRX_OK;
 }

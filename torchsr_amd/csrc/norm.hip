@@ -8,7 +8,9 @@
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK = 256;
+// rows of the activation matrix summed by one workgroup: small tensors get small blocks so that the
+// reduction still fills the chip (a 16x24x24x64 tensor is only 9216 rows)
+__host__ __device__ inline int rows_per_block(int64_t M) { return M >= 131072 ? 512 : (M >= 32768 ? 128 : 32); }
 
 __device__ __forceinline__ float act_fwd(float z, int act, float slope) {
   if (act == SRX_ACT_NONE) return z;
@@ -28,8 +30,8 @@ __global__ __launch_bounds__(256) void bn_partial_stats_kernel(const float* __re
   const int cq = C / 4, nrl = 256 / cq;
   const int tid = threadIdx.x;
   const int q = tid % cq, rl = tid / cq;
-  const int64_t rbeg = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-  const int64_t rend = min(M, rbeg + ROWS_PER_BLOCK);
+  const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block(M);
+  const int64_t rend = min(M, rbeg + rows_per_block(M));
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   if (rl < nrl) {
     for (int64_t r = rbeg + rl; r < rend; r += nrl) {
@@ -53,14 +55,23 @@ __global__ __launch_bounds__(256) void bn_partial_stats_kernel(const float* __re
 __global__ void bn_finalize_kernel(const float* __restrict__ part, int rows, int64_t M, int C, float eps, float mom,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
                                    float* __restrict__ rvar, int64_t* __restrict__ nbt) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
+  // one wave per channel: lanes stride over the partial rows, fp64 butterfly reduction
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c == 0 && lane == 0 && nbt) *nbt += 1;
   if (c >= C) return;
   double s = 0.0, s2 = 0.0;
-  for (int r = 0; r < rows; ++r) {
-    s += (double)part[((size_t)r * C + c) * 2];
-    s2 += (double)part[((size_t)r * C + c) * 2 + 1];
+  for (int r = lane; r < rows; r += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c) * 2);
+    s += (double)v.x;
+    s2 += (double)v.y;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (lane != 0) return;
   const double mu = s / (double)M;
   double var = s2 / (double)M - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -117,8 +128,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const int cq = C / 4, nrl = 256 / cq;
   const int tid = threadIdx.x;
   const int q = tid % cq, rl = tid / cq;
-  const int64_t rbeg = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-  const int64_t rend = min(M, rbeg + ROWS_PER_BLOCK);
+  const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block(M);
+  const int64_t rend = min(M, rbeg + rows_per_block(M));
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   float sp = 0.f;
   if (rl < nrl) {
@@ -158,12 +169,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ ws, int rows, int C, float* __restrict__ sums) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ ws, int rows, int C,
+                                                              float* __restrict__ sums) {
+  // one wave per column: lanes stride over the partial rows (a few hundred at most), fp64 butterfly
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (c > 2 * C) return;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)ws[(size_t)r * (2 * C + 4) + c];
-  sums[c] = (float)s;
+  for (int r = lane; r < rows; r += 64) s += (double)ws[(size_t)r * (2 * C + 4) + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) sums[c] = (float)s;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
@@ -215,7 +231,7 @@ unsigned stream_grid(int64_t n4) {
 
 }  // namespace
 
-extern "C" int srx_bn_stat_rows(int64_t M) { return (int)srx_cdiv(M, ROWS_PER_BLOCK); }
+extern "C" int srx_bn_stat_rows(int64_t M) { return (int)srx_cdiv(M, rows_per_block(M)); }
 
 extern "C" int srx_bn_partial_stats(const float* y, float* partials, int64_t M, int C, void* stream) {
   if (int rc = check_c(C, "bn_partial_stats")) return rc;
@@ -231,7 +247,7 @@ extern "C" int srx_bn_finalize(const float* partials, int rows, int64_t M, int C
                                int64_t* nbt, void* stream) {
   SRX_REQUIRE(partials && save_mean && save_invstd && rows > 0 && M > 0 && C > 0, "bn_finalize: bad argument");
   SRX_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)srx_cdiv(C, 64)), dim3(64), 0, srx_stream(stream), partials,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)srx_cdiv(C, 4)), dim3(256), 0, srx_stream(stream), partials,
                      rows, M, C, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
   SRX_CHECK_LAUNCH("bn_finalize_kernel");
   return SRX_OK;
@@ -273,7 +289,7 @@ extern "C" int srx_bn_act_bwd_reduce(const float* dout, const float* y, const fl
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, dout, y, mean, invstd, gamma, beta,
                      ws, M, C, act, slope, prelu);
   SRX_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)srx_cdiv(2 * C + 1, 64)), dim3(64), 0, st, ws, rows, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)srx_cdiv(2 * C + 1, 4)), dim3(256), 0, st, ws, rows, C,
                      sums);
   SRX_CHECK_LAUNCH("bn_bwd_finalize_kernel");
   return SRX_OK;
