@@ -80,7 +80,7 @@ def roofline_pass(trainer, lr, hr, reps=2):
             name = 'wgrad_kernel'
         else:
             lib.srx_conv2d_plan(C.byref(d), 0 if kind == 'fwd' else 1, plan)
-            wm, wn = {(128, 128): (64, 64), (128, 64): (64, 32), (64, 64): (32, 32), (128, 32): (32, 32)}[
+            wm, wn = {(128, 128): (64, 32), (128, 64): (32, 32), (64, 64): (32, 32), (128, 32): (32, 32)}[
                 (plan[0], plan[1])]
             name = f'gconv_kernel<{plan[0]},{plan[1]},{wm},{wn}>'
         gsum = groups.setdefault(name, [0.0, 0.0, 0])

@@ -55,10 +55,13 @@ def timeit(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--only', type=str, default='')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     print(f'{"layer":26s} {"GF":>7s} | {"fwd us":>8s} {"TF/s":>6s} | {"dgrad us":>8s} {"TF/s":>6s} | {"wgrad us":>8s} {"TF/s":>6s}')
     for name, n, h, w, cin, cout, k, s, p, sh in SHAPES:
+        if args.only and args.only not in name:
+            continue
         conv = Conv2d(cin, cout, k, s, p, bias=False, shuffle=sh).to(dev)
         cin_s = (cin + 3) // 4 * 4
         x = torch.rand(n, h, w, cin_s, device=dev).requires_grad_(True)

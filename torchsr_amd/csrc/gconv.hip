@@ -31,7 +31,12 @@ struct GArgs {
   int act; float slope;
   int linear_out;
   int mtiles;
-  int kchunks, kc_per_split, nsplit;
+  // work decomposition: workgroups [0, full_tiles) each own one whole output tile; the remaining
+  // (tail) tiles are cut tail_split ways along K so that the last, partially filled "round" of the
+  // chip still keeps every CU busy; their raw partial tiles go to `ws` and tail_fixup_kernel
+  // finishes them (sum, bias, activation, BatchNorm partials).
+  int kchunks, kc_per_split, full_tiles, tail_split;
+  float* ws;
 };
 
 constexpr int BK = 32;           // floats per k-chunk (one 128-byte LDS row)
@@ -41,12 +46,16 @@ constexpr int INVALID = -20000;  // coordinate that fails every bounds check
 // forward / data-gradient gather-GEMM.  256 threads = 4 waves, wave tile WMxWN.
 // ---------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gconv_kernel(const GArgs a) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_kernel(const GArgs a) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-  constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int NT = WAVES_M * WAVES_N * 64;  // 256 or 512 threads: the big tiles run 8 waves so that every
+                                              // SIMD holds two and one's MFMAs cover the other's loads/barriers
+  static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
+  constexpr int RPP = NT / 8;                 // tile rows staged per pass (8 threads x float4 = one 128-byte row)
+  constexpr int RA = BM / RPP, RB = BN / RPP;
+  static_assert(RA >= 1 && RB >= 1, "tile too small for the thread count");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sA = reinterpret_cast<float*>(smem);
@@ -55,15 +64,25 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int mt = blockIdx.x % a.mtiles, nt = blockIdx.x / a.mtiles;
+  int tile = blockIdx.x, kc_beg = 0, kc_end = a.kchunks;
+  bool raw = false;
+  float* slab = nullptr;
+  if ((int)blockIdx.x >= a.full_tiles) {
+    const int t = blockIdx.x - a.full_tiles;
+    tile = a.full_tiles + t / a.tail_split;
+    if (a.tail_split > 1) {
+      kc_beg = (t % a.tail_split) * a.kc_per_split;
+      kc_end = min(a.kchunks, kc_beg + a.kc_per_split);
+      raw = true;
+      slab = a.ws + (size_t)t * (BM * BN);
+    }
+  }
+  const int mt = tile % a.mtiles, nt = tile / a.mtiles;
   const int m0 = mt * BM, n0 = nt * BN;
   const int q = tid & 7, r0 = tid >> 3;
 
-  const int kc_beg = blockIdx.z * a.kc_per_split;
-  const int kc_end = min(a.kchunks, kc_beg + a.kc_per_split);
-
   // ---- k table: (dh, dw) and linear input offset for every float4 of K in range
-  for (int e = kc_beg * 8 + tid; e < kc_end * 8; e += 256) {
+  for (int e = kc_beg * 8 + tid; e < kc_end * 8; e += NT) {
     const int k = 4 * e;
     int2 ent;
     if (k < a.K) {
@@ -90,7 +109,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GArgs a) {
   int rbase[RA], rih[RA], riw[RA];
 #pragma unroll
   for (int p = 0; p < RA; ++p) {
-    const int m = m0 + r0 + 32 * p;
+    const int m = m0 + r0 + RPP * p;
     if (m < a.M) {
       int n, rem, mh, mw;
       srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
@@ -129,16 +148,16 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GArgs a) {
     }
 #pragma unroll
     for (int p = 0; p < RB; ++p)
-      rb[p] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(32 * p) * a.Kp + kc * BK);
+      rb[p] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(RPP * p) * a.Kp + kc * BK);
   };
   const int wchunk = (q ^ ((r0 >> 1) & 7)) * 4;
   auto swrite = [&](int buf) {
     float* dA = sA + buf * BM * BK;
     float* dB = sB + buf * BN * BK;
 #pragma unroll
-    for (int p = 0; p < RA; ++p) *reinterpret_cast<f32x4*>(dA + (r0 + 32 * p) * BK + wchunk) = ra[p];
+    for (int p = 0; p < RA; ++p) *reinterpret_cast<f32x4*>(dA + (r0 + RPP * p) * BK + wchunk) = ra[p];
 #pragma unroll
-    for (int p = 0; p < RB; ++p) *reinterpret_cast<f32x4*>(dB + (r0 + 32 * p) * BK + wchunk) = rb[p];
+    for (int p = 0; p < RB; ++p) *reinterpret_cast<f32x4*>(dB + (r0 + RPP * p) * BK + wchunk) = rb[p];
   };
 
   const int h = lane >> 5, l31 = lane & 31;
@@ -179,8 +198,19 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GArgs a) {
 
   // ------------------------------------------------------------- epilogue
   // accumulator map (32x32 MFMA): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const bool raw = a.nsplit > 1;
-  float* outp = raw ? a.out + (size_t)blockIdx.z * a.M * a.Cs : a.out;
+  if (raw) {  // tile-local [BM][BN] partial; each half wave writes 128 contiguous bytes
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          slab[row * BN + wn * WN + j * 32 + l31] = acc[i][j][r];
+        }
+    return;
+  }
+  float* outp = a.out;
 
   float bv[TN];
   int colv[TN], ocol[TN];
@@ -195,7 +225,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GArgs a) {
       oc = (((ij >> 1) * a.Wo) + (ij & 1)) * a.Co + cc;  // offset inside the 2x2 output block
     }
     ocol[j] = oc;
-    bv[j] = (!raw && a.bias && col < a.Cn) ? a.bias[bidx] : 0.f;
+    bv[j] = (a.bias && col < a.Cn) ? a.bias[bidx] : 0.f;
   }
   float csum[TN], csq[TN];
 #pragma unroll
@@ -208,8 +238,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GArgs a) {
       const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       const bool mok = m < a.M;
       size_t obase;
-      if (a.linear_out || raw) {
-        obase = (size_t)m * a.Cs;
+      if (a.linear_out) {
+        obase = (size_t)m * a.Co;
       } else {
         int n, rem, mh, mw;
         srx_divmod(mok ? m : 0, a.HmWm, a.inv_HmWm, n, rem);
@@ -221,10 +251,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GArgs a) {
       for (int j = 0; j < TN; ++j) {
         float v = acc[i][j][r] + bv[j];
         if (mok) { csum[j] += v; csq[j] += v * v; }
-        if (!raw) {
-          if (a.act == SRX_ACT_RELU) v = fmaxf(v, 0.f);
-          else if (a.act == SRX_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
-        }
+        if (a.act == SRX_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (a.act == SRX_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
         if (mok && colv[j] < a.Cs) outp[obase + ocol[j]] = v;
       }
     }
@@ -257,22 +285,65 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GArgs a) {
   }
 }
 
-// split-K tail: out = act(sum_z slab[z] + bias)
-__global__ void splitk_epilogue_kernel(const float* __restrict__ slab, int nsplit, int64_t MC, int Cs, int Cn,
-                                       const float* __restrict__ bias, int act, float slope, float* __restrict__ out) {
-  const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i4 * 4 >= MC) return;
-  f32x4 s = *reinterpret_cast<const f32x4*>(slab + i4 * 4);
-  for (int z = 1; z < nsplit; ++z) s += *reinterpret_cast<const f32x4*>(slab + (size_t)z * MC + i4 * 4);
-  const int c = (int)((i4 * 4) % Cs);
+// finishes the K-split tail tiles: out = act(sum_z partial[z] + bias) and, when asked, the tile's
+// per-channel (sum, sum of squares) row of the BatchNorm partial table.  One workgroup per
+// (tile, 16-column group): every column's statistics stay inside one workgroup, and a tile with
+// many K splits is still drained by BN/16 workgroups rather than one.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void tail_fixup_kernel(const GArgs a) {
+  constexpr int CG = BN / 16;
+  __shared__ f32x4 red[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = tid & 3, rl = tid >> 2;  // 4 float4 quads x 64 row lanes
+  const int t = blockIdx.x / CG, cg = blockIdx.x % CG;
+  const int tile = a.full_tiles + t;
+  const int mt = tile % a.mtiles, nt = tile / a.mtiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const float* slab = a.ws + (size_t)t * a.tail_split * (BM * BN);
+  const int lc = cg * 16 + q * 4;  // column inside the tile
+  const int col = n0 + lc;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float v = s[e] + ((bias && c + e < Cn) ? bias[c + e] : 0.f);
-    if (act == SRX_ACT_RELU) v = fmaxf(v, 0.f);
-    else if (act == SRX_ACT_LRELU) v = v > 0.f ? v : v * slope;
-    s[e] = v;
+    for (int e = 0; e < 4; ++e) bv[e] = (col + e < a.Cn) ? a.bias[col + e] : 0.f;
   }
-  *reinterpret_cast<f32x4*>(out + i4 * 4) = s;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = rl; r < BM; r += 64) {
+    const int m = m0 + r;
+    if (m < a.M) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(slab + r * BN + lc);
+      for (int z = 1; z < a.tail_split; ++z)
+        v += *reinterpret_cast<const f32x4*>(slab + (size_t)z * (BM * BN) + r * BN + lc);
+      v += bv;
+      s1 += v;
+      s2 += v * v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (a.act == SRX_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+        else if (a.act == SRX_ACT_LRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+      }
+      if (col < a.Cs) *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col) = v;  // Cs is a multiple of 4
+    }
+  }
+  if (a.part) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = 4; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+    if (lane < 4) { red[0][wave * 4 + lane] = s1; red[1][wave * 4 + lane] = s2; }
+    __syncthreads();
+    if (tid < 4) {
+      const f32x4 t1 = red[0][tid] + red[0][4 + tid] + red[0][8 + tid] + red[0][12 + tid];
+      const f32x4 t2 = red[1][tid] + red[1][4 + tid] + red[1][8 + tid] + red[1][12 + tid];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (col + e < a.Cn) {
+          a.part[((size_t)mt * a.Cn + col + e) * 2 + 0] = t1[e];
+          a.part[((size_t)mt * a.Cn + col + e) * 2 + 1] = t2[e];
+        }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -476,7 +547,7 @@ Geo fwd_geo(const srx_conv2d_t* d) {
   Geo g;
   g.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
   g.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
-  g.Ck = d->Cin_s;
+  g.Ck = (int)srx_roundup(d->Cin, 4);  // k-space channels; the tensor's channel stride Cin_s may be larger
   g.K = d->KH * d->KW * g.Ck;
   g.Kp = (int)srx_roundup(g.K, BK);
   g.Cnp = pad_rows(d->Cout);
@@ -521,74 +592,97 @@ int bwd_classes(const srx_conv2d_t* d, BwdClass* cls, size_t& total_floats) {
   return n;
 }
 
-struct Plan { int BM, BN, mtiles, ntiles, nsplit, kc_per_split; };
+// Launch plan.  The chip finishes when its busiest CU does, and a CU's matrix pipes are shared by
+// whatever workgroups sit on it, so time ~ (tiles on the busiest CU) x (tile work).  With T equal
+// tiles on P CUs that is ceil(T/P): 288 tiles cost as much as 512.  The plan therefore runs the
+// first floor(T/P)*P tiles whole and cuts the remaining r = T mod P tiles `split` ways along K so
+// that the last round is r*split <= ~P small workgroups (a data-parallel + split-K-tail hybrid);
+// only those r tiles take the partial-sum round trip through HBM.  Larger tiles are preferred
+// (fewer L2->LDS bytes per MFMA: the 64x64 tile moves 16 B/clk/workgroup and stalls on L1/L2)
+// unless they leave the chip under-filled.
+struct Plan { int BM, BN, mtiles, ntiles, tiles, full, tail, split, kc_per_split; float cost; };
 
-Plan make_plan(int M, int Cnp, int kchunks, bool can_split) {
+int device_cus() {
   static int cus = 0;
   if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
+  return cus;
+}
+
+Plan make_plan(int M, int Cnp, int kchunks, bool can_split) {
+  const int P = device_cus();
   const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
-  Plan best{0, 0, 0, 0, 1, kchunks};
+  const float eff[4] = {0.95f, 0.85f, 0.60f, 0.50f};  // measured MFMA efficiency of each tile in steady state
+  Plan best{};
+  best.cost = 1e30f;
   for (int i = 0; i < 4; ++i) {
     const int bm = cand[i][0], bn = cand[i][1];
     if (Cnp == 32) { if (bn != 32) continue; }
     else if (bn == 32 || Cnp % bn != 0) continue;
-    const int mt = (int)srx_cdiv(M, bm), ntl = Cnp / bn;
-    best = Plan{bm, bn, mt, ntl, 1, kchunks};
-    if ((int64_t)mt * ntl >= 2 * cus) break;  // largest tile that still gives two workgroups per CU
-  }
-  const int64_t wgs = (int64_t)best.mtiles * best.ntiles;
-  if (can_split && wgs < cus && kchunks >= 8) {
-    int s = (int)srx_cdiv(2 * cus, wgs);
-    if (s > kchunks / 4) s = kchunks / 4;
-    if (s > 16) s = 16;
-    if (s > 1) {
-      best.kc_per_split = (int)srx_cdiv(kchunks, s);
-      best.nsplit = (int)srx_cdiv(kchunks, best.kc_per_split);
+    Plan p{};
+    p.BM = bm; p.BN = bn;
+    p.mtiles = (int)srx_cdiv(M, bm);
+    p.ntiles = Cnp / bn;
+    p.tiles = p.mtiles * p.ntiles;
+    // microseconds for one whole tile on an otherwise idle CU (4 SIMDs x 64 FLOP/clk at ~2.1 GHz)
+    const float t_tile = 2.0f * bm * bn * (float)kchunks * BK / (4 * 64 * 2.1e3f) / eff[i];
+    const int rounds = p.tiles / P, r = p.tiles % P;
+    p.full = rounds * P; p.tail = r; p.split = 1; p.kc_per_split = kchunks;
+    float tail_cost = r ? t_tile : 0.f;
+    if (r && can_split) {
+      const int smax = kchunks / 4 < 16 ? kchunks / 4 : 16;
+      for (int s = 2; s <= smax; ++s) {
+        const int kcs = (int)srx_cdiv(kchunks, s);
+        const int s_eff = (int)srx_cdiv(kchunks, kcs);
+        const float busiest = (float)srx_cdiv((int64_t)r * s_eff, P) * kcs / (float)kchunks;
+        // fix-up: (s+1) passes over the tail tiles at ~3 TB/s plus one more kernel boundary
+        const float fix = 4.0f + (float)r * (s_eff + 1) * bm * bn * 4.0f / 3.0e6f + (float)s_eff * bm * 64.0f / 40.0e3f;
+        const float c = busiest * t_tile + fix;
+        if (c < tail_cost) { tail_cost = c; p.split = s_eff; p.kc_per_split = kcs; }
+      }
     }
+    p.cost = rounds * t_tile + tail_cost;
+    if (p.cost < best.cost) best = p;
   }
   return best;
 }
 
+size_t plan_ws_floats(const Plan& p) { return p.split > 1 ? (size_t)p.tail * p.split * p.BM * p.BN : 0; }
+
 template <int BM, int BN, int WM, int WN>
 int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
-  const size_t lds = (size_t)(2 * (BM + BN) * BK) * sizeof(float) + (size_t)p.kc_per_split * 8 * sizeof(int2);
+  const int ktab_chunks = p.full > 0 || p.split == 1 ? a.kchunks : p.kc_per_split;
+  const size_t lds = (size_t)(2 * (BM + BN) * BK) * sizeof(float) + (size_t)ktab_chunks * 8 * sizeof(int2);
   if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
   static std::once_flag once;
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit);
-  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, st, a);
+  dim3 grid(p.full + p.tail * p.split);
+  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN>), grid, dim3((BM / WM) * (BN / WN) * 64), lds, st, a);
   SRX_CHECK_LAUNCH("gconv_kernel");
+  if (p.split > 1) {
+    hipLaunchKernelGGL((tail_fixup_kernel<BM, BN>), dim3(p.tail * (BN / 16)), dim3(256), 0, st, a);
+    SRX_CHECK_LAUNCH("tail_fixup_kernel");
+  }
   return SRX_OK;
 }
 
-int run_gconv(GArgs& a, Plan p, float* final_out, float* ws, size_t ws_floats, hipStream_t st) {
+int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t st) {
   a.kchunks = a.Kp / BK;
-  if (p.nsplit > 1) {
-    const size_t need = (size_t)p.nsplit * a.M * a.Cs;
-    if (!ws || need > ws_floats) SRX_FAIL(SRX_E_WORKSPACE, "conv2d: split-K workspace %zu < %zu floats", ws_floats, need);
-  }
+  const size_t need = plan_ws_floats(p);
+  if (need && (!ws || need > ws_floats))
+    SRX_FAIL(SRX_E_WORKSPACE, "conv2d: split-K workspace %zu < %zu floats", ws_floats, need);
+  if (p.split > 1 && !a.linear_out) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: internal: split plan on a strided output");
   a.mtiles = p.mtiles;
   a.kc_per_split = p.kc_per_split;
-  a.nsplit = p.nsplit;
-  a.out = p.nsplit > 1 ? ws : final_out;
-  int rc;
-  if (p.BM == 128 && p.BN == 128) rc = launch_gconv<128, 128, 64, 64>(a, p, st);
-  else if (p.BM == 128 && p.BN == 64) rc = launch_gconv<128, 64, 64, 32>(a, p, st);
-  else if (p.BM == 64 && p.BN == 64) rc = launch_gconv<64, 64, 32, 32>(a, p, st);
-  else rc = launch_gconv<128, 32, 32, 32>(a, p, st);
-  if (rc) return rc;
-  if (p.nsplit > 1) {
-    const int64_t MC = (int64_t)a.M * a.Cs;
-    const int threads = 256;
-    const int64_t blocks = srx_cdiv(MC / 4, threads);
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, ws, p.nsplit, MC, a.Cs,
-                       a.Cn, a.bias, a.act, a.slope, final_out);
-    SRX_CHECK_LAUNCH("splitk_epilogue_kernel");
-  }
-  return SRX_OK;
+  a.full_tiles = p.full;
+  a.tail_split = p.split;
+  a.ws = ws;
+  if (p.BM == 128 && p.BN == 128) return launch_gconv<128, 128, 64, 32>(a, p, st);
+  if (p.BM == 128 && p.BN == 64) return launch_gconv<128, 64, 32, 32>(a, p, st);
+  if (p.BM == 64 && p.BN == 64) return launch_gconv<64, 64, 32, 32>(a, p, st);
+  return launch_gconv<128, 32, 32, 32>(a, p, st);
 }
 
 void set_mgrid(GArgs& a, int N, int Hm, int Wm) {
@@ -607,9 +701,7 @@ Plan bwd_plan(const srx_conv2d_t* d, const BwdClass& c) {
 
 int stat_rows_for(const srx_conv2d_t* d) {
   const Geo g = fwd_geo(d);
-  const Plan p = fwd_plan(d, g);
-  if (p.nsplit > 1) return srx_bn_stat_rows((int64_t)d->N * g.Ho * g.Wo);
-  return p.mtiles;
+  return fwd_plan(d, g).mtiles;
 }
 
 }  // namespace
@@ -632,8 +724,7 @@ extern "C" size_t srx_conv2d_packed_bwd_floats(const srx_conv2d_t* d) {
 extern "C" size_t srx_conv2d_fwd_ws_floats(const srx_conv2d_t* d) {
   if (check_desc(d)) return 0;
   const Geo g = fwd_geo(d);
-  const Plan p = fwd_plan(d, g);
-  return p.nsplit > 1 ? (size_t)p.nsplit * d->N * g.Ho * g.Wo * d->Cout_s : 0;
+  return plan_ws_floats(fwd_plan(d, g));
 }
 
 extern "C" size_t srx_conv2d_bwd_data_ws_floats(const srx_conv2d_t* d) {
@@ -642,8 +733,7 @@ extern "C" size_t srx_conv2d_bwd_data_ws_floats(const srx_conv2d_t* d) {
   BwdClass cls[16];
   size_t total;
   bwd_classes(d, cls, total);
-  const Plan p = bwd_plan(d, cls[0]);
-  return p.nsplit > 1 ? (size_t)p.nsplit * d->N * d->H * d->W * d->Cin_s : 0;
+  return plan_ws_floats(bwd_plan(d, cls[0]));
 }
 
 extern "C" size_t srx_conv2d_bwd_weight_ws_floats(const srx_conv2d_t* d) {
@@ -672,7 +762,7 @@ extern "C" int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out) {
     bwd_classes(d, cls, total);
     p = bwd_plan(d, cls[0]);
   }
-  out[0] = p.BM; out[1] = p.BN; out[2] = p.nsplit; out[3] = p.mtiles * p.ntiles * p.nsplit;
+  out[0] = p.BM; out[1] = p.BN; out[2] = p.split; out[3] = p.full + p.tail * p.split;
   return SRX_OK;
 }
 
@@ -725,18 +815,12 @@ extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float
     a.out_shuffle = g.cps; a.Cs = d->Cout; a.Ho = 2 * g.Ho; a.Wo = 2 * g.Wo; a.Co = d->Cout_s;
     a.out_stride = 2; a.oh_off = 0; a.ow_off = 0; a.linear_out = 0;
   } else {
-    a.out_shuffle = 0; a.Cs = d->Cout_s; a.Ho = g.Ho; a.Wo = g.Wo; a.Co = d->Cout_s;
+    a.out_shuffle = 0; a.Cs = (int)srx_roundup(d->Cout, 4); a.Ho = g.Ho; a.Wo = g.Wo; a.Co = d->Cout_s;
     a.out_stride = 1; a.oh_off = 0; a.ow_off = 0; a.linear_out = 1;
   }
-  const Plan p = fwd_plan(d, g);
-  const bool split = p.nsplit > 1;
-  if (bn_partials && !split) a.part = bn_partials;
-  if (int rc = run_gconv(a, p, y, ws, ws_floats, st)) return rc;
-  if (bn_partials && split) {
-    SRX_REQUIRE(d->Cout_s == d->Cout, "conv2d_fwd: BN statistics need Cout_s == Cout");
-    return srx_bn_partial_stats(y, bn_partials, a.M, d->Cout, stream);
-  }
-  return SRX_OK;
+  a.part = bn_partials;
+  a.out = y;
+  return run_gconv(a, fwd_plan(d, g), ws, ws_floats, st);
 }
 
 extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx, float* ws,
@@ -766,13 +850,14 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     a.Ck = d->shuffle ? d->Cout : d->Cout_s;
     a.K = c.K; a.Kp = c.Kp;
     a.in_shuffle = g.cps;
-    a.Cn = d->Cin; a.Cs = d->Cin_s;
+    a.Cn = d->Cin; a.Cs = (int)srx_roundup(d->Cin, 4);
     a.Ho = d->H; a.Wo = d->W; a.Co = d->Cin_s;
     a.out_stride = d->stride; a.oh_off = c.ph; a.ow_off = c.pw;
     a.out_shuffle = 0;
     a.act = SRX_ACT_NONE; a.slope = 0.f;
     a.linear_out = (d->stride == 1);
-    if (int rc = run_gconv(a, bwd_plan(d, c), dx, ws, ws_floats, st)) return rc;
+    a.out = dx;
+    if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st)) return rc;
   }
   return SRX_OK;
 }
