@@ -110,25 +110,35 @@ int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float* wpk_fwd, 
 /* dx = conv_transpose(dy, W)  (autograd of nn.Conv2d wrt its input) */
 int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
                         float* ws, size_t ws_floats, void* stream);
-/* dw (OIHW, overwritten) = autograd of nn.Conv2d wrt its weight */
+/* dw (OIHW) = autograd of nn.Conv2d wrt its weight; accumulate != 0 adds into dw (a .grad buffer)
+ * instead of overwriting it.  The same flag exists on srx_colsum, srx_linear_bwd_weight,
+ * srx_prelu_bwd; srx_bn_act_bwd_reduce takes optional accumulation targets. */
 int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, const float* dy, float* dw_oihw,
-                          float* ws, size_t ws_floats, void* stream);
+                          int accumulate, float* ws, size_t ws_floats, void* stream);
 
 /* ------------------------------------------------- elementwise / reductions */
 /* out[c] = sum_m x[m][c]  (bias gradient of Conv2d / Linear); ws >= 2*rows*C floats */
 size_t srx_colsum_ws_floats(int64_t M, int C);
-int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, float* ws, size_t ws_floats, void* stream);
+int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, int accumulate, float* ws, size_t ws_floats,
+               void* stream);
 /* dx = dy * act'(y) for sign-recoverable activations fused into a conv epilogue (ReLU, LeakyReLU) */
 int srx_act_bwd_from_out(const float* dy, const float* y, float* dx, int64_t n, int act, float slope, void* stream);
 /* nn.PReLU (one shared slope): srgan/generator.py:39, srgan/residual.py:29,66 */
 int srx_prelu_fwd(const float* x, const float* slope, float* y, int64_t n, void* stream);
 /* dx and d(slope); ws >= 1024 floats */
 int srx_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx, float* dslope,
-                  int64_t n, float* ws, void* stream);
+                  int accumulate, int64_t n, float* ws, void* stream);
 /* nn.LeakyReLU as a standalone op (ESRGAN, esrgan/residual.py:36-55) */
 int srx_lrelu_fwd(const float* x, float* y, int64_t n, float slope, void* stream);
 /* y = a*x + b*z  (residual scaling of esrgan/residual.py:86,128; torch.add of srgan/generator.py:78) */
 int srx_axpby(const float* x, const float* z, float* y, int64_t n, float a, float b, void* stream);
+/* channel concat / split of NHWC tensors: dst[m][dst_off+c] (+)= src[m][src_off+c], c < C
+ * (torch.cat((x, conv1, ...), dim=1) of the dense block, esrgan/residual.py:82-85, and its adjoint) */
+int srx_copy_channels(const float* src, int src_cs, int src_off, float* dst, int dst_cs, int dst_off, int C,
+                      int64_t M, int accumulate, void* stream);
+/* F.interpolate(scale_factor=2, mode='nearest') (esrgan/generator.py:73,76) and its adjoint; x is [N][H][W][C] */
+int srx_upsample_nearest2x_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int srx_upsample_nearest2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* nn.Sigmoid of the SRGAN discriminator head (srgan/discriminator.py:68) */
 int srx_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream);
 int srx_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
@@ -156,7 +166,8 @@ int srx_bn_act_fwd(const float* y, const float* mean, const float* invstd, const
 size_t srx_bn_bwd_ws_floats(int64_t M, int C);
 int srx_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, float* sums, int64_t M, int C, int act,
-                          float slope, const float* prelu, float* ws, size_t ws_floats, void* stream);
+                          float slope, const float* prelu, float* dgamma_acc, float* dbeta_acc,
+                          float* dprelu_acc, float* ws, size_t ws_floats, void* stream);
 /* backward, pass 2: dy = gamma*invstd*(dz - sum_dz/M - xhat*sum_dzxhat/M) (training) or
  * dy = gamma*invstd*dz (eval, training=0) */
 int srx_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* invstd,
@@ -176,7 +187,8 @@ int srx_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
                    int act, float slope, float* ws, size_t ws_floats, void* stream);
 int srx_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int K, int J, float* ws,
                         size_t ws_floats, void* stream);
-int srx_linear_bwd_weight(const float* x, const float* dy, float* dw, int B, int K, int J, void* stream);
+int srx_linear_bwd_weight(const float* x, const float* dy, float* dw, int accumulate, int B, int K, int J,
+                          void* stream);
 
 /* ------------------------------------------------------------------ losses */
 /* all losses reduce with mean; `loss` is one float on the device; ws >= 2048 floats.
@@ -193,6 +205,9 @@ int srx_bce_bwd(const float* p, float target, const float* gscale, float* dp, in
 /* nn.BCEWithLogitsLoss(x - shift[0], target) (esrgan/trainer.py:164,451-453,468); shift may be NULL */
 int srx_bce_logits_fwd(const float* x, const float* shift, float target, float* loss, int64_t n, float* ws, void* stream);
 int srx_bce_logits_bwd(const float* x, const float* shift, float target, const float* gscale, float* dx, int64_t n, void* stream);
+/* torch.mean over all elements (esrgan/trainer.py:451-452,468); ws >= 2048 floats */
+int srx_mean_fwd(const float* x, float* out, int64_t n, float* ws, void* stream);
+int srx_mean_bwd(const float* x, const float* gscale, float* dx, int64_t n, void* stream);
 /* sum of squared error -> used for PSNR (srgan/trainer.py:296) is srx_mse_fwd */
 
 /* --------------------------------------------------------------- optimiser */

@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 REF = '/root/reference'
 sys.path.insert(0, REF)
 
+from oracle import esrgan as OE  # noqa: E402
 from oracle import srgan as O  # noqa: E402
 from oracle.weights import closed_form_state, seeded_input, tensor_digest  # noqa: E402
 
@@ -350,6 +351,88 @@ def gen_steps():
     os.chdir(ROOT)
 
 
+def gen_esrgan():
+    """ESRGAN generator (2 RRDBs), discriminator (64 px) and the first two steps of the UNMODIFIED
+    ESRGANTrainer._gan_loop / pre-training body (full 23-RRDB generator, 128x128 crops, batch 2)."""
+    from torchsr.esrgan.discriminator import Discriminator
+    from torchsr.esrgan.generator import Generator
+    out = {}
+    ref = Generator(num_rrdb_blocks=2)
+    sd0 = closed_form_state(ref.state_dict())
+    seed = well_conditioned_seed(_dx_of(lambda sd, x: OE.generator_forward(sd, x), sd0, torch.float64),
+                                 _dx_of(lambda sd, x: OE.generator_forward(sd, x), sd0, torch.float32), (2, 3, 8, 10),
+                                 range(300, 320))
+    ref.load_state_dict(sd0)
+    x = seeded_input((2, 3, 8, 10), seed).requires_grad_(True)
+    y = ref(x)
+    loss = y.square().mean()
+    g = grads_of(ref, loss)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    leaves = O._leaves(sd)
+    xo = x.detach().clone().requires_grad_(True)
+    yo = OE.generator_forward(sd, xo)
+    yo.square().mean().backward()
+    check('ESRGAN G output', yo, y)
+    check('ESRGAN G dx', xo.grad, x.grad)
+    names = [k for k, v in sd0.items() if v.is_floating_point()]
+    for k, leaf in zip(names, leaves):
+        if k in ('conv1.weight', 'blocks.1.RDB2.conv3.0.weight', 'blocks.0.RDB1.conv5.bias', 'conv4.weight'):
+            check(f'ESRGAN G grad {k}', leaf.grad, g[k])
+    gk, gd = digest_table(g)
+    out.update(g_x=x.detach().numpy(), g_y=y.detach().numpy(), g_dx=x.grad.numpy(), g_grad_keys=gk, g_grad_digest=gd,
+               g_loss=np.float64(loss.item()))
+
+    refd = Discriminator(image_size=64)
+    sd0 = closed_form_state(refd.state_dict())
+    dfwd = lambda sd_, x_: OE.discriminator_forward(sd_, x_, True)  # noqa: E731
+    seed = well_conditioned_seed(_dx_of(dfwd, sd0, torch.float64), _dx_of(dfwd, sd0, torch.float32), (2, 3, 64, 64),
+                                 range(320, 340))
+    refd.load_state_dict(sd0)
+    x = seeded_input((2, 3, 64, 64), seed).requires_grad_(True)
+    refd.train()
+    logits = refd(x)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits - 0.3, torch.full((2, 1), 1.0))
+    g = grads_of(refd, loss)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    xo = x.detach().clone().requires_grad_(True)
+    lo = OE.discriminator_forward(sd, xo, True)
+    torch.nn.functional.binary_cross_entropy_with_logits(lo - 0.3, torch.full((2, 1), 1.0)).backward()
+    check('ESRGAN D logits', lo, logits)
+    check('ESRGAN D dx', xo.grad, x.grad)
+    gk, gd = digest_table(g)
+    out.update(d_x=x.detach().numpy(), d_logits=logits.detach().numpy(), d_dx_digest=tensor_digest(x.grad),
+               d_grad_keys=gk, d_grad_digest=gd, d_loss=np.float64(loss.item()))
+
+    os.chdir(REF)
+    from torchsr.esrgan.trainer import ESRGANTrainer
+    args = Namespace(disable_amp=True, batch_size=2, epochs=8, gan_checkpoint=None, local_rank=0, pretrain_epochs=1,
+                     psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1)
+    lr_img, hr_img = seeded_input((2, 3, 32, 32), 61), seeded_input((2, 3, 128, 128), 62)
+    t = ESRGANTrainer('cpu', args, [], [], 2, 2, distributed=False)
+    t.generator.load_state_dict(closed_form_state(t.generator.state_dict()))
+    t.discriminator.load_state_dict(closed_form_state(t.discriminator.state_dict()))
+    t.generator.train()
+    t.discriminator.train()
+    logged = []
+    t._log_wandb = lambda contents, step=None: logged.append(float(contents['gan/train-loss']))
+    orc = OE.ESRGANStepOracle(closed_form_state(t.generator.state_dict()),
+                              closed_form_state(t.discriminator.state_dict()),
+                              {k: v.clone() for k, v in t.vgg_loss.features.state_dict().items()})
+    losses = []
+    for step in range(2):
+        t._gan_loop(lr_img, hr_img, step)
+        res = orc.gan_step(lr_img, hr_img)
+        assert abs(res[4] - logged[-1]) <= (1e-6 if step == 0 else 2e-3) * max(1, abs(res[4])), (res, logged[-1])
+        losses.append(res)
+        print(f'  esrgan gan step {step}: disc {res[0]:.6f} pixel {res[1]:.6f} content {res[2]:.6f} adv {res[3]:.6f} '
+              f'gen {res[4]:.6f}')
+    check('ESRGAN step G conv4.weight', orc.g['conv4.weight'].detach(), t.generator.state_dict()['conv4.weight'], tol=1e-3)
+    out.update(low_res=lr_img.numpy(), high_res=hr_img.numpy(), gan_losses=np.array(losses),
+               gan_ref_gen_losses=np.array(logged))
+    np.savez_compressed(os.path.join(OUT, 'esrgan.npz'), **out)
+    os.chdir(ROOT)
+
+
 if __name__ == '__main__':
     import warnings
     warnings.simplefilter('ignore')
@@ -358,5 +441,6 @@ if __name__ == '__main__':
     print('discriminator'); gen_discriminator()
     print('vgg19'); gen_vgg()
     print('train steps'); gen_steps()
+    print('esrgan'); gen_esrgan()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -79,6 +79,18 @@ def test_oracle_first_gan_step_matches_reference_trainer_golden():
         assert abs(d[1] - dg[1]) <= 1e-5 * max(dg[1], 1e-9), k
 
 
+def test_oracle_esrgan_matches_reference_golden():
+    from oracle import esrgan as OE
+    from torchsr_amd.esrgan.discriminator import Discriminator
+    from torchsr_amd.esrgan.generator import Generator
+    gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
+    sd = closed_form_state(Generator(num_rrdb_blocks=2).state_dict())
+    assert rel(OE.generator_forward(sd, torch.from_numpy(gold['g_x'])), gold['g_y']) < 1e-5
+    sd = closed_form_state(Discriminator(image_size=64).state_dict())
+    assert rel(OE.discriminator_forward(sd, torch.from_numpy(gold['d_x']), True), gold['d_logits']) < 1e-5
+    assert len(Generator().state_dict()) == 702 and len(Discriminator().state_dict()) == 60
+
+
 # ------------------------------------------------------------------ C ABI
 def test_library_exports_every_declared_symbol():
     from torchsr_amd import _lib

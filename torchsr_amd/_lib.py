@@ -67,14 +67,19 @@ _SIGS = {
     'srx_conv2d_pack': (_I, [_D, _P, _P, _P, _P]),
     'srx_conv2d_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_data': (_I, [_D, _P, _P, _P, _P, _Z, _P]),
-    'srx_conv2d_bwd_weight': (_I, [_D, _P, _P, _P, _P, _Z, _P]),
+    'srx_conv2d_bwd_weight': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
     'srx_colsum_ws_floats': (_Z, [_L, _I]),
-    'srx_colsum': (_I, [_P, _P, _L, _I, _I, _P, _Z, _P]),
+    'srx_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     'srx_act_bwd_from_out': (_I, [_P, _P, _P, _L, _I, _F, _P]),
     'srx_prelu_fwd': (_I, [_P, _P, _P, _L, _P]),
-    'srx_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _L, _P, _P]),
+    'srx_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _I, _L, _P, _P]),
     'srx_lrelu_fwd': (_I, [_P, _P, _L, _F, _P]),
     'srx_axpby': (_I, [_P, _P, _P, _L, _F, _F, _P]),
+    'srx_copy_channels': (_I, [_P, _I, _I, _P, _I, _I, _I, _L, _I, _P]),
+    'srx_upsample_nearest2x_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'srx_upsample_nearest2x_bwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'srx_mean_fwd': (_I, [_P, _P, _L, _P, _P]),
+    'srx_mean_bwd': (_I, [_P, _P, _P, _L, _P]),
     'srx_sigmoid_fwd': (_I, [_P, _P, _L, _P]),
     'srx_sigmoid_bwd': (_I, [_P, _P, _P, _L, _P]),
     'srx_bn_stat_rows': (_I, [_L]),
@@ -83,14 +88,14 @@ _SIGS = {
     'srx_bn_eval_stats': (_I, [_P, _P, _I, _F, _P, _P, _P]),
     'srx_bn_act_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _P]),
     'srx_bn_bwd_ws_floats': (_Z, [_L, _I]),
-    'srx_bn_act_bwd_reduce': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _P, _Z, _P]),
+    'srx_bn_act_bwd_reduce': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_bn_act_bwd_apply': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _I, _P]),
     'srx_maxpool2x2_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'srx_maxpool2x2_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'srx_linear_ws_floats': (_Z, [_I, _I, _I]),
     'srx_linear_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _Z, _P]),
     'srx_linear_bwd_data': (_I, [_P, _P, _P, _I, _I, _I, _P, _Z, _P]),
-    'srx_linear_bwd_weight': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'srx_linear_bwd_weight': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'srx_mse_fwd': (_I, [_P, _P, _P, _L, _P, _P]),
     'srx_l1_fwd': (_I, [_P, _P, _P, _L, _P, _P]),
     'srx_mse_bwd': (_I, [_P, _P, _P, _P, _P, _L, _P]),

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int nb, float scale,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, int accumulate) {
   __shared__ double red[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < nb; i += 256) s += (double)partial[i];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = (float)(red[0] * (double)scale);
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + (float)(red[0] * (double)scale);
 }
 
 __global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ y,
@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C4 + q * 4) = t;
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int rows, int C, int C4, float* __restrict__ out) {
+__global__ void colsum_final_kernel(const float* __restrict__ part, int rows, int C, int C4, float* __restrict__ out,
+                                    int accumulate) {
   // one wave per column, lanes over the (<= 256) partial rows
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -185,15 +186,16 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int rows, in
   for (int r = lane; r < rows; r += 64) s += (double)part[(size_t)r * C4 + c];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) out[c] = (float)s;
+  if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 // fallback for a channel stride that is not a multiple of 4 (e.g. the [B][1] output of the last Linear)
-__global__ void colsum_scalar_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t M, int C, int Cs) {
+__global__ void colsum_scalar_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t M, int C, int Cs,
+                                     int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0;
   for (int64_t r = 0; r < M; ++r) s += (double)x[r * Cs + c];
-  out[c] = (float)s;
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 // ----------------------------------------------------------------- pooling
@@ -257,7 +259,83 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const float* __
   }
 }
 
+// dst[m][dst_off + c] (+)= src[m][src_off + c], c < C: channel concat / split of NHWC tensors
+__global__ void copy_channels_kernel(const float* __restrict__ src, int scs, int soff, float* __restrict__ dst, int dcs,
+                                     int doff, int C, int64_t M, int accumulate) {
+  const int cq = C / 4;
+  const int64_t total = M * cq;
+  GRID_STRIDE(i, total) {
+    const int64_t m = i / cq;
+    const int q = (int)(i - m * cq);
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + m * scs + soff + q * 4);
+    f32x4* d = reinterpret_cast<f32x4*>(dst + m * dcs + doff + q * 4);
+    if (accumulate) v += *d;
+    *d = v;
+  }
+}
+
+// F.interpolate(scale_factor=2, mode='nearest') on NHWC and its adjoint
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+  const int cq = C / 4;
+  const int64_t total = (int64_t)N * 2 * H * 2 * W * cq;
+  GRID_STRIDE(i, total) {
+    const int q = (int)(i % cq);
+    int64_t t = i / cq;
+    const int ow = (int)(t % (2 * W));
+    t /= 2 * W;
+    const int oh = (int)(t % (2 * H));
+    const int n = (int)(t / (2 * H));
+    *reinterpret_cast<f32x4*>(y + i * 4) =
+        *reinterpret_cast<const f32x4*>(x + (((int64_t)n * H + (oh >> 1)) * W + (ow >> 1)) * C + q * 4);
+  }
+}
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C) {
+  const int cq = C / 4;
+  const int64_t total = (int64_t)N * H * W * cq;
+  GRID_STRIDE(i, total) {
+    const int q = (int)(i % cq);
+    int64_t t = i / cq;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    const float* p = dy + (((int64_t)n * 2 * H + 2 * h) * 2 * W + 2 * w) * C + q * 4;
+    const f32x4 s = *reinterpret_cast<const f32x4*>(p) + *reinterpret_cast<const f32x4*>(p + C) +
+                    *reinterpret_cast<const f32x4*>(p + (int64_t)2 * W * C) +
+                    *reinterpret_cast<const f32x4*>(p + (int64_t)2 * W * C + C);
+    *reinterpret_cast<f32x4*>(dx + i * 4) = s;
+  }
+}
+
 }  // namespace
+
+extern "C" int srx_copy_channels(const float* src, int src_cs, int src_off, float* dst, int dst_cs, int dst_off, int C,
+                                 int64_t M, int accumulate, void* stream) {
+  SRX_REQUIRE(src && dst && C > 0 && M > 0, "copy_channels: bad argument");
+  SRX_REQUIRE(C % 4 == 0 && src_cs % 4 == 0 && dst_cs % 4 == 0 && src_off % 4 == 0 && dst_off % 4 == 0,
+              "copy_channels: channel counts and offsets must be multiples of 4");
+  SRX_REQUIRE(src_off + C <= src_cs && dst_off + C <= dst_cs, "copy_channels: slice out of range");
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(stream_grid(M * (C / 4))), dim3(256), 0, srx_stream(stream), src, src_cs,
+                     src_off, dst, dst_cs, dst_off, C, M, accumulate);
+  SRX_CHECK_LAUNCH("copy_channels_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_upsample_nearest2x_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  SRX_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "upsample_nearest2x_fwd: bad argument");
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(stream_grid((int64_t)N * 4 * H * W * (C / 4))), dim3(256), 0,
+                     srx_stream(stream), x, y, N, H, W, C);
+  SRX_CHECK_LAUNCH("upsample2x_fwd_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_upsample_nearest2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+  SRX_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "upsample_nearest2x_bwd: bad argument");
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(stream_grid((int64_t)N * H * W * (C / 4))), dim3(256), 0,
+                     srx_stream(stream), dy, dx, N, H, W, C);
+  SRX_CHECK_LAUNCH("upsample2x_bwd_kernel");
+  return SRX_OK;
+}
 
 extern "C" int srx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int Cs, void* stream) {
   SRX_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cs >= C, "nchw_to_nhwc: bad argument");
@@ -280,13 +358,14 @@ extern "C" size_t srx_colsum_ws_floats(int64_t M, int C) {
   return (size_t)srx_cdiv(M, rpb) * (size_t)srx_roundup(C, 4);
 }
 
-extern "C" int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, float* ws, size_t ws_floats,
-                          void* stream) {
+extern "C" int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, int accumulate, float* ws,
+                          size_t ws_floats, void* stream) {
   SRX_REQUIRE(x && out && ws && M > 0 && C > 0 && Cs >= C, "colsum: bad argument");
   hipStream_t st = srx_stream(stream);
   if (Cs % 4 != 0 || ((uintptr_t)x % 16) != 0) {
     SRX_REQUIRE(M <= 65536, "colsum: unaligned input only supported for small M");
-    hipLaunchKernelGGL(colsum_scalar_kernel, dim3((unsigned)srx_cdiv(C, 64)), dim3(64), 0, st, x, out, M, C, Cs);
+    hipLaunchKernelGGL(colsum_scalar_kernel, dim3((unsigned)srx_cdiv(C, 64)), dim3(64), 0, st, x, out, M, C, Cs,
+                       accumulate);
     SRX_CHECK_LAUNCH("colsum_scalar_kernel");
     return SRX_OK;
   }
@@ -299,7 +378,8 @@ extern "C" int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, 
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)rows, (unsigned)srx_cdiv(cq, qpb)), dim3(256), 0, st, x, ws,
                      M, C4, Cs, qpb, rpb);
   SRX_CHECK_LAUNCH("colsum_partial_kernel");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)srx_cdiv(C, 4)), dim3(256), 0, st, ws, rows, C, C4, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)srx_cdiv(C, 4)), dim3(256), 0, st, ws, rows, C, C4, out,
+                     accumulate);
   SRX_CHECK_LAUNCH("colsum_final_kernel");
   return SRX_OK;
 }
@@ -329,15 +409,15 @@ extern "C" int srx_lrelu_fwd(const float* x, float* y, int64_t n, float slope, v
   return SRX_OK;
 }
 
-extern "C" int srx_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx, float* dslope, int64_t n,
-                             float* ws, void* stream) {
+extern "C" int srx_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx, float* dslope,
+                             int accumulate, int64_t n, float* ws, void* stream) {
   SRX_REQUIRE(dy && x && slope && dx && dslope && ws && n > 0, "prelu_bwd: bad argument");
   unsigned nb = stream_grid(n / 4);
   if (nb > 1024) nb = 1024;
   hipStream_t st = srx_stream(stream);
   hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nb), dim3(256), 0, st, dy, x, slope, dx, ws, n);
   SRX_CHECK_LAUNCH("prelu_bwd_kernel");
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, ws, (int)nb, 1.0f, dslope);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, ws, (int)nb, 1.0f, dslope, accumulate);
   SRX_CHECK_LAUNCH("sum_partials_kernel");
   return SRX_OK;
 }

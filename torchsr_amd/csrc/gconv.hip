@@ -454,7 +454,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
 
 // slab sums -> OIHW gradient
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int Cnw, int Kw, int K, int Ck,
-                                    int Cout, int Cin, int KH, int KW, int shuffle_cps, float* __restrict__ dw) {
+                                    int Cout, int Cin, int KH, int KW, int shuffle_cps, float* __restrict__ dw,
+                                    int accumulate) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)Cout * K) return;
   const int np = (int)(idx / K), k = (int)(idx - (int64_t)np * K);
@@ -465,7 +466,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, 
   int co = np;
   if (shuffle_cps) { const int ij = np / shuffle_cps, cc = np - ij * shuffle_cps; co = cc * 4 + ij; }
   const int kh = tap / KW, kw = tap - kh * KW;
-  dw[(((size_t)co * Cin + ci) * KH + kh) * KW + kw] = s;
+  float* o = dw + (((size_t)co * Cin + ci) * KH + kh) * KW + kw;
+  *o = accumulate ? *o + s : s;
 }
 
 // ---------------------------------------------------------------------------
@@ -862,8 +864,8 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
   return SRX_OK;
 }
 
-extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, const float* dy, float* dw, float* ws,
-                                     size_t ws_floats, void* stream) {
+extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, const float* dy, float* dw, int accumulate,
+                                     float* ws, size_t ws_floats, void* stream) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(x && dy && dw && ws, "conv2d_bwd_weight: null pointer");
   hipStream_t st = srx_stream(stream);
@@ -899,7 +901,7 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
   SRX_CHECK_LAUNCH("wgrad_kernel");
   const int64_t n = (int64_t)d->Cout * g.K;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, st, ws, nsplit, a.Cnw, a.Kw,
-                     g.K, g.Ck, d->Cout, d->Cin, d->KH, d->KW, g.cps, dw);
+                     g.K, g.Ck, d->Cout, d->Cin, d->KH, d->KW, g.cps, dw, accumulate);
   SRX_CHECK_LAUNCH("wgrad_reduce_kernel");
   return SRX_OK;
 }

@@ -126,7 +126,7 @@ __global__ void sum_slabs_kernel(const float* __restrict__ part, int nsplit, int
 // dw[j][k] = sum_b dy[b][j] x[b][k];  wave = 16 j rows x 64 k columns
 __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ dy, float* __restrict__ dw,
-                                                                int B, int K, int J) {
+                                                                int B, int K, int J, int accumulate) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, h = lane >> 4;
   const int n0 = (blockIdx.x * 4 + wave) * 64;
@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* __r
       const int jj = j0 + 4 * h + g;
       if (jj < J) {
         f32x4 o = {acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
-        *reinterpret_cast<f32x4*>(dw + (size_t)jj * K + kcol) = o;
+        f32x4* dst = reinterpret_cast<f32x4*>(dw + (size_t)jj * K + kcol);
+        if (accumulate) o += *dst;
+        *dst = o;
       }
     }
   }
@@ -226,11 +228,12 @@ extern "C" int srx_linear_bwd_data(const float* dy, const float* w, float* dx, i
   return SRX_OK;
 }
 
-extern "C" int srx_linear_bwd_weight(const float* x, const float* dy, float* dw, int B, int K, int J, void* stream) {
+extern "C" int srx_linear_bwd_weight(const float* x, const float* dy, float* dw, int accumulate, int B, int K, int J,
+                                     void* stream) {
   SRX_REQUIRE(x && dy && dw && B > 0 && K > 0 && J > 0, "linear_bwd_weight: bad argument");
   SRX_REQUIRE(K % 4 == 0, "linear_bwd_weight: in_features must be a multiple of 4");
   hipLaunchKernelGGL(linear_bwd_weight_kernel, dim3((unsigned)srx_cdiv(K, 256), (unsigned)srx_cdiv(J, 16)), dim3(256),
-                     0, srx_stream(stream), x, dy, dw, B, K, J);
+                     0, srx_stream(stream), x, dy, dw, B, K, J, accumulate);
   SRX_CHECK_LAUNCH("linear_bwd_weight_kernel");
   return SRX_OK;
 }

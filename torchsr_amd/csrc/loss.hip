@@ -5,7 +5,7 @@
 
 namespace {
 
-enum { L_MSE = 0, L_L1 = 1, L_BCE = 2, L_BCE_LOGITS = 3 };
+enum { L_MSE = 0, L_L1 = 1, L_BCE = 2, L_BCE_LOGITS = 3, L_MEAN = 4 };
 
 __device__ __forceinline__ float loss_term(int kind, float a, float b, float target) {
   if (kind == L_MSE) { const float d = a - b; return d * d; }
@@ -15,6 +15,7 @@ __device__ __forceinline__ float loss_term(int kind, float a, float b, float tar
     const float lp = fmaxf(logf(a), -100.f), lq = fmaxf(log1pf(-a), -100.f);
     return -(target * lp + (1.f - target) * lq);
   }
+  if (kind == L_MEAN) return a;
   // BCEWithLogits: (1-t)*x + log(1+exp(-|x|)) + max(-x,0)   (a = logit - shift)
   return (1.f - target) * a + fmaxf(-a, 0.f) + log1pf(expf(-fabsf(a)));
 }
@@ -64,6 +65,8 @@ __global__ void loss_bwd_kernel(int kind, const float* __restrict__ a, const flo
     else if (kind == L_BCE) {
       // torch: grad * (p - t) / max((1-p)*p, 1e-12)
       d = (av - target) / fmaxf((1.f - av) * av, 1e-12f);
+    } else if (kind == L_MEAN) {
+      d = 1.f;
     } else {
       d = 1.f / (1.f + expf(-av)) - target;  // sigmoid(x) - t
     }
@@ -135,4 +138,11 @@ extern "C" int srx_bce_logits_fwd(const float* x, const float* shift, float targ
 extern "C" int srx_bce_logits_bwd(const float* x, const float* shift, float target, const float* gscale, float* dx,
                                   int64_t n, void* stream) {
   return loss_bwd(L_BCE_LOGITS, x, nullptr, shift, target, gscale, dx, nullptr, n, stream, "bce_logits_bwd");
+}
+// torch.mean over all elements (relativistic average terms, esrgan/trainer.py:451-452,468)
+extern "C" int srx_mean_fwd(const float* x, float* out, int64_t n, float* ws, void* stream) {
+  return loss_fwd(L_MEAN, x, nullptr, nullptr, 0.f, out, n, ws, stream, "mean_fwd");
+}
+extern "C" int srx_mean_bwd(const float* x, const float* gscale, float* dx, int64_t n, void* stream) {
+  return loss_bwd(L_MEAN, x, nullptr, nullptr, 0.f, gscale, dx, nullptr, n, stream, "mean_bwd");
 }

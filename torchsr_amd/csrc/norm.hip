@@ -170,7 +170,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ ws, int rows, int C,
-                                                              float* __restrict__ sums) {
+                                                              float* __restrict__ sums, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ dprelu) {
   // one wave per column: lanes stride over the partial rows (a few hundred at most), fp64 butterfly
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -179,7 +180,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   for (int r = lane; r < rows; r += 64) s += (double)ws[(size_t)r * (2 * C + 4) + c];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) sums[c] = (float)s;
+  if (lane == 0) {
+    sums[c] = (float)s;
+    // optional direct accumulation into the parameters' .grad buffers (saves three tiny adds per layer)
+    if (c < C) { if (dbeta) dbeta[c] += (float)s; }
+    else if (c < 2 * C) { if (dgamma) dgamma[c - C] += (float)s; }
+    else if (dprelu) dprelu[0] += (float)s;
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
@@ -279,7 +286,8 @@ extern "C" size_t srx_bn_bwd_ws_floats(int64_t M, int C) { return (size_t)srx_bn
 
 extern "C" int srx_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, float* sums, int64_t M, int C, int act,
-                                     float slope, const float* prelu, float* ws, size_t ws_floats, void* stream) {
+                                     float slope, const float* prelu, float* dgamma_acc, float* dbeta_acc,
+                                     float* dprelu_acc, float* ws, size_t ws_floats, void* stream) {
   if (int rc = check_c(C, "bn_act_bwd_reduce")) return rc;
   SRX_REQUIRE(dout && y && mean && invstd && gamma && beta && sums && ws && M > 0, "bn_act_bwd_reduce: bad argument");
   SRX_REQUIRE(act != SRX_ACT_PRELU || prelu, "bn_act_bwd_reduce: PReLU needs its slope pointer");
@@ -290,7 +298,7 @@ extern "C" int srx_bn_act_bwd_reduce(const float* dout, const float* y, const fl
                      ws, M, C, act, slope, prelu);
   SRX_CHECK_LAUNCH("bn_bwd_reduce_kernel");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)srx_cdiv(2 * C + 1, 4)), dim3(256), 0, st, ws, rows, C,
-                     sums);
+                     sums, dgamma_acc, dbeta_acc, dprelu_acc);
   SRX_CHECK_LAUNCH("bn_bwd_finalize_kernel");
   return SRX_OK;
 }

@@ -1,8 +1,39 @@
-"""ESRGAN generator placeholder (filled in below in this round)."""
-from torch import nn
+"""ESRGAN generator (RRDBNet) -- interface of torchsr/esrgan/generator.py:32-81."""
+from torch import nn, Tensor
+
+from .. import functional as F
+from ..layers import ACT_LRELU, Conv2d, Marker
+from .residual import ResidualInResidualDenseBlock
+
+NUM_RESIDUAL = 23  # torchsr/esrgan/generator.py:20
 
 
 class Generator(nn.Module):
-    def __init__(self, num_rrdb_blocks: int = 23) -> None:
+    """``Generator(num_rrdb_blocks=23)``; ``forward([N,3,h,w]) -> [N,3,4h,4w]``.
+
+    No BatchNorm, no PixelShuffle: two nearest-neighbour x2 upsamples, each followed by a
+    conv + LeakyReLU (fused epilogue).
+    """
+
+    def __init__(self, num_rrdb_blocks: int = NUM_RESIDUAL) -> None:
         super().__init__()
-        raise NotImplementedError('ESRGAN generator: in progress')
+        self.conv1 = Conv2d(3, 64, kernel_size=3, stride=1, padding=1)
+        self.blocks = nn.Sequential(*[ResidualInResidualDenseBlock(channels=64, growth_channels=32, scale_ratio=0.2)
+                                      for _ in range(num_rrdb_blocks)])
+        self.conv2 = Conv2d(64, 64, kernel_size=3, stride=1, padding=1)
+        self.upsample1 = Conv2d(64, 64, kernel_size=3, stride=1, padding=1, act=ACT_LRELU, slope=0.2)
+        self.upsample2 = Conv2d(64, 64, kernel_size=3, stride=1, padding=1, act=ACT_LRELU, slope=0.2)
+        self.conv3 = nn.Sequential(Conv2d(64, 64, kernel_size=3, stride=1, padding=1, act=ACT_LRELU, slope=0.2),
+                                   Marker('LeakyReLU(0.2) (conv epilogue)'))
+        self.conv4 = Conv2d(64, 3, kernel_size=3, stride=1, padding=1)
+
+    def forward_nhwc(self, x4: Tensor) -> Tensor:
+        conv1 = self.conv1(x4)
+        conv2 = self.conv2(self.blocks(conv1))
+        out = F.axpby(conv1, conv2, 1.0, 1.0)                       # torch.add, generator.py:72
+        out = self.upsample1(F.upsample_nearest2x(out))             # :73-75
+        out = self.upsample2(F.upsample_nearest2x(out))             # :76-78
+        return self.conv4(self.conv3[0](out))                       # :79-80
+
+    def forward(self, x: Tensor) -> Tensor:
+        return F.to_nchw(self.forward_nhwc(F.to_nhwc(x, 4)), 3)

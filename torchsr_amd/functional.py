@@ -37,6 +37,21 @@ def _prof_call(kind, d, name, *args):
     return r
 
 
+# When enabled (by the trainers, whose parameters' ``.grad`` are persistent views of one flat
+# buffer) parameter gradients are accumulated straight into ``param.grad`` by the kernels and the
+# Functions return ``None`` for them: no per-parameter AccumulateGrad add kernels (~200 per step).
+direct_grads = [False]
+
+
+def _sink(param: Optional[Tensor]) -> Optional[Tensor]:
+    if not direct_grads[0] or param is None or not param.requires_grad:
+        return None
+    g = param.grad
+    if g is None or not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous():
+        return None
+    return g
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -197,6 +212,7 @@ class _Conv2d(Function):
         _prof_call('fwd', d, 'srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(b), _p(y), _p(part), _p(ws), nws, _stream())
         ctx.st, ctx.d = st, d
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         ctx.save_for_backward(x, y if st.act != ACT_NONE else None)
         ctx.wpk_bwd = st.wpk_bwd
         if want_stats:
@@ -222,26 +238,35 @@ class _Conv2d(Function):
             nws = L.srx_conv2d_bwd_data_ws_floats(dref)
             ws = _ws(nws, x) if nws else None
             _prof_call('dgrad', d, 'srx_conv2d_bwd_data', dref, _p(dy), _p(ctx.wpk_bwd), _p(dx), _p(ws), nws, s)
+        wparam, bparam = ctx.params
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((st.cout, st.cin, st.k, st.k), dtype=torch.float32, device=x.device)
+            sink = _sink(wparam)
+            dw = None if sink is not None else torch.empty((st.cout, st.cin, st.k, st.k), dtype=torch.float32,
+                                                             device=x.device)
             nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
             ws = _ws(nws, x)
-            _prof_call('wgrad', d, 'srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw), _p(ws), nws, s)
+            _prof_call('wgrad', d, 'srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw if sink is None else sink),
+                       0 if sink is None else 1, _p(ws), nws, s)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            if st.shuffle:
+            sink = None if st.shuffle else _sink(bparam)
+            if sink is not None:
+                m = dy.numel() // st.cout_s
+                nws = L.srx_colsum_ws_floats(m, st.cout)
+                call('srx_colsum', _p(dy), _p(sink), m, st.cout, st.cout_s, 1, _p(_ws(nws, dy)), nws, s)
+            elif st.shuffle:
                 # dy is [N, 2Ho, 2Wo, cps]; bias index co = c*4 + i*2 + j
                 n, h2, w2, cps = dy.shape
                 rows, cols = n * (h2 // 2), 2 * w2 * cps
                 t = torch.empty(cols, dtype=torch.float32, device=dy.device)
                 nws = L.srx_colsum_ws_floats(rows, cols)
-                call('srx_colsum', _p(dy), _p(t), rows, cols, cols, _p(_ws(nws, dy)), nws, s)
+                call('srx_colsum', _p(dy), _p(t), rows, cols, cols, 0, _p(_ws(nws, dy)), nws, s)
                 # t is [i][wo][j][c]; fold wo (tiny tensor, plumbing) and permute to (c,i,j)
                 db = t.view(2, w2 // 2, 2, cps).sum(1).permute(2, 0, 1).reshape(-1)[:st.cout].contiguous()
             else:
                 m = dy.numel() // st.cout_s
                 db = torch.empty(st.cout, dtype=torch.float32, device=dy.device)
                 nws = L.srx_colsum_ws_floats(m, st.cout)
-                call('srx_colsum', _p(dy), _p(db), m, st.cout, st.cout_s, _p(_ws(nws, dy)), nws, s)
+                call('srx_colsum', _p(dy), _p(db), m, st.cout, st.cout_s, 0, _p(_ws(nws, dy)), nws, s)
         return dx, dw, db, None, None, None
 
 
@@ -280,6 +305,7 @@ class _BNAct(Function):
         call('srx_bn_act_fwd', _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), m, c, act, slope, _p(pw), s)
         ctx.save_for_backward(y, mean, invstd, g, b, pw)
         ctx.cfg = (m, c, act, slope, training, residual is not None, prelu is not None)
+        ctx.params = (gamma, beta, prelu)
         return out
 
     @staticmethod
@@ -290,16 +316,17 @@ class _BNAct(Function):
         s = _stream()
         sums = torch.empty(2 * c + 4, dtype=torch.float32, device=y.device)
         nws = _lib.lib().srx_bn_bwd_ws_floats(m, c)
+        gs, bs, ps = (_sink(t) for t in ctx.params)
         call('srx_bn_act_bwd_reduce', _p(dout), _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(sums), m, c, act, slope,
-             _p(pw), _p(_ws(nws, y)), nws, s)
+             _p(pw), _p(gs), _p(bs), _p(ps), _p(_ws(nws, y)), nws, s)
         dy = None
         if ctx.needs_input_grad[0]:
             dy = torch.empty_like(y)
             call('srx_bn_act_bwd_apply', _p(dout), _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(sums), _p(dy), m, c,
                  act, slope, _p(pw), 1 if training else 0, s)
-        dgamma = sums[c:2 * c] if ctx.needs_input_grad[2] else None
-        dbeta = sums[:c] if ctx.needs_input_grad[3] else None
-        dprelu = sums[2 * c:2 * c + 1] if (has_prelu and ctx.needs_input_grad[4]) else None
+        dgamma = sums[c:2 * c] if (ctx.needs_input_grad[2] and gs is None) else None
+        dbeta = sums[:c] if (ctx.needs_input_grad[3] and bs is None) else None
+        dprelu = sums[2 * c:2 * c + 1] if (has_prelu and ctx.needs_input_grad[4] and ps is None) else None
         dres = dout if (has_res and ctx.needs_input_grad[5]) else None
         return dy, None, dgamma, dbeta, dprelu, dres, None, None, None, None, None, None, None, None
 
@@ -323,6 +350,7 @@ class _PReLU(Function):
         y = torch.empty_like(x)
         call('srx_prelu_fwd', _p(x), _p(wd), _p(y), x.numel(), _stream())
         ctx.save_for_backward(x, wd)
+        ctx.param = w
         return y
 
     @staticmethod
@@ -330,8 +358,10 @@ class _PReLU(Function):
         x, w = ctx.saved_tensors
         dy = _chk(dy, 'prelu.grad')
         dx = torch.empty_like(x)
-        dw = torch.empty(1, dtype=torch.float32, device=x.device)
-        call('srx_prelu_bwd', _p(dy), _p(x), _p(w), _p(dx), _p(dw), x.numel(), _p(_ws(1024, x)), _stream())
+        sink = _sink(ctx.param) if ctx.needs_input_grad[1] else None
+        dw = None if sink is not None else torch.empty(1, dtype=torch.float32, device=x.device)
+        call('srx_prelu_bwd', _p(dy), _p(x), _p(w), _p(dx), _p(dw if sink is None else sink), 0 if sink is None else 1,
+             x.numel(), _p(_ws(1024, x)), _stream())
         return dx, dw
 
 
@@ -455,6 +485,7 @@ class _Linear(Function):
         b = None if bias is None else _chk(bias.detach(), 'linear.bias')
         call('srx_linear_fwd', _p(x), _p(wd), _p(b), _p(y), bsz, k, j, act, slope, _p(_ws(nws, x)), nws, _stream())
         ctx.cfg = (bsz, k, j, act, slope, bias is not None, nws)
+        ctx.params = (w, bias)
         ctx.save_for_backward(x, wd, y if act != ACT_NONE else None)
         return y
 
@@ -472,13 +503,18 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             call('srx_linear_bwd_data', _p(dy), _p(w), _p(dx), bsz, k, j, _p(_ws(nws, x)), nws, s)
+        wparam, bparam = ctx.params
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            call('srx_linear_bwd_weight', _p(x), _p(dy), _p(dw), bsz, k, j, s)
+            sink = _sink(wparam)
+            dw = None if sink is not None else torch.empty_like(w)
+            call('srx_linear_bwd_weight', _p(x), _p(dy), _p(dw if sink is None else sink), 0 if sink is None else 1,
+                 bsz, k, j, s)
         if has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(j, dtype=torch.float32, device=x.device)
+            sink = _sink(bparam)
+            db = None if sink is not None else torch.empty(j, dtype=torch.float32, device=x.device)
             n2 = _lib.lib().srx_colsum_ws_floats(bsz, j)
-            call('srx_colsum', _p(dy), _p(db), bsz, j, j, _p(_ws(n2, x)), n2, s)
+            call('srx_colsum', _p(dy), _p(db if sink is None else sink), bsz, j, j, 0 if sink is None else 1,
+                 _p(_ws(n2, x)), n2, s)
         return dx, dw, db, None, None
 
 
@@ -571,3 +607,88 @@ class _BCELogits(Function):
 def bce_with_logits(x: Tensor, target: float, shift: Optional[Tensor] = None) -> Tensor:
     """nn.BCEWithLogitsLoss()(x - shift, full(target)) (esrgan/trainer.py:451-453)."""
     return _BCELogits.apply(x, shift, float(target))
+
+
+class _Mean(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        x = _chk(x, 'mean.input')
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        call('srx_mean_fwd', _p(x), _p(out), x.numel(), _p(_ws(2048, x)), _stream())
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (x,) = ctx.saved_tensors
+        g = _chk(g, 'mean.grad')
+        dx = torch.empty_like(x)
+        call('srx_mean_bwd', _p(x), _p(g), _p(dx), x.numel(), _stream())
+        return dx
+
+
+def mean(x: Tensor) -> Tensor:
+    """torch.mean(x) over all elements (esrgan/trainer.py:451-452)."""
+    return _Mean.apply(x)
+
+
+# --------------------------------------------------------------------------- ESRGAN helpers
+class _ConcatChannels(Function):
+    """torch.cat(tensors, dim=1) of the reference's NCHW tensors == channel concat in NHWC."""
+
+    @staticmethod
+    def forward(ctx, *xs: Tensor):
+        xs = [_chk(x, 'concat.input') for x in xs]
+        lead = xs[0].shape[:-1]
+        cs = [x.shape[-1] for x in xs]
+        m = xs[0].numel() // cs[0]
+        out = torch.empty(tuple(lead) + (sum(cs),), dtype=torch.float32, device=xs[0].device)
+        off, s = 0, _stream()
+        for x, c in zip(xs, cs):
+            call('srx_copy_channels', _p(x), c, 0, _p(out), sum(cs), off, c, m, 0, s)
+            off += c
+        ctx.cs, ctx.m = cs, m
+        return out
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        dy = _chk(dy, 'concat.grad')
+        total, s = sum(ctx.cs), _stream()
+        grads, off = [], 0
+        for i, c in enumerate(ctx.cs):
+            if ctx.needs_input_grad[i]:
+                g = torch.empty(dy.shape[:-1] + (c,), dtype=torch.float32, device=dy.device)
+                call('srx_copy_channels', _p(dy), total, off, _p(g), c, 0, c, ctx.m, 0, s)
+                grads.append(g)
+            else:
+                grads.append(None)
+            off += c
+        return tuple(grads)
+
+
+def concat_channels(xs) -> Tensor:
+    return _ConcatChannels.apply(*xs)
+
+
+class _Upsample2x(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        x = _chk(x, 'upsample.input')
+        n, h, w, c = x.shape
+        y = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.float32, device=x.device)
+        call('srx_upsample_nearest2x_fwd', _p(x), _p(y), n, h, w, c, _stream())
+        ctx.shape = (n, h, w, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        dy = _chk(dy, 'upsample.grad')
+        n, h, w, c = ctx.shape
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+        call('srx_upsample_nearest2x_bwd', _p(dy), _p(dx), n, h, w, c, _stream())
+        return dx
+
+
+def upsample_nearest2x(x: Tensor) -> Tensor:
+    """F.interpolate(x, scale_factor=2, mode='nearest') (esrgan/generator.py:73,76) on NHWC."""
+    return _Upsample2x.apply(x)

@@ -57,6 +57,8 @@ class SRGANTrainer:
     """
 
     phase_prefix = 'srgan'
+    generator_cls = Generator
+    discriminator_cls = Discriminator
 
     def __init__(self, device, args: Namespace, train_loader, test_loader, train_len: int, test_len: int,
                  distributed: bool = False) -> None:
@@ -90,6 +92,7 @@ class SRGANTrainer:
         self._graph_pool = None
         self._calls: Dict[str, int] = {}
         self._static: Dict[str, Tensor] = {}
+        F.direct_grads[0] = True  # parameter gradients accumulate straight into the flat .grad views
         self._initialize_trainer()
         self._create_test_image()
 
@@ -101,8 +104,8 @@ class SRGANTrainer:
 
     def _initialize_models(self) -> None:
         """trainer.py:136-157.  DDP wrapping is replaced by flat buffers + explicit all-reduce."""
-        self.generator = Generator().to(self.device)
-        self.discriminator = Discriminator().to(self.device)
+        self.generator = self.generator_cls().to(self.device)
+        self.discriminator = self.discriminator_cls().to(self.device)
         if self.distributed:
             broadcast_module(self.generator)
             broadcast_module(self.discriminator)
@@ -114,6 +117,7 @@ class SRGANTrainer:
     def _initialize_loss(self) -> None:
         """trainer.py:159-165 (MSELoss / BCELoss are kernels in torchsr_amd.functional)."""
         self.mse_loss = F.mse_loss
+        self.pixel_loss = F.mse_loss  # pre-training objective (trainer.py:384)
         self.bce_loss = F.bce_loss
         self.vgg_loss = VGGLoss(weights=self.vgg_weights).to(self.device)
 
@@ -210,7 +214,7 @@ class SRGANTrainer:
         """Loop body of ``_pretrain``, trainer.py:380-388 (no autocast / GradScaler: fp32)."""
         self.psnr_optimizer.zero_grad()
         super_res = self.generator(self._static['low_res'])
-        loss = self.mse_loss(super_res, self._static['high_res'])
+        loss = self.pixel_loss(super_res, self._static['high_res'])
         loss.backward()
         self._losses['psnr/train-loss'] = loss.detach()
 
