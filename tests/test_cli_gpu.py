@@ -1,0 +1,45 @@
+"""End-to-end CLI on the GPU: a tiny two-phase training run, checkpoint files, then the `test`
+sub-command (which the reference cannot run) and tiled == untiled inference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_then_test_cli(dev, tmp_path, monkeypatch):
+    from PIL import Image
+    from torchsr_amd.torchsr import main
+    monkeypatch.chdir(tmp_path)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'SLURM_NTASKS'):
+        monkeypatch.delenv(k, raising=False)
+    main(['train', '--model', 'srgan', '--train-dir', 'synthetic:16', '--batch-size', '4', '--epochs', '2',
+          '--pretrain-epochs', '1', '--disable-amp', '--seed', '3'])
+    for f in ('srgan-psnr-best.pth', 'srgan-psnr-latest.pth', 'srgan-gan-best.pth', 'srgan-gan-latest.pth',
+              'output/SR_epoch1.png'):
+        assert os.path.exists(f), f
+    ckpt = torch.load('srgan-gan-latest.pth', map_location='cpu')
+    assert set(ckpt) == {'epoch', 'phase', 'state'} and ckpt['phase'] == 'srgan-gan' and len(ckpt['state']) == 225
+    Image.fromarray((np.random.rand(20, 28, 3) * 255).astype('uint8')).save('lr.png')
+    main(['test', 'lr.png', '--model', 'srgan'])
+    out = Image.open('upres-lr.png')
+    assert out.size == (112, 80)
+
+
+def test_tiled_inference_equals_untiled(dev):
+    from torchsr_amd.srgan.generator import Generator
+    from torchsr_amd.test import upscale
+    torch.manual_seed(1)
+    gen = Generator().to(dev)
+    with torch.no_grad():
+        for m in gen.modules():  # non-trivial running statistics
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    lr = torch.rand(1, 3, 150, 210, device=dev)
+    whole = upscale(gen, lr, max_tile_pixels=10 ** 9)
+    tiled = upscale(gen, lr, halo=48, max_tile_pixels=150 * 110)
+    assert whole.shape == (1, 3, 600, 840)
+    assert (whole - tiled).abs().max().item() <= 1e-4 * whole.abs().max().item()

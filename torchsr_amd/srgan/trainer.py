@@ -84,7 +84,8 @@ class SRGANTrainer:
         if self.device.type != 'cuda':
             raise RuntimeError('torchsr_amd trains on an MI355X (device "cuda"); there is no CPU path')
         if self.device.index is None:
-            self.device = torch.device('cuda', self.local_rank if self.local_rank is not None else 0)
+            # single-process runs carry local_rank -1 (torchsr.py:148-150)
+            self.device = torch.device('cuda', max(int(self.local_rank or 0), 0))
         torch.cuda.set_device(self.device)
         if self.save_image and self.main_process and not os.path.exists('output'):
             os.makedirs('output')

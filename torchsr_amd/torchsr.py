@@ -1,0 +1,132 @@
+"""``torchsr`` command line -- interface of torchsr/torchsr.py:157-270 (same sub-commands, flags
+and defaults; ``python -m torchsr_amd.torchsr train ...``).
+
+Differences, all deliberate: the process group backend stays ``nccl`` (= RCCL over xGMI on ROCm)
+but falls back to ``gloo`` when no GPU is visible so the launcher itself is testable; the ``test``
+sub-command works (the reference's crashes on ``args.seed``); ``--epochs < 8`` no
+longer divides by zero; ``--train-dir synthetic:N`` trains on N seeded random crops.
+"""
+import os
+import random
+from argparse import ArgumentParser, ArgumentTypeError, Namespace
+from typing import Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from torchsr_amd.constants import BATCH_SIZE, EPOCHS, MODEL, PRE_EPOCHS, TRAIN_DIR
+from torchsr_amd.models import MODELS, select_test_model, select_trainer_model
+
+
+def positive_integer(value: str) -> int:
+    """torchsr.py:36-66."""
+    try:
+        int_value = int(value)
+    except (TypeError, ValueError):
+        raise ArgumentTypeError(f'invalid int value: \'{value}\'')
+    if int_value < 1:
+        raise ArgumentTypeError('value must be a positive integer!')
+    return int_value
+
+
+def get_device(args: Namespace) -> torch.device:
+    """torchsr.py:69-98."""
+    count = torch.cuda.device_count()
+    if args.local_world_size > count:
+        print('More processes per node requested than GPUs found')
+        print('Assuming CPU-only mode...')
+        return torch.device('cpu')
+    if count < 1 or not torch.cuda.is_available():
+        print('No GPUs found')
+        print('Running in CPU-only mode...')
+        return torch.device('cpu')
+    return torch.device('cuda')
+
+
+def distributed_params(args: Namespace) -> Tuple[Namespace, bool]:
+    """torchsr.py:101-154: torchrun env, then Slurm env, else single process (rank -1)."""
+    try:
+        args.world_size = int(os.environ['WORLD_SIZE'])
+        args.rank = int(os.environ['RANK'])
+        args.local_rank = int(os.environ['LOCAL_RANK'])
+        args.local_world_size = int(os.environ['LOCAL_WORLD_SIZE'])
+        distributed = True
+    except (KeyError, ValueError):
+        try:
+            args.world_size = int(os.environ['SLURM_NTASKS'])
+            args.rank = int(os.environ['SLURM_PROCID'])
+            args.local_rank = int(os.environ['SLURM_LOCALID'])
+            args.local_world_size = int(os.environ['SLURM_NTASKS_PER_NODE'])
+            os.environ['RANK'] = str(args.rank)
+            os.environ['WORLD_SIZE'] = str(args.world_size)
+            distributed = True
+        except (KeyError, ValueError):
+            distributed = False
+    if not distributed:
+        args.world_size, args.rank, args.local_rank, args.local_world_size = 1, -1, -1, 1
+    if getattr(args, 'seed', 0):
+        torch.manual_seed(args.seed + args.rank)
+    return args, distributed
+
+
+def parse_args(argv=None) -> Namespace:
+    """torchsr.py:157-236."""
+    parser = ArgumentParser(description='Super-resolution training and inference on AMD Instinct MI355X')
+    commands = parser.add_subparsers(dest='function', metavar='function', required=True)
+    train = commands.add_parser('train', help='Train an SRGAN / ESRGAN model against an HD dataset.')
+    train.add_argument('--batch-size', type=int, default=BATCH_SIZE)
+    train.add_argument('--data-workers', type=positive_integer, default=16)
+    train.add_argument('--dataset-multiplier', type=positive_integer, default=1)
+    train.add_argument('--disable-amp', action='store_true')
+    train.add_argument('--epochs', type=int, default=EPOCHS)
+    train.add_argument('--gan-checkpoint', type=str, default=None)
+    train.add_argument('--master-addr', type=str, default=None)
+    train.add_argument('--master-port', type=str, default=None)
+    train.add_argument('--model', type=str, default=MODEL, choices=MODELS.keys())
+    train.add_argument('--pretrain-epochs', type=int, default=PRE_EPOCHS)
+    train.add_argument('--psnr-checkpoint', type=str, default=None)
+    train.add_argument('--seed', type=int, default=0)
+    train.add_argument('--skip-image-save', action='store_true')
+    train.add_argument('--train-dir', type=str, default=TRAIN_DIR)
+    train.add_argument('--vgg-weights', type=str, default=None, help='path to vgg19-dcbb9e9d.pth')
+    train.add_argument('--no-graphs', action='store_true', help='run the step eagerly instead of as a hipGraph')
+    test = commands.add_parser('test', help='Generate a super resolution image from a trained model.')
+    test.add_argument('image', type=str)
+    test.add_argument('--model', type=str, default=MODEL, choices=MODELS.keys())
+    return parser.parse_args(argv)
+
+
+def main(argv=None) -> None:
+    """torchsr.py:239-270."""
+    args = parse_args(argv)
+    args, distributed = distributed_params(args)
+    device = get_device(args)
+    if args.function == 'test':
+        from torchsr_amd.test import test
+        test(args, select_test_model(args), device)
+        return
+    model_class, crop_size = select_trainer_model(args)
+    if args.seed:
+        random.seed(args.seed)
+        np.random.seed(args.seed)
+    if distributed:
+        if args.master_addr:
+            os.environ['MASTER_ADDR'] = args.master_addr
+        if args.master_port:
+            os.environ['MASTER_PORT'] = args.master_port
+        dist.init_process_group(backend='nccl' if device.type == 'cuda' else 'gloo')
+    args.use_graphs = not args.no_graphs
+    from torchsr_amd.dataset import initialize_datasets
+    train_loader, test_loader, train_len, test_len = initialize_datasets(
+        args.train_dir, batch_size=args.batch_size, crop_size=crop_size, upscale_factor=4,
+        dataset_multiplier=args.dataset_multiplier, workers=args.data_workers, distributed=distributed,
+        seed=args.seed)
+    trainer = model_class(device, args, train_loader, test_loader, train_len, test_len, distributed)
+    trainer.train()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
