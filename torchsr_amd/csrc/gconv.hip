@@ -740,6 +740,7 @@ extern "C" size_t srx_conv2d_bwd_data_ws_floats(const srx_conv2d_t* d) {
 
 extern "C" size_t srx_conv2d_bwd_weight_ws_floats(const srx_conv2d_t* d) {
   if (check_desc(d)) return 0;
+  if (srx_thin_wgrad_applicable(d)) return srx_thin_wgrad_ws_floats(d);
   const Geo g = fwd_geo(d);
   const size_t Cnw = (size_t)srx_roundup(d->Cout, 64), Kw = (size_t)srx_roundup(g.K, 64);
   return Cnw * Kw * 64;  // up to 64 row splits
@@ -773,13 +774,17 @@ extern "C" int srx_conv2d_pack(const srx_conv2d_t* d, const float* w, float* wpk
   SRX_REQUIRE(w && wpk_fwd, "conv2d_pack: null pointer");
   hipStream_t st = srx_stream(stream);
   const Geo g = fwd_geo(d);
-  {
+  if (srx_thin_fwd_applicable(d)) {
+    if (int rc = srx_thin_pack(d, w, wpk_fwd, 0, st)) return rc;
+  } else {
     const int64_t n = (int64_t)g.Cnp * g.Kp;
     hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, st, w, wpk_fwd, d->Cout,
                        d->Cin, d->KH, d->KW, g.Ck, g.K, g.Kp, g.Cnp, g.cps);
     SRX_CHECK_LAUNCH("pack_fwd_kernel");
   }
-  if (wpk_bwd) {
+  if (wpk_bwd && srx_thin_dgrad_applicable(d)) {
+    if (int rc = srx_thin_pack(d, w, wpk_bwd, 1, st)) return rc;
+  } else if (wpk_bwd) {
     SRX_REQUIRE(d->stride <= 4, "conv2d_pack: stride > 4 unsupported for the data gradient");
     BwdClass cls[16];
     size_t total;
@@ -803,6 +808,7 @@ extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(x && wpk && y, "conv2d_fwd: null pointer");
   hipStream_t st = srx_stream(stream);
+  if (srx_thin_fwd_applicable(d) && !bn_partials) return srx_thin_fwd(d, x, wpk, bias, y, d->Cout, st);
   const Geo g = fwd_geo(d);
   GArgs a{};
   a.in = x; a.w = wpk; a.bias = bias; a.part = nullptr;
@@ -831,6 +837,7 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
   SRX_REQUIRE(dy && wpk_bwd && dx, "conv2d_bwd_data: null pointer");
   SRX_REQUIRE(d->stride <= 4, "conv2d_bwd_data: stride > 4 unsupported");
   hipStream_t st = srx_stream(stream);
+  if (srx_thin_dgrad_applicable(d)) return srx_thin_fwd(d, dy, wpk_bwd, nullptr, dx, d->Cin, st);
   const Geo g = fwd_geo(d);
   BwdClass cls[16];
   size_t total;
@@ -869,6 +876,7 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(x && dy && dw && ws, "conv2d_bwd_weight: null pointer");
   hipStream_t st = srx_stream(stream);
+  if (srx_thin_wgrad_applicable(d)) return srx_thin_wgrad(d, x, dy, dw, accumulate, ws, ws_floats, st);
   const Geo g = fwd_geo(d);
   WArgs a{};
   a.in = x; a.dy = dy; a.slab = ws;

@@ -28,6 +28,17 @@ void srx_set_error(const char* fmt, ...);
     if (e__ != hipSuccess) SRX_FAIL(SRX_E_HIP, "%s: %s", name, hipGetErrorString(e__)); \
   } while (0)
 
+// thin.hip: 3-channel-side convolutions on v_mfma_f32_4x4x1 (internal, called from gconv.hip)
+bool srx_thin_wgrad_applicable(const srx_conv2d_t* d);
+size_t srx_thin_wgrad_ws_floats(const srx_conv2d_t* d);
+int srx_thin_wgrad(const srx_conv2d_t* d, const float* x, const float* dy, float* dw, int accumulate, float* ws,
+                   size_t ws_floats, hipStream_t st);
+bool srx_thin_fwd_applicable(const srx_conv2d_t* d);
+bool srx_thin_dgrad_applicable(const srx_conv2d_t* d);
+int srx_thin_pack(const srx_conv2d_t* d, const float* w, float* p, int mode, hipStream_t st);
+int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, float* out, int n_out,
+                 hipStream_t st);
+
 static inline hipStream_t srx_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t srx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t srx_roundup(int64_t a, int64_t b) { return srx_cdiv(a, b) * b; }
