@@ -134,8 +134,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_kernel(const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[RA], rb[RB];
-  auto gload = [&](int kc) {
+  // Two register stages: while chunk k is multiplied out of LDS, chunk k+1 waits in registers and
+  // the loads of chunk k+2 are in flight.  With one workgroup per CU (most launches here have fewer
+  // tiles than 2 x CUs) a single stage leaves ~0.5 us of L2/HBM latency exposed per chunk.
+  f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
+  auto gload = [&](int kc, f32x4 (&ra)[RA], f32x4 (&rb)[RB]) {
     const int2 kt = ktab[(kc - kc_beg) * 8 + q];
     const int dh = (int)(short)(kt.x & 0xffff), dw = kt.x >> 16;
 #pragma unroll
@@ -151,7 +154,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_kernel(const
       rb[p] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(RPP * p) * a.Kp + kc * BK);
   };
   const int wchunk = (q ^ ((r0 >> 1) & 7)) * 4;
-  auto swrite = [&](int buf) {
+  auto swrite = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) {
     float* dA = sA + buf * BM * BK;
     float* dB = sB + buf * BN * BK;
 #pragma unroll
@@ -163,19 +166,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_kernel(const
   const int h = lane >> 5, l31 = lane & 31;
   const int xr = (l31 >> 1) & 7;
   const int arow = (wm * WM + l31) * BK, brow = (wn * WN + l31) * BK;
-
-  if (kc_beg < kc_end) {
-    gload(kc_beg);
-    swrite(0);
-  }
-  __syncthreads();
-
-  for (int kc = kc_beg; kc < kc_end; ++kc) {
-    const int cur = (kc - kc_beg) & 1;
-    const bool more = (kc + 1 < kc_end);
-    if (more) gload(kc + 1);
-    const float* cA = sA + cur * BM * BK + arow;
-    const float* cB = sB + cur * BN * BK + brow;
+  auto compute = [&](int buf) {
+    const float* cA = sA + buf * BM * BK + arow;
+    const float* cB = sB + buf * BN * BK + brow;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int ch = ((2 * s + h) ^ xr) * 4;
@@ -192,7 +185,26 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_kernel(const
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
     }
-    if (more) swrite(cur ^ 1);
+  };
+
+  if (kc_beg < kc_end) {
+    gload(kc_beg, ra0, rb0);
+    if (kc_beg + 1 < kc_end) gload(kc_beg + 1, ra1, rb1);
+    swrite(0, ra0, rb0);
+  }
+  __syncthreads();
+
+  for (int kc = kc_beg; kc < kc_end; kc += 2) {
+    // even step: chunk kc sits in LDS buffer 0, chunk kc+1 in register stage 1
+    if (kc + 2 < kc_end) gload(kc + 2, ra0, rb0);
+    compute(0);
+    if (kc + 1 < kc_end) swrite(1, ra1, rb1);
+    __syncthreads();
+    if (kc + 1 >= kc_end) break;
+    // odd step: chunk kc+1 in LDS buffer 1, chunk kc+2 in register stage 0
+    if (kc + 3 < kc_end) gload(kc + 3, ra1, rb1);
+    compute(1);
+    if (kc + 2 < kc_end) swrite(0, ra0, rb0);
     __syncthreads();
   }
 
@@ -391,8 +403,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
   const int mbeg = blockIdx.z * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
-  f32x4 rd[2], rx[2];
-  auto gload = [&](int mb) {
+  f32x4 rd0[2], rx0[2], rd1[2], rx1[2];  // two register stages, as in gconv_kernel
+  auto gload = [&](int mb, f32x4 (&rd)[2], f32x4 (&rx)[2]) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int m = mb + r0 + 16 * p;
@@ -415,7 +427,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
       rd[p] = okd ? vd : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto swrite = [&](int buf) {
+  auto swrite = [&](int buf, const f32x4 (&rd)[2], const f32x4 (&rx)[2]) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       *reinterpret_cast<f32x4*>(&sD[buf][(r0 + 16 * p) * 64 + q * 4]) = rd[p];
@@ -429,20 +441,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
   const int h = lane >> 5, l31 = lane & 31;
   const int wn = wave >> 1, wk = wave & 1;
 
-  if (mbeg < mend) { gload(mbeg); swrite(0); }
-  __syncthreads();
-  int cur = 0;
-  for (int mb = mbeg; mb < mend; mb += 32) {
-    const bool more = mb + 32 < mend;
-    if (more) gload(mb + 32);
-    const float* cD = &sD[cur][h * 64 + wn * 32 + l31];
-    const float* cX = &sX[cur][h * 64 + wk * 32 + l31];
+  auto compute = [&](int buf) {
+    const float* cD = &sD[buf][h * 64 + wn * 32 + l31];
+    const float* cX = &sX[buf][h * 64 + wk * 32 + l31];
 #pragma unroll
     for (int s = 0; s < 16; ++s)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cD[s * 128], cX[s * 128], acc, 0, 0, 0);
-    if (more) swrite(cur ^ 1);
+  };
+  if (mbeg < mend) {
+    gload(mbeg, rd0, rx0);
+    if (mbeg + 32 < mend) gload(mbeg + 32, rd1, rx1);
+    swrite(0, rd0, rx0);
+  }
+  __syncthreads();
+  for (int mb = mbeg; mb < mend; mb += 64) {
+    if (mb + 64 < mend) gload(mb + 64, rd0, rx0);
+    compute(0);
+    if (mb + 32 < mend) swrite(1, rd1, rx1);
     __syncthreads();
-    cur ^= 1;
+    if (mb + 32 >= mend) break;
+    if (mb + 96 < mend) gload(mb + 96, rd1, rx1);
+    compute(1);
+    if (mb + 64 < mend) swrite(0, rd0, rx0);
+    __syncthreads();
   }
   float* slab = a.slab + (size_t)blockIdx.z * a.Cnw * a.Kw;
 #pragma unroll
@@ -461,8 +482,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, 
   const int np = (int)(idx / K), k = (int)(idx - (int64_t)np * K);
   const int tap = k / Ck, ci = k - tap * Ck;
   if (ci >= Cin) return;
-  float s = 0.f;
-  for (int z = 0; z < nsplit; ++z) s += slab[((size_t)z * Cnw + np) * Kw + k];
+  const float* sp = slab + (size_t)np * Kw + k;
+  const size_t zs = (size_t)Cnw * Kw;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int z = 0;
+  for (; z + 3 < nsplit; z += 4) {
+    s0 += sp[(size_t)z * zs];
+    s1 += sp[(size_t)(z + 1) * zs];
+    s2 += sp[(size_t)(z + 2) * zs];
+    s3 += sp[(size_t)(z + 3) * zs];
+  }
+  for (; z < nsplit; ++z) s0 += sp[(size_t)z * zs];
+  const float s = (s0 + s1) + (s2 + s3);
   int co = np;
   if (shuffle_cps) { const int ij = np / shuffle_cps, cc = np - ij * shuffle_cps; co = cc * 4 + ij; }
   const int kh = tap / KW, kw = tap - kh * KW;
