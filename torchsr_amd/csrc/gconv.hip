@@ -46,7 +46,7 @@ constexpr int INVALID = -20000;  // coordinate that fails every bounds check
 // forward / data-gradient gather-GEMM.  256 threads = 4 waves, wave tile WMxWN.
 // ---------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_kernel(const GArgs a) {
+__device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
@@ -64,11 +64,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_kernel(const
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  int tile = blockIdx.x, kc_beg = 0, kc_end = a.kchunks;
+  int tile = bid, kc_beg = 0, kc_end = a.kchunks;
   bool raw = false;
   float* slab = nullptr;
-  if ((int)blockIdx.x >= a.full_tiles) {
-    const int t = blockIdx.x - a.full_tiles;
+  if (bid >= a.full_tiles) {
+    const int t = bid - a.full_tiles;
     tile = a.full_tiles + t / a.tail_split;
     if (a.tail_split > 1) {
       kc_beg = (t % a.tail_split) * a.kc_per_split;
@@ -295,6 +295,26 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_kernel(const
       }
     }
   }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_kernel(const GArgs a) {
+  gconv_body<BM, BN, WM, WN>(a, blockIdx.x);
+}
+
+// several independent gather-GEMMs in one launch: the stride-parity classes of a strided data
+// gradient (four small problems that would each under-fill the chip and pay a kernel boundary)
+struct GMulti {
+  int n;
+  int first[5];  // first[i] = first workgroup of problem i; first[n] = grid size
+  GArgs g[4];
+};
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_multi_kernel(const GMulti m) {
+  int ci = 0;
+  while (ci + 1 < m.n && (int)blockIdx.x >= m.first[ci + 1]) ++ci;
+  const GArgs a = m.g[ci];
+  gconv_body<BM, BN, WM, WN>(a, blockIdx.x - m.first[ci]);
 }
 
 // finishes the K-split tail tiles: out = act(sum_z partial[z] + bias) and, when asked, the tile's
@@ -701,6 +721,43 @@ int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
   return SRX_OK;
 }
 
+template <int BM, int BN, int WM, int WN>
+int launch_gconv_multi(const GMulti& m, size_t lds, hipStream_t st) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_multi_kernel<BM, BN, WM, WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  hipLaunchKernelGGL((gconv_multi_kernel<BM, BN, WM, WN>), dim3(m.first[m.n]), dim3((BM / WM) * (BN / WN) * 64), lds, st,
+                     m);
+  SRX_CHECK_LAUNCH("gconv_multi_kernel");
+  return SRX_OK;
+}
+
+// all problems use tile (BM, BN) of `p`; no K split (strided outputs cannot take the fix-up path)
+int run_gconv_multi(GMulti& m, int BM, int BN, hipStream_t st) {
+  int maxk = 0;
+  m.first[0] = 0;
+  for (int i = 0; i < m.n; ++i) {
+    GArgs& a = m.g[i];
+    a.kchunks = a.Kp / BK;
+    a.mtiles = (int)srx_cdiv(a.M, BM);
+    a.kc_per_split = a.kchunks;
+    a.tail_split = 1;
+    a.ws = nullptr;
+    const int tiles = a.mtiles * (int)srx_cdiv(a.Cn, BN);
+    a.full_tiles = tiles;
+    m.first[i + 1] = m.first[i] + tiles;
+    if (a.kchunks > maxk) maxk = a.kchunks;
+  }
+  const size_t lds = (size_t)(2 * (BM + BN) * BK) * sizeof(float) + (size_t)maxk * 8 * sizeof(int2);
+  if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
+  if (BM == 128 && BN == 128) return launch_gconv_multi<128, 128, 64, 32>(m, lds, st);
+  if (BM == 128 && BN == 64) return launch_gconv_multi<128, 64, 32, 32>(m, lds, st);
+  if (BM == 64 && BN == 64) return launch_gconv_multi<64, 64, 32, 32>(m, lds, st);
+  return launch_gconv_multi<128, 32, 32, 32>(m, lds, st);
+}
+
 int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t st) {
   a.kchunks = a.Kp / BK;
   const size_t need = plan_ws_floats(p);
@@ -879,6 +936,7 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     if (hipMemsetAsync(dx, 0, (size_t)d->N * d->H * d->W * d->Cin_s * sizeof(float), st) != hipSuccess)
       SRX_FAIL(SRX_E_HIP, "conv2d_bwd_data: memset failed");
   }
+  GMulti multi{};
   for (int i = 0; i < nc; ++i) {
     const BwdClass& c = cls[i];
     if (c.K == 0 || c.Hm <= 0 || c.Wm <= 0) continue;
@@ -897,7 +955,18 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     a.act = SRX_ACT_NONE; a.slope = 0.f;
     a.linear_out = (d->stride == 1);
     a.out = dx;
-    if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st)) return rc;
+    if (d->stride == 1) {
+      if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st)) return rc;
+    } else if (nc <= 4) {
+      multi.g[multi.n++] = a;
+    } else {  // stride > 2: one launch per class
+      if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st)) return rc;
+    }
+  }
+  if (multi.n > 0) {
+    // tile choice: the classes are (nearly) equal sized; pick the tile for their combined work
+    const Plan p = make_plan(multi.g[0].M * multi.n, pad_rows(d->Cin), multi.g[0].Kp / BK, false);
+    if (int rc = run_gconv_multi(multi, p.BM, p.BN, st)) return rc;
   }
   return SRX_OK;
 }

@@ -81,6 +81,7 @@ def round4(c: int) -> int:
 class _ToNHWC(Function):
     @staticmethod
     def forward(ctx, x: Tensor, cs: int) -> Tensor:
+        ctx.set_materialize_grads(False)
         x = _chk(x, 'to_nhwc')
         n, c, h, w = x.shape
         ctx.c = c
@@ -100,6 +101,7 @@ class _ToNHWC(Function):
 class _ToNCHW(Function):
     @staticmethod
     def forward(ctx, x: Tensor, c: int) -> Tensor:
+        ctx.set_materialize_grads(False)
         x = _chk(x, 'to_nchw')
         n, h, w, cs = x.shape
         ctx.cs = cs
@@ -193,6 +195,7 @@ class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], st: ConvState, want_stats: bool,
                 master: Tensor):
+        ctx.set_materialize_grads(False)
         x = _chk(x, 'conv2d.input')
         n, h, w, cs = x.shape
         if cs != st.cin_s:
@@ -282,6 +285,7 @@ class _BNAct(Function):
     def forward(ctx, y: Tensor, part: Optional[Tensor], gamma: Tensor, beta: Tensor, prelu: Optional[Tensor],
                 residual: Optional[Tensor], running_mean: Tensor, running_var: Tensor, nbt: Optional[Tensor],
                 training: bool, eps: float, momentum: float, act: int, slope: float):
+        ctx.set_materialize_grads(False)
         y = _chk(y, 'bn.input')
         c = y.shape[-1]
         m = y.numel() // c
@@ -345,6 +349,7 @@ def bn_act(y, part, bn, act=ACT_NONE, slope=0.0, prelu: Optional[Tensor] = None,
 class _PReLU(Function):
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor):
+        ctx.set_materialize_grads(False)
         x = _chk(x, 'prelu.input')
         wd = _chk(w.detach(), 'prelu.weight')
         y = torch.empty_like(x)
@@ -374,6 +379,7 @@ def prelu(x: Tensor, w: Tensor) -> Tensor:
 class _LReLU(Function):
     @staticmethod
     def forward(ctx, x: Tensor, slope: float):
+        ctx.set_materialize_grads(False)
         x = _chk(x, 'lrelu.input')
         y = torch.empty_like(x)
         call('srx_lrelu_fwd', _p(x), _p(y), x.numel(), slope, _stream())
@@ -397,6 +403,7 @@ def leaky_relu(x: Tensor, slope: float) -> Tensor:
 class _Sigmoid(Function):
     @staticmethod
     def forward(ctx, x: Tensor):
+        ctx.set_materialize_grads(False)
         x = _chk(x, 'sigmoid.input')
         y = torch.empty_like(x)
         call('srx_sigmoid_fwd', _p(x), _p(y), x.numel(), _stream())
@@ -419,6 +426,7 @@ def sigmoid(x: Tensor) -> Tensor:
 class _Axpby(Function):
     @staticmethod
     def forward(ctx, x: Tensor, z: Tensor, a: float, b: float):
+        ctx.set_materialize_grads(False)
         x, z = _chk(x, 'axpby.x'), _chk(z, 'axpby.z')
         y = torch.empty_like(x)
         call('srx_axpby', _p(x), _p(z), _p(y), x.numel(), a, b, _stream())
@@ -451,6 +459,7 @@ def axpby(x: Tensor, z: Tensor, a: float = 1.0, b: float = 1.0) -> Tensor:
 class _MaxPool(Function):
     @staticmethod
     def forward(ctx, x: Tensor):
+        ctx.set_materialize_grads(False)
         x = _chk(x, 'maxpool.input')
         n, h, w, c = x.shape
         y = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
@@ -476,6 +485,7 @@ def maxpool2x2(x: Tensor) -> Tensor:
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor, bias: Optional[Tensor], act: int, slope: float):
+        ctx.set_materialize_grads(False)
         x = _chk(x, 'linear.input')
         wd = _chk(w.detach(), 'linear.weight')
         bsz, k = x.shape
@@ -528,6 +538,7 @@ class _PairLoss(Function):
 
     @staticmethod
     def forward(ctx, a: Tensor, b: Tensor, kind: str):
+        ctx.set_materialize_grads(False)
         a, b = _chk(a, f'{kind}.input'), _chk(b, f'{kind}.target')
         if a.shape != b.shape:
             raise RuntimeError(f'{kind}_loss: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}')
@@ -560,6 +571,7 @@ def l1_loss(a: Tensor, b: Tensor) -> Tensor:
 class _BCE(Function):
     @staticmethod
     def forward(ctx, p: Tensor, target: float):
+        ctx.set_materialize_grads(False)
         p = _chk(p, 'bce.input')
         loss = torch.empty((), dtype=torch.float32, device=p.device)
         call('srx_bce_fwd', _p(p), target, _p(loss), p.numel(), _p(_ws(2048, p)), _stream())
@@ -584,6 +596,7 @@ def bce_loss(p: Tensor, target: float) -> Tensor:
 class _BCELogits(Function):
     @staticmethod
     def forward(ctx, x: Tensor, shift: Optional[Tensor], target: float):
+        ctx.set_materialize_grads(False)
         x = _chk(x, 'bce_logits.input')
         sh = None if shift is None else _chk(shift.detach().reshape(1), 'bce_logits.shift')
         loss = torch.empty((), dtype=torch.float32, device=x.device)
@@ -612,6 +625,7 @@ def bce_with_logits(x: Tensor, target: float, shift: Optional[Tensor] = None) ->
 class _Mean(Function):
     @staticmethod
     def forward(ctx, x: Tensor):
+        ctx.set_materialize_grads(False)
         x = _chk(x, 'mean.input')
         out = torch.empty((), dtype=torch.float32, device=x.device)
         call('srx_mean_fwd', _p(x), _p(out), x.numel(), _p(_ws(2048, x)), _stream())
@@ -638,6 +652,7 @@ class _ConcatChannels(Function):
 
     @staticmethod
     def forward(ctx, *xs: Tensor):
+        ctx.set_materialize_grads(False)
         xs = [_chk(x, 'concat.input') for x in xs]
         lead = xs[0].shape[:-1]
         cs = [x.shape[-1] for x in xs]
@@ -673,6 +688,7 @@ def concat_channels(xs) -> Tensor:
 class _Upsample2x(Function):
     @staticmethod
     def forward(ctx, x: Tensor):
+        ctx.set_materialize_grads(False)
         x = _chk(x, 'upsample.input')
         n, h, w, c = x.shape
         y = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.float32, device=x.device)
