@@ -45,24 +45,29 @@ constexpr int INVALID = -20000;  // coordinate that fails every bounds check
 // ---------------------------------------------------------------------------
 // forward / data-gradient gather-GEMM.  256 threads = 4 waves, wave tile WMxWN.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+// KS > 1: the k-chunks of the tile are dealt round-robin to KS groups of waves (each group owns a
+// private pair of LDS staging buffers and covers the whole BM x BN tile); the groups' accumulators are
+// folded through LDS at the end.  Used when a launch has fewer tiles than CUs (e.g. the 16x24x24
+// residual convs: 144 tiles): it halves the serial chunk chain per wave and puts two waves on a SIMD.
+template <int BM, int BN, int WM, int WN, int KS>
 __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
-  constexpr int NT = WAVES_M * WAVES_N * 64;  // 256 or 512 threads: the big tiles run 8 waves so that every
+  constexpr int GT = WAVES_M * WAVES_N * 64;  // threads of one k-group
+  constexpr int NT = GT * KS;                 // 256 or 512 threads: the big tiles run 8 waves so that every
                                               // SIMD holds two and one's MFMAs cover the other's loads/barriers
   static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
-  constexpr int RPP = NT / 8;                 // tile rows staged per pass (8 threads x float4 = one 128-byte row)
+  constexpr int RPP = GT / 8;                 // tile rows staged per pass (8 threads x float4 = one 128-byte row)
   constexpr int RA = BM / RPP, RB = BN / RPP;
   static_assert(RA >= 1 && RB >= 1, "tile too small for the thread count");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sA = reinterpret_cast<float*>(smem);
+  const int ks = threadIdx.x / GT;            // k-group of this wave (waves of a group are contiguous)
+  const int tid = threadIdx.x % GT, lane = tid & 63, wave = tid >> 6;
+  float* sA = reinterpret_cast<float*>(smem) + ks * 2 * (BM + BN) * BK;
   float* sB = sA + 2 * BM * BK;
-  int2* ktab = reinterpret_cast<int2*>(sB + 2 * BN * BK);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int2* ktab = reinterpret_cast<int2*>(reinterpret_cast<float*>(smem) + KS * 2 * (BM + BN) * BK);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int tile = bid, kc_beg = 0, kc_end = a.kchunks;
   bool raw = false;
@@ -82,7 +87,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   const int q = tid & 7, r0 = tid >> 3;
 
   // ---- k table: (dh, dw) and linear input offset for every float4 of K in range
-  for (int e = kc_beg * 8 + tid; e < kc_end * 8; e += NT) {
+  for (int e = kc_beg * 8 + (int)threadIdx.x; e < kc_end * 8; e += NT) {
     const int k = 4 * e;
     int2 ent;
     if (k < a.K) {
@@ -187,30 +192,61 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
     }
   };
 
-  if (kc_beg < kc_end) {
-    gload(kc_beg, ra0, rb0);
-    if (kc_beg + 1 < kc_end) gload(kc_beg + 1, ra1, rb1);
+  // this group's chunks: kc_beg + ks, + KS, ...; every group runs the same number of steps (barriers)
+  const int c0 = kc_beg + ks;
+  const int nsteps = (kc_end - kc_beg + KS - 1) / KS;
+  if (c0 < kc_end) {
+    gload(c0, ra0, rb0);
+    if (c0 + KS < kc_end) gload(c0 + KS, ra1, rb1);
     swrite(0, ra0, rb0);
   }
   __syncthreads();
 
-  for (int kc = kc_beg; kc < kc_end; kc += 2) {
-    // even step: chunk kc sits in LDS buffer 0, chunk kc+1 in register stage 1
-    if (kc + 2 < kc_end) gload(kc + 2, ra0, rb0);
-    compute(0);
-    if (kc + 1 < kc_end) swrite(1, ra1, rb1);
+  for (int j = 0; j < nsteps; j += 2) {
+    const int kc = c0 + j * KS;
+    // even step: chunk kc sits in LDS buffer 0, chunk kc+KS in register stage 1
+    if (kc + 2 * KS < kc_end) gload(kc + 2 * KS, ra0, rb0);
+    if (kc < kc_end) compute(0);
+    if (kc + KS < kc_end) swrite(1, ra1, rb1);
     __syncthreads();
-    if (kc + 1 >= kc_end) break;
-    // odd step: chunk kc+1 in LDS buffer 1, chunk kc+2 in register stage 0
-    if (kc + 3 < kc_end) gload(kc + 3, ra1, rb1);
-    compute(1);
-    if (kc + 2 < kc_end) swrite(0, ra0, rb0);
+    if (j + 1 >= nsteps) break;
+    // odd step: chunk kc+KS in LDS buffer 1, chunk kc+2KS in register stage 0
+    if (kc + 3 * KS < kc_end) gload(kc + 3 * KS, ra1, rb1);
+    if (kc + KS < kc_end) compute(1);
+    if (kc + 2 * KS < kc_end) swrite(0, ra0, rb0);
     __syncthreads();
   }
+
+  if (KS > 1) {  // fold the k-groups' accumulators into group 0 (staging buffers are free now)
+    float* fold = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int g = 1; g < KS; ++g) {
+      if (ks == g) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fold[((wave * TM * TN + i * TN + jj) * 16 + r) * 64 + lane] = acc[i][jj][r];
+      }
+      __syncthreads();
+      if (ks == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] += fold[((wave * TM * TN + i * TN + jj) * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+  }
+  const bool lead = (ks == 0);
 
   // ------------------------------------------------------------- epilogue
   // accumulator map (32x32 MFMA): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   if (raw) {  // tile-local [BM][BN] partial; each half wave writes 128 contiguous bytes
+    if (!lead) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -265,26 +301,26 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
         if (mok) { csum[j] += v; csq[j] += v * v; }
         if (a.act == SRX_ACT_RELU) v = fmaxf(v, 0.f);
         else if (a.act == SRX_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
-        if (mok && colv[j] < a.Cs) outp[obase + ocol[j]] = v;
+        if (lead && mok && colv[j] < a.Cs) outp[obase + ocol[j]] = v;
       }
     }
   }
 
   if (a.part) {  // per-channel sum / sum of squares of this row block (training-mode BatchNorm)
     __syncthreads();  // everyone is done with the staging buffers
-    float* red = sA;  // [WAVES_M][BN][2]
+    float* red = reinterpret_cast<float*>(smem);  // [WAVES_M][BN][2]
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       float s = csum[j] + __shfl_xor(csum[j], 32, 64);
       float s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
-      if (h == 0) {
+      if (lead && h == 0) {
         const int c = wn * WN + j * 32 + l31;
         red[(wm * BN + c) * 2 + 0] = s;
         red[(wm * BN + c) * 2 + 1] = s2;
       }
     }
     __syncthreads();
-    if (tid < BN) {
+    if (lead && tid < BN) {
       float s = 0.f, s2 = 0.f;
 #pragma unroll
       for (int w = 0; w < WAVES_M; ++w) { s += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
@@ -297,9 +333,9 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_kernel(const GArgs a) {
-  gconv_body<BM, BN, WM, WN>(a, blockIdx.x);
+template <int BM, int BN, int WM, int WN, int KS>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KS) void gconv_kernel(const GArgs a) {
+  gconv_body<BM, BN, WM, WN, KS>(a, blockIdx.x);
 }
 
 // several independent gather-GEMMs in one launch: the stride-parity classes of a strided data
@@ -314,7 +350,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_multi_kernel
   int ci = 0;
   while (ci + 1 < m.n && (int)blockIdx.x >= m.first[ci + 1]) ++ci;
   const GArgs a = m.g[ci];
-  gconv_body<BM, BN, WM, WN>(a, blockIdx.x - m.first[ci]);
+  gconv_body<BM, BN, WM, WN, 1>(a, blockIdx.x - m.first[ci]);
 }
 
 // finishes the K-split tail tiles: out = act(sum_z partial[z] + bias) and, when asked, the tile's
@@ -653,7 +689,7 @@ int bwd_classes(const srx_conv2d_t* d, BwdClass* cls, size_t& total_floats) {
 // only those r tiles take the partial-sum round trip through HBM.  Larger tiles are preferred
 // (fewer L2->LDS bytes per MFMA: the 64x64 tile moves 16 B/clk/workgroup and stalls on L1/L2)
 // unless they leave the chip under-filled.
-struct Plan { int BM, BN, mtiles, ntiles, tiles, full, tail, split, kc_per_split; float cost; };
+struct Plan { int BM, BN, mtiles, ntiles, tiles, full, tail, split, kc_per_split, ks; float cost; };
 
 int device_cus() {
   static int cus = 0;
@@ -696,23 +732,25 @@ Plan make_plan(int M, int Cnp, int kchunks, bool can_split) {
     p.cost = rounds * t_tile + tail_cost;
     if (p.cost < best.cost) best = p;
   }
+  // fewer workgroups than CUs and a 4-wave tile: split its k-chunks over two wave groups (KS = 2)
+  best.ks = (best.BM == 64 && best.BN == 64 && best.full + best.tail * best.split <= P && best.kc_per_split >= 4) ? 2 : 1;
   return best;
 }
 
 size_t plan_ws_floats(const Plan& p) { return p.split > 1 ? (size_t)p.tail * p.split * p.BM * p.BN : 0; }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KS>
 int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
   const int ktab_chunks = p.full > 0 || p.split == 1 ? a.kchunks : p.kc_per_split;
-  const size_t lds = (size_t)(2 * (BM + BN) * BK) * sizeof(float) + (size_t)ktab_chunks * 8 * sizeof(int2);
+  const size_t lds = (size_t)(KS * 2 * (BM + BN) * BK) * sizeof(float) + (size_t)ktab_chunks * 8 * sizeof(int2);
   if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN, KS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(p.full + p.tail * p.split);
-  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN>), grid, dim3((BM / WM) * (BN / WN) * 64), lds, st, a);
+  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN, KS>), grid, dim3((BM / WM) * (BN / WN) * 64 * KS), lds, st, a);
   SRX_CHECK_LAUNCH("gconv_kernel");
   if (p.split > 1) {
     hipLaunchKernelGGL((tail_fixup_kernel<BM, BN>), dim3(p.tail * (BN / 16)), dim3(256), 0, st, a);
@@ -769,10 +807,11 @@ int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t 
   a.full_tiles = p.full;
   a.tail_split = p.split;
   a.ws = ws;
-  if (p.BM == 128 && p.BN == 128) return launch_gconv<128, 128, 64, 32>(a, p, st);
-  if (p.BM == 128 && p.BN == 64) return launch_gconv<128, 64, 32, 32>(a, p, st);
-  if (p.BM == 64 && p.BN == 64) return launch_gconv<64, 64, 32, 32>(a, p, st);
-  return launch_gconv<128, 32, 32, 32>(a, p, st);
+  if (p.BM == 128 && p.BN == 128) return launch_gconv<128, 128, 64, 32, 1>(a, p, st);
+  if (p.BM == 128 && p.BN == 64) return launch_gconv<128, 64, 32, 32, 1>(a, p, st);
+  if (p.BM == 64 && p.BN == 64)
+    return p.ks == 2 ? launch_gconv<64, 64, 32, 32, 2>(a, p, st) : launch_gconv<64, 64, 32, 32, 1>(a, p, st);
+  return launch_gconv<128, 32, 32, 32, 1>(a, p, st);
 }
 
 void set_mgrid(GArgs& a, int N, int Hm, int Wm) {
