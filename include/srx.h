@@ -174,6 +174,17 @@ int srx_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, c
                          const float* gamma, const float* beta, const float* sums, float* dy, int64_t M,
                          int C, int act, float slope, const float* prelu, int training, void* stream);
 
+/* one-call forms used by the trainers; for small tensors they fuse the finalize step into the
+ * streaming pass (one kernel boundary less per BatchNorm and direction) */
+int srx_bn_train_fwd(const float* y, const float* partials, int rows, int64_t M, int C, float eps, float momentum,
+                     const float* gamma, const float* beta, const float* residual, float* out, int act, float slope,
+                     const float* prelu, float* save_mean, float* save_invstd, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, void* stream);
+int srx_bn_act_bwd(const float* dout, const float* y, const float* mean, const float* invstd, const float* gamma,
+                   const float* beta, float* sums, float* dy, int64_t M, int C, int act, float slope,
+                   const float* prelu, int training, float* dgamma_acc, float* dbeta_acc, float* dprelu_acc,
+                   float* ws, size_t ws_floats, void* stream);
+
 /* ----------------------------------------------------------------- pooling */
 /* nn.MaxPool2d(2,2) of VGG19 (torchvision cfg 'E', srgan/loss.py:30-31); H, W even */
 int srx_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);

@@ -90,6 +90,8 @@ _SIGS = {
     'srx_bn_bwd_ws_floats': (_Z, [_L, _I]),
     'srx_bn_act_bwd_reduce': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_bn_act_bwd_apply': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _I, _P]),
+    'srx_bn_train_fwd': (_I, [_P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
+    'srx_bn_act_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _I, _P, _P, _P, _P, _Z, _P]),
     'srx_maxpool2x2_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'srx_maxpool2x2_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'srx_linear_ws_floats': (_Z, [_I, _I, _I]),

@@ -297,16 +297,21 @@ class _BNAct(Function):
                 rows = _lib.lib().srx_bn_stat_rows(m)
                 part = torch.empty((rows, c, 2), dtype=torch.float32, device=y.device)
                 call('srx_bn_partial_stats', _p(y), _p(part), m, c, s)
-            call('srx_bn_finalize', _p(part), part.shape[0], m, c, eps, momentum, _p(mean), _p(invstd),
-                 _p(running_mean), _p(running_var), _p(nbt), s)
+            fused = True
         else:
             call('srx_bn_eval_stats', _p(running_mean), _p(running_var), c, eps, _p(mean), _p(invstd), s)
+            fused = False
         g = _chk(gamma.detach(), 'bn.weight')
         b = _chk(beta.detach(), 'bn.bias')
         pw = None if prelu is None else _chk(prelu.detach(), 'prelu.weight')
         res = None if residual is None else _chk(residual, 'bn.residual')
         out = torch.empty_like(y)
-        call('srx_bn_act_fwd', _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), m, c, act, slope, _p(pw), s)
+        if fused:
+            call('srx_bn_train_fwd', _p(y), _p(part), part.shape[0], m, c, eps, momentum, _p(g), _p(b), _p(res), _p(out),
+                 act, slope, _p(pw), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt), s)
+        else:
+            call('srx_bn_act_fwd', _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), m, c, act, slope, _p(pw),
+                 s)
         ctx.save_for_backward(y, mean, invstd, g, b, pw)
         ctx.cfg = (m, c, act, slope, training, residual is not None, prelu is not None)
         ctx.params = (gamma, beta, prelu)
@@ -321,13 +326,9 @@ class _BNAct(Function):
         sums = torch.empty(2 * c + 4, dtype=torch.float32, device=y.device)
         nws = _lib.lib().srx_bn_bwd_ws_floats(m, c)
         gs, bs, ps = (_sink(t) for t in ctx.params)
-        call('srx_bn_act_bwd_reduce', _p(dout), _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(sums), m, c, act, slope,
-             _p(pw), _p(gs), _p(bs), _p(ps), _p(_ws(nws, y)), nws, s)
-        dy = None
-        if ctx.needs_input_grad[0]:
-            dy = torch.empty_like(y)
-            call('srx_bn_act_bwd_apply', _p(dout), _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(sums), _p(dy), m, c,
-                 act, slope, _p(pw), 1 if training else 0, s)
+        dy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
+        call('srx_bn_act_bwd', _p(dout), _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(sums), _p(dy), m, c, act, slope,
+             _p(pw), 1 if training else 0, _p(gs), _p(bs), _p(ps), _p(_ws(nws, y)), nws, s)
         dgamma = sums[c:2 * c] if (ctx.needs_input_grad[2] and gs is None) else None
         dbeta = sums[:c] if (ctx.needs_input_grad[3] and bs is None) else None
         dprelu = sums[2 * c:2 * c + 1] if (has_prelu and ctx.needs_input_grad[4] and ps is None) else None
