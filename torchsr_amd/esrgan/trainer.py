@@ -45,6 +45,7 @@ class ESRGANTrainer(SRGANTrainer):
         d_fake = self.bce_loss(fake_output, 0.0, shift=F.mean(real_output))      # :452
         disc_loss = F.axpby(d_real, d_fake, 0.5, 0.5)                            # :453
         disc_loss.backward()                                                     # :455
+        F.join_side_stream()
         self._losses['gan/disc-loss'] = disc_loss.detach()
 
     def _phase_content(self) -> None:
@@ -68,6 +69,7 @@ class ESRGANTrainer(SRGANTrainer):
         adversarial = self.bce_loss(fake_output, 1.0, shift=real_mean)           # :468
         gen_loss = F.axpby(self._content, adversarial, 1.0, 0.005)               # :469
         gen_loss.backward()                                                      # :480
+        F.join_side_stream()
         self._losses['gan/adversarial-loss'] = adversarial.detach()
         self._losses['gan/train-loss'] = gen_loss.detach()
         self._super_res = self._content = None

@@ -52,6 +52,29 @@ def _sink(param: Optional[Tensor]) -> Optional[Tensor]:
     return g
 
 
+# Weight-gradient kernels of the small layers fill only part of the chip and nothing downstream in
+# the backward pass needs their result, so (when enabled by a trainer) they are issued on a second
+# HIP stream: in the captured hipGraph they become a parallel branch next to the data-gradient chain.
+side_stream_enabled = [False]
+_side = {}
+
+
+def side_stream(device) -> 'torch.cuda.Stream':
+    st = _side.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side[device] = st
+    return st
+
+
+def join_side_stream() -> None:
+    """Make the current stream wait for everything issued on the side stream (call after backward)."""
+    if side_stream_enabled[0]:
+        dev = torch.cuda.current_device()
+        if dev in _side:
+            torch.cuda.current_stream().wait_stream(_side[dev])
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -247,9 +270,19 @@ class _Conv2d(Function):
             dw = None if sink is not None else torch.empty((st.cout, st.cin, st.k, st.k), dtype=torch.float32,
                                                              device=x.device)
             nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
-            ws = _ws(nws, x)
-            _prof_call('wgrad', d, 'srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw if sink is None else sink),
-                       0 if sink is None else 1, _p(ws), nws, s)
+            if sink is not None and side_stream_enabled[0]:
+                main, side = torch.cuda.current_stream(), side_stream(x.device.index)
+                side.wait_stream(main)          # dy (and x) are complete on the main stream
+                with torch.cuda.stream(side):
+                    ws = _ws(nws, x)
+                    _prof_call('wgrad', d, 'srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(sink), 1, _p(ws), nws,
+                               side.cuda_stream)
+                x.record_stream(side)
+                dy.record_stream(side)
+            else:
+                ws = _ws(nws, x)
+                _prof_call('wgrad', d, 'srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw if sink is None else sink),
+                           0 if sink is None else 1, _p(ws), nws, s)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             sink = None if st.shuffle else _sink(bparam)
             if sink is not None:
