@@ -73,16 +73,23 @@ def roofline_pass(trainer, lr, hr, reps=2):
         F._conv_prof[0] = None
         trainer.use_graphs = was
     groups = {}
-    plan = (C.c_int * 4)()
+    plan = (C.c_int * 6)()
+    wave_tile = {(128, 128): (64, 32), (128, 64): (32, 32), (64, 64): (32, 32), (128, 32): (32, 32)}
     for kind, d, e0, e1 in rec:
         ms = e0.elapsed_time(e1)
+        thin_out = d.Cout <= 4 and d.Cin == 64 and d.stride == 1 and d.KH in (3, 9) and not d.shuffle
+        thin_in = d.Cin <= 4 and d.Cout == 64 and d.stride == 1 and d.KH in (3, 9) and not d.shuffle
         if kind == 'wgrad':
-            name = 'wgrad_kernel'
+            name = 'thin_wgrad_kernel' if (thin_out or thin_in) else 'wgrad_kernel'
+        elif (kind == 'fwd' and thin_out and d.act == 0) or (kind == 'dgrad' and thin_in):
+            name = f'thin_fwd_kernel<{d.KH}, {d.KW}>'
         else:
             lib.srx_conv2d_plan(C.byref(d), 0 if kind == 'fwd' else 1, plan)
-            wm, wn = {(128, 128): (64, 32), (128, 64): (32, 32), (64, 64): (32, 32), (128, 32): (32, 32)}[
-                (plan[0], plan[1])]
-            name = f'gconv_kernel<{plan[0]},{plan[1]},{wm},{wn}>'
+            wm, wn = wave_tile[(plan[0], plan[1])]
+            if plan[5]:
+                name = f'gconv_multi_kernel<{plan[0]}, {plan[1]}, {wm}, {wn}>'
+            else:
+                name = f'gconv_kernel<{plan[0]}, {plan[1]}, {wm}, {wn}, {plan[4]}>'
         gsum = groups.setdefault(name, [0.0, 0.0, 0])
         gsum[0] += ms
         gsum[1] += conv_flops(d)
@@ -92,9 +99,17 @@ def roofline_pass(trainer, lr, hr, reps=2):
     achieved = fl / (ms * 1e-3) / 1e12
     table = {k: {'ms_per_step': v[0] / reps, 'gflop_per_step': v[1] / reps / 1e9, 'launches_per_step': v[2] // reps,
                  'tflops': v[1] / (v[0] * 1e-3) / 1e12} for k, v in groups.items()}
+    # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
+    # tools/pmc_traffic.py); counters cannot be read from inside the process, so the committed summary is used
+    traffic = None
+    for f in sorted(os.listdir(os.path.join(ROOT, 'profiles'))) if os.path.isdir(os.path.join(ROOT, 'profiles')) else []:
+        if f.startswith('r01_traffic') and f.endswith('.json'):
+            t = json.load(open(os.path.join(ROOT, 'profiles', f)))
+            if t.get('kernel') == name:
+                traffic = round(t['hbm_bytes_per_launch'])
     return {
         'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / PEAK_TFLOPS, 4), 'traffic': None,
+        'frac': round(achieved / PEAK_TFLOPS, 4), 'traffic': traffic,
         'avg_launch_us': round(ms / cnt * 1e3, 2), 'launches_per_step': cnt // reps,
         'gflop_per_launch': round(fl / cnt / 1e9, 4),
         'conv_ms_per_step': round(total_ms / reps, 3), 'by_kernel': table,
@@ -149,12 +164,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # SRX_BENCH_ONE_GPU=1 + SRX_BENCH_BACKEND=gloo: rehearse the N>1 control flow with all ranks on one card
+    dev_index = 0 if os.environ.get('SRX_BENCH_ONE_GPU') == '1' else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     distributed = world > 1
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=device)
+        backend = os.environ.get('SRX_BENCH_BACKEND', 'nccl')  # 'nccl' is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     import warnings
     warnings.filterwarnings('ignore', message='.*seeded random features.*')

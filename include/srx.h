@@ -93,8 +93,9 @@ size_t srx_conv2d_bwd_weight_ws_floats(const srx_conv2d_t* d);
 int srx_conv2d_stat_rows(const srx_conv2d_t* d);
 
 /* launch plan the library will use (for profiling / the bench's roofline bookkeeping):
- * which = 0 forward, 1 data gradient; out[4] = {tile rows BM, tile cols BN, split-K factor, workgroups}.
- * The kernel launched is `gconv_kernel<BM,BN,..>`. */
+ * which = 0 forward, 1 data gradient; out[6] = {tile rows BM, tile cols BN, tail split-K factor, workgroups,
+ * KS (wave groups splitting K inside a workgroup), multi (1: stride-parity classes in one launch)}.
+ * The kernel launched is `gconv_kernel<BM, BN, WM, WN, KS>` or `gconv_multi_kernel<BM, BN, WM, WN>`. */
 int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out);
 
 /* OIHW master weights -> packed forward ([Cout_p][K_p], K=(kh,kw,ci)) and, when

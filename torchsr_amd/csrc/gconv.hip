@@ -878,21 +878,29 @@ extern "C" int srx_conv2d_stat_rows(const srx_conv2d_t* d) {
   return stat_rows_for(d);
 }
 
-// which: 0 = forward, 1 = data gradient (first stride-parity class).  out = {BM, BN, nsplit, workgroups}
+// which: 0 = forward, 1 = data gradient.  out[6] = {BM, BN, tail split, workgroups, KS, multi}
+// (multi = 1: the stride-parity classes run as one gconv_multi_kernel launch)
 extern "C" int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(out, "conv2d_plan: null pointer");
   Plan p;
+  int multi = 0;
   if (which == 0) {
     p = fwd_plan(d, fwd_geo(d));
   } else {
     SRX_REQUIRE(d->stride <= 4, "conv2d_plan: stride > 4 unsupported");
     BwdClass cls[16];
     size_t total;
-    bwd_classes(d, cls, total);
-    p = bwd_plan(d, cls[0]);
+    const int nc = bwd_classes(d, cls, total);
+    if (d->stride > 1 && nc <= 4) {
+      p = make_plan(d->N * cls[0].Hm * cls[0].Wm * nc, pad_rows(d->Cin), cls[0].Kp / BK, false);
+      p.ks = 1;
+      multi = 1;
+    } else {
+      p = bwd_plan(d, cls[0]);
+    }
   }
-  out[0] = p.BM; out[1] = p.BN; out[2] = p.split; out[3] = p.full + p.tail * p.split;
+  out[0] = p.BM; out[1] = p.BN; out[2] = p.split; out[3] = p.full + p.tail * p.split; out[4] = p.ks; out[5] = multi;
   return SRX_OK;
 }
 

@@ -196,8 +196,20 @@ class SRGANTrainer:
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._graph_pool):
+        # with a process group alive, RCCL's watchdog thread may query events while we capture; only
+        # the capturing thread's own calls should be policed then
+        mode = 'thread_local' if self.distributed else 'global'
+        try:
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=mode):
+                fn()
+        except Exception as exc:  # keep training: run this and all later steps eagerly
+            self._log(f'hipGraph capture of {key} failed ({type(exc).__name__}: {exc}); continuing without graphs')
+            self.use_graphs = False
+            self._graphs.clear()
+            torch.cuda.synchronize()
+            F.bump_pack_epoch()  # packs "refreshed" during the failed capture never ran
             fn()
+            return
         self._graphs[key] = g
         g.replay()  # capture records without executing; run this step's work now
 
