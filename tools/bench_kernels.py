@@ -56,6 +56,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--only', type=str, default='')
+    ap.add_argument('--graph', action='store_true', help='time the forward as a replayed hipGraph of `reps` calls')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     print(f'{"layer":26s} {"GF":>7s} | {"fwd us":>8s} {"TF/s":>6s} | {"dgrad us":>8s} {"TF/s":>6s} | {"wgrad us":>8s} {"TF/s":>6s}')
@@ -69,6 +70,18 @@ def main():
         gy = torch.rand_like(y)
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         gf = 2.0 * n * ho * wo * cout * cin * k * k / 1e9
+        if args.graph:
+            xd0 = x.detach()
+            with torch.no_grad():
+                conv(xd0)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(args.reps):
+                        conv(xd0)
+            t_f = timeit(g.replay, 5) / args.reps
+            print(f'{name:26s} {gf:7.3f} | graph fwd {t_f:8.2f} us {gf / t_f * 1e3:6.1f} TF/s', flush=True)
+            continue
         t_f = timeit(lambda: conv(x.detach()), args.reps)
         xd = x.detach().requires_grad_(True)
         conv.weight.requires_grad_(False)

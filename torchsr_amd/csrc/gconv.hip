@@ -14,6 +14,8 @@
 // 32 floats read back with conflict-free ds_read_b128.
 // MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak).
 #include "srx_common.h"
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 
 namespace {
@@ -599,6 +601,42 @@ __global__ void pack_bwd_kernel(const float* __restrict__ w, float* __restrict__
   p[idx] = v;
 }
 
+// forward pack and every data-gradient class in ONE launch (blockIdx.y = segment): a repack after each
+// optimiser step used to be 1 + stride^2 tiny launches per layer, ~130 per train step
+struct PackSeg { float* dst; int rows, K, Kp, Ck, bwd, ph, pw, dminh, dminw, ntw; };
+struct PackArgs {
+  const float* w;
+  int Cout, Cin, KH, KW, stride, pad, cps, nseg;
+  PackSeg seg[17];
+};
+__global__ void pack_all_kernel(const PackArgs a) {
+  const PackSeg sg = a.seg[blockIdx.y];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)sg.rows * sg.Kp) return;
+  const int row = (int)(idx / sg.Kp), k = (int)(idx - (int64_t)row * sg.Kp);
+  float v = 0.f;
+  if (k < sg.K) {
+    const int tap = k / sg.Ck, c = k - tap * sg.Ck;
+    if (!sg.bwd) {  // row = packed output channel n', c = input channel
+      if (row < a.Cout && c < a.Cin) {
+        int co = row;
+        if (a.cps) { const int ij = row / a.cps, cc = row - ij * a.cps; co = cc * 4 + ij; }
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        v = a.w[(((size_t)co * a.Cin + c) * a.KH + kh) * a.KW + kw];
+      }
+    } else {        // row = input channel ci, c = (packed) output channel
+      if (row < a.Cin && c < a.Cout) {
+        const int th = tap / sg.ntw, tw = tap - th * sg.ntw;
+        const int kh = sg.ph + a.pad - a.stride * (sg.dminh + th), kw = sg.pw + a.pad - a.stride * (sg.dminw + tw);
+        int co = c;
+        if (a.cps) { const int ij = c / a.cps, cc = c - ij * a.cps; co = cc * 4 + ij; }
+        v = a.w[(((size_t)co * a.Cin + row) * a.KH + kh) * a.KW + kw];
+      }
+    }
+  }
+  sg.dst[idx] = v;
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -731,6 +769,18 @@ Plan make_plan(int M, int Cnp, int kchunks, bool can_split) {
     }
     p.cost = rounds * t_tile + tail_cost;
     if (p.cost < best.cost) best = p;
+  }
+  // developer override for tile experiments: SRX_FORCE_PLAN="BM,BN,split,ks" (split: K-split of ALL tiles)
+  if (const char* f = getenv("SRX_FORCE_PLAN")) {
+    int bm = 0, bn = 0, sp = 1, ks = 1;
+    if (sscanf(f, "%d,%d,%d,%d", &bm, &bn, &sp, &ks) == 4 && Cnp % bn == 0) {
+      Plan p{};
+      p.BM = bm; p.BN = bn; p.mtiles = (int)srx_cdiv(M, bm); p.ntiles = Cnp / bn; p.tiles = p.mtiles * p.ntiles;
+      if (sp > 1 && can_split) { p.full = 0; p.tail = p.tiles; p.kc_per_split = (int)srx_cdiv(kchunks, sp); p.split = (int)srx_cdiv(kchunks, p.kc_per_split); }
+      else { p.full = p.tiles; p.tail = 0; p.split = 1; p.kc_per_split = kchunks; }
+      p.ks = (bm == 64 && bn == 64 && ks == 2) ? 2 : 1;
+      return p;
+    }
   }
   // fewer workgroups than CUs and a 4-wave tile: split its k-chunks over two wave groups (KS = 2)
   best.ks = (best.BM == 64 && best.BN == 64 && best.full + best.tail * best.split <= P && best.kc_per_split >= 4) ? 2 : 1;
@@ -909,13 +959,16 @@ extern "C" int srx_conv2d_pack(const srx_conv2d_t* d, const float* w, float* wpk
   SRX_REQUIRE(w && wpk_fwd, "conv2d_pack: null pointer");
   hipStream_t st = srx_stream(stream);
   const Geo g = fwd_geo(d);
+  PackArgs pa{};
+  pa.w = w; pa.Cout = d->Cout; pa.Cin = d->Cin; pa.KH = d->KH; pa.KW = d->KW; pa.stride = d->stride; pa.pad = d->pad;
+  pa.cps = g.cps;
+  int64_t maxn = 0;
   if (srx_thin_fwd_applicable(d)) {
     if (int rc = srx_thin_pack(d, w, wpk_fwd, 0, st)) return rc;
   } else {
-    const int64_t n = (int64_t)g.Cnp * g.Kp;
-    hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, st, w, wpk_fwd, d->Cout,
-                       d->Cin, d->KH, d->KW, g.Ck, g.K, g.Kp, g.Cnp, g.cps);
-    SRX_CHECK_LAUNCH("pack_fwd_kernel");
+    PackSeg& sg = pa.seg[pa.nseg++];
+    sg = PackSeg{wpk_fwd, g.Cnp, g.K, g.Kp, g.Ck, 0, 0, 0, 0, 0, 1};
+    maxn = (int64_t)g.Cnp * g.Kp;
   }
   if (wpk_bwd && srx_thin_dgrad_applicable(d)) {
     if (int rc = srx_thin_pack(d, w, wpk_bwd, 1, st)) return rc;
@@ -928,12 +981,14 @@ extern "C" int srx_conv2d_pack(const srx_conv2d_t* d, const float* w, float* wpk
     const int Cnp = pad_rows(d->Cin);
     for (int i = 0; i < nc; ++i) {
       const BwdClass& c = cls[i];
-      const int64_t n = (int64_t)Cnp * c.Kp;
-      hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, st, w, wpk_bwd + c.woff,
-                         d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, c.ph, c.pw, c.dminh, c.dminw,
-                         c.ntw > 0 ? c.ntw : 1, Ck, c.K, c.Kp, Cnp, g.cps);
-      SRX_CHECK_LAUNCH("pack_bwd_kernel");
+      PackSeg& sg = pa.seg[pa.nseg++];
+      sg = PackSeg{wpk_bwd + c.woff, Cnp, c.K, c.Kp, Ck, 1, c.ph, c.pw, c.dminh, c.dminw, c.ntw > 0 ? c.ntw : 1};
+      if ((int64_t)Cnp * c.Kp > maxn) maxn = (int64_t)Cnp * c.Kp;
     }
+  }
+  if (pa.nseg > 0) {
+    hipLaunchKernelGGL(pack_all_kernel, dim3((unsigned)srx_cdiv(maxn, 256), pa.nseg), dim3(256), 0, st, pa);
+    SRX_CHECK_LAUNCH("pack_all_kernel");
   }
   return SRX_OK;
 }
