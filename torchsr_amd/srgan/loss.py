@@ -91,8 +91,15 @@ class VGGLoss(nn.Module):
                 out = m(out)
         return out
 
-    def forward(self, source: Tensor, target: Tensor) -> Tensor:
+    @torch.no_grad()
+    def target_features(self, target: Tensor) -> Tensor:
+        """``self.features(target)`` of the detached branch (loss.py:53); no autograd state."""
+        return self.features_nhwc(F.to_nhwc(target, 4))
+
+    def forward(self, source: Tensor, target: Tensor = None, target_features: Tensor = None) -> Tensor:
+        """``l1_loss(features(source), features(target))``.  ``target_features`` may carry the second
+        term when the caller has already computed it (the trainers do so on a second stream: the target
+        branch depends on nothing but the HR batch)."""
         fs = self.features_nhwc(F.to_nhwc(source, 4))
-        with torch.no_grad():
-            ft = self.features_nhwc(F.to_nhwc(target, 4))
+        ft = target_features if target_features is not None else self.target_features(target)
         return F.l1_loss(fs, ft)
