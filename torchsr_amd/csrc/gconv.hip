@@ -184,6 +184,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * BK + ch);
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * BK + ch);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -191,6 +192,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
   };
 
