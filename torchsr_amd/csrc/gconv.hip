@@ -39,7 +39,19 @@ struct GArgs {
   // finishes them (sum, bias, activation, BatchNorm partials).
   int kchunks, kc_per_split, full_tiles, tail_split;
   float* ws;
+  // sizes of the `in` and `w` buffers: both are read through raw buffer descriptors, whose range
+  // check returns 0 for the padding taps (no branch, no select, statically countable loads)
+  unsigned in_bytes, w_bytes;
 };
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t srx_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 srx_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ int srx_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 constexpr int BK = 32;           // floats per k-chunk (one 128-byte LDS row)
 constexpr int INVALID = -20000;  // coordinate that fails every bounds check
@@ -65,8 +77,10 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   static_assert(RA >= 1 && RB >= 1, "tile too small for the thread count");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int ks = threadIdx.x / GT;            // k-group of this wave (waves of a group are contiguous)
-  const int tid = threadIdx.x % GT, lane = tid & 63, wave = tid >> 6;
+  // wave-uniform quantities are forced into SGPRs (readfirstlane): loop control then compiles to
+  // scalar branches instead of exec-mask juggling around the MFMA blocks
+  const int ks = KS == 1 ? 0 : srx_uniform(threadIdx.x / GT);  // k-group of this wave (groups are contiguous)
+  const int tid = threadIdx.x - ks * GT, lane = tid & 63, wave = srx_uniform(tid >> 6);
   float* sA = reinterpret_cast<float*>(smem) + ks * 2 * (BM + BN) * BK;
   float* sB = sA + 2 * BM * BK;
   int2* ktab = reinterpret_cast<int2*>(reinterpret_cast<float*>(smem) + KS * 2 * (BM + BN) * BK);
@@ -84,9 +98,11 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       slab = a.ws + (size_t)t * (BM * BN);
     }
   }
-  const int mt = tile % a.mtiles, nt = tile / a.mtiles;
+  tile = srx_uniform(tile); kc_beg = srx_uniform(kc_beg); kc_end = srx_uniform(kc_end);
+  const int nt = srx_uniform(tile / a.mtiles), mt = tile - nt * a.mtiles;
   const int m0 = mt * BM, n0 = nt * BN;
   const int q = tid & 7, r0 = tid >> 3;
+  const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes), rw = srx_rsrc(a.w, a.w_bytes);
 
   // ---- k table: (dh, dw) and linear input offset for every float4 of K in range
   for (int e = kc_beg * 8 + (int)threadIdx.x; e < kc_end * 8; e += NT) {
@@ -104,7 +120,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
         koff = (dh * a.Wi + dw) * a.Ci + c;
       }
       ent.x = (int)((unsigned)(dh & 0xffff) | ((unsigned)dw << 16));
-      ent.y = koff;
+      ent.y = koff * 4;  // bytes
     } else {
       ent.x = (INVALID & 0xffff);
       ent.y = 0;
@@ -113,7 +129,8 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   }
 
   // ---- per-thread rows of the A tile (fixed for the whole k loop)
-  int rbase[RA], rih[RA], riw[RA];
+  int rih[RA], riw[RA];
+  unsigned rbase[RA];  // byte offset of the row's centre pixel
 #pragma unroll
   for (int p = 0; p < RA; ++p) {
     const int m = m0 + r0 + RPP * p;
@@ -124,13 +141,15 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       const int ih0 = mh * a.in_stride, iw0 = mw * a.in_stride;
       rih[p] = ih0;
       riw[p] = iw0;
-      rbase[p] = a.in_shuffle ? ((n * 2 * a.Hi + 2 * ih0) * (2 * a.Wi) + 2 * iw0) * a.Ci
-                              : ((n * a.Hi + ih0) * a.Wi + iw0) * a.Ci;
+      rbase[p] = 4u * (unsigned)(a.in_shuffle ? ((n * 2 * a.Hi + 2 * ih0) * (2 * a.Wi) + 2 * iw0) * a.Ci
+                                              : ((n * a.Hi + ih0) * a.Wi + iw0) * a.Ci);
     } else {
       rih[p] = INVALID; riw[p] = 0; rbase[p] = 0;
     }
   }
-  const float* wrow = a.w + (size_t)(n0 + r0) * a.Kp + q * 4;
+  unsigned wvoff[RB];
+#pragma unroll
+  for (int p = 0; p < RB; ++p) wvoff[p] = 4u * ((unsigned)(n0 + r0 + RPP * p) * (unsigned)a.Kp + q * 4);
   __syncthreads();
 
   f32x16 acc[TM][TN];
@@ -145,20 +164,22 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   // the loads of chunk k+2 are in flight.  With one workgroup per CU (most launches here have fewer
   // tiles than 2 x CUs) a single stage leaves ~0.5 us of L2/HBM latency exposed per chunk.
   f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
+  // Every step issues the same RA + RB loads -- past the end of the k range they are pointed out of
+  // range and cost nothing -- so that the compiler can count outstanding loads exactly (s_waitcnt
+  // vmcnt(N) for the older register stage only) instead of draining both stages at every step.
   auto gload = [&](int kc, f32x4 (&ra)[RA], f32x4 (&rb)[RB]) {
-    const int2 kt = ktab[(kc - kc_beg) * 8 + q];
+    const bool live = kc < kc_end;  // wave-uniform
+    const int2 kt = ktab[(live ? kc - kc_beg : 0) * 8 + q];
     const int dh = (int)(short)(kt.x & 0xffff), dw = kt.x >> 16;
 #pragma unroll
     for (int p = 0; p < RA; ++p) {
       const int ih = rih[p] + dh, iw = riw[p] + dw;
-      const bool ok = ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
-      const int off = ok ? rbase[p] + kt.y : 0;
-      f32x4 v = *reinterpret_cast<const f32x4*>(a.in + off);
-      ra[p] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const bool ok = live && ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
+      ra[p] = srx_bload(rin, ok ? rbase[p] + (unsigned)kt.y : 0xffffffffu, 0);  // out of range reads 0
     }
 #pragma unroll
     for (int p = 0; p < RB; ++p)
-      rb[p] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(RPP * p) * a.Kp + kc * BK);
+      rb[p] = srx_bload(rw, live ? wvoff[p] : 0xffffffffu, (unsigned)srx_uniform(live ? kc * (BK * 4) : 0));
   };
   const int wchunk = (q ^ ((r0 >> 1) & 7)) * 4;
   auto swrite = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) {
@@ -176,14 +197,19 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   auto compute = [&](int buf) {
     const float* cA = sA + buf * BM * BK + arow;
     const float* cB = sB + buf * BN * BK + brow;
+    // fragments of step s+1 are read while the MFMAs of step s run (two register sets)
+    f32x4 af[2][TM], bf[2][TN];
+    auto frag = [&](int s, int set) {
+      const int ch = ((2 * s + h) ^ xr) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[set][i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * BK + ch);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * BK + ch);
+    };
+    frag(0, 0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int ch = ((2 * s + h) ^ xr) * 4;
-      f32x4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * BK + ch);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * BK + ch);
+      if (s + 1 < 4) frag(s + 1, (s + 1) & 1);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -191,7 +217,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i][e], bf[s & 1][j][e], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
   };
@@ -199,25 +225,23 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   // this group's chunks: kc_beg + ks, + KS, ...; every group runs the same number of steps (barriers)
   const int c0 = kc_beg + ks;
   const int nsteps = (kc_end - kc_beg + KS - 1) / KS;
-  if (c0 < kc_end) {
-    gload(c0, ra0, rb0);
-    if (c0 + KS < kc_end) gload(c0 + KS, ra1, rb1);
-    swrite(0, ra0, rb0);
-  }
+  gload(c0, ra0, rb0);
+  gload(c0 + KS, ra1, rb1);
+  swrite(0, ra0, rb0);
   __syncthreads();
 
   for (int j = 0; j < nsteps; j += 2) {
     const int kc = c0 + j * KS;
     // even step: chunk kc sits in LDS buffer 0, chunk kc+KS in register stage 1
-    if (kc + 2 * KS < kc_end) gload(kc + 2 * KS, ra0, rb0);
+    gload(kc + 2 * KS, ra0, rb0);
     if (kc < kc_end) compute(0);
-    if (kc + KS < kc_end) swrite(1, ra1, rb1);
+    swrite(1, ra1, rb1);  // (zeros past the end of the range: never multiplied)
     __syncthreads();
-    if (j + 1 >= nsteps) break;
-    // odd step: chunk kc+KS in LDS buffer 1, chunk kc+2KS in register stage 0
-    if (kc + 3 * KS < kc_end) gload(kc + 3 * KS, ra1, rb1);
+    // odd step (runs even when nsteps is odd: an early exit here would make the loop's load count
+    // path-dependent and cost the exact vmcnt waits): chunk kc+KS in LDS buffer 1, chunk kc+2KS in register stage 0
+    gload(kc + 3 * KS, ra1, rb1);
     if (kc + KS < kc_end) compute(1);
-    if (kc + 2 * KS < kc_end) swrite(0, ra0, rb0);
+    swrite(0, ra0, rb0);
     __syncthreads();
   }
 
@@ -665,7 +689,7 @@ int check_desc(const srx_conv2d_t* d) {
   SRX_REQUIRE(Ho > 0 && Wo > 0, "conv2d: empty output");
   SRX_REQUIRE((int64_t)d->N * d->H * d->W < (1 << 24) && (int64_t)d->N * Ho * Wo < (1 << 24),
               "conv2d: more than 2^24 pixels per call; tile the image");
-  SRX_REQUIRE((int64_t)d->N * d->H * d->W * d->Cin_s < 2147483647LL, "conv2d: input too large for 32-bit offsets");
+  SRX_REQUIRE((int64_t)d->N * d->H * d->W * d->Cin_s < (1LL << 30) - 4, "conv2d: input above 4 GiB; tile the image");
   SRX_REQUIRE(d->pad < 16000 && d->KH < 16000, "conv2d: kernel too large");
   return SRX_OK;
 }
@@ -1020,6 +1044,8 @@ extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float
   }
   a.part = bn_partials;
   a.out = y;
+  a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin_s * sizeof(float));
+  a.w_bytes = (unsigned)((size_t)g.Cnp * g.Kp * sizeof(float));
   return run_gconv(a, fwd_plan(d, g), ws, ws_floats, st);
 }
 
@@ -1040,6 +1066,8 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     if (hipMemsetAsync(dx, 0, (size_t)d->N * d->H * d->W * d->Cin_s * sizeof(float), st) != hipSuccess)
       SRX_FAIL(SRX_E_HIP, "conv2d_bwd_data: memset failed");
   }
+  const size_t dy_bytes = (size_t)d->N * g.Ho * g.Wo * (d->shuffle ? 4 : 1) * d->Cout_s * sizeof(float);
+  SRX_REQUIRE(dy_bytes < 0xfffffff0ull, "conv2d_bwd_data: gradient tensor too large for 32-bit offsets; tile the image");
   GMulti multi{};
   for (int i = 0; i < nc; ++i) {
     const BwdClass& c = cls[i];
@@ -1059,6 +1087,8 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     a.act = SRX_ACT_NONE; a.slope = 0.f;
     a.linear_out = (d->stride == 1);
     a.out = dx;
+    a.in_bytes = (unsigned)dy_bytes;
+    a.w_bytes = (unsigned)((size_t)pad_rows(d->Cin) * c.Kp * sizeof(float));
     if (d->stride == 1) {
       if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st)) return rc;
     } else if (nc <= 4) {
