@@ -12,6 +12,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torchsr_amd import functional as F  # noqa: E402
 from torchsr_amd.layers import Conv2d  # noqa: E402
 
 SHAPES = [
@@ -80,7 +81,34 @@ def main():
                     for _ in range(args.reps):
                         conv(xd0)
             t_f = timeit(g.replay, 5) / args.reps
-            print(f'{name:26s} {gf:7.3f} | graph fwd {t_f:8.2f} us {gf / t_f * 1e3:6.1f} TF/s', flush=True)
+
+            def bwd_graph(wrt_weight):
+                # forward + one gradient per repetition inside the capture (as the trainer does); the
+                # forward time measured above is subtracted.  Leaves are created inside the capture and
+                # the weight gradient goes through the direct-accumulation sink, so that no
+                # AccumulateGrad node bound to the default stream takes part.
+                conv.weight.requires_grad_(wrt_weight)
+                F.direct_grads[0] = True
+                if wrt_weight:
+                    conv.weight.grad = torch.zeros_like(conv.weight)
+
+                def once():
+                    if wrt_weight:
+                        conv(xd0).backward(gy)
+                    else:
+                        xin = xd0.detach().requires_grad_(True)
+                        torch.autograd.grad(conv(xin), xin, gy)
+                once()
+                torch.cuda.synchronize()
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb):
+                    for _ in range(args.reps):
+                        once()
+                return timeit(gb.replay, 5) / args.reps - t_f
+            t_d = bwd_graph(False)
+            t_w = bwd_graph(True)
+            print(f'{name:26s} {gf:7.3f} | graph fwd {t_f:7.2f} us {gf / t_f * 1e3:6.1f} | dgrad {t_d:7.2f} us '
+                  f'{gf / t_d * 1e3:6.1f} | wgrad {t_w:7.2f} us {gf / t_w * 1e3:6.1f} TF/s', flush=True)
             continue
         t_f = timeit(lambda: conv(x.detach()), args.reps)
         xd = x.detach().requires_grad_(True)

@@ -16,7 +16,9 @@
 #include "srx_common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <mutex>
+#include <vector>
 
 namespace {
 
@@ -453,15 +455,17 @@ struct WArgs {
   int in_stride, nth, ntw, dh0, dw0, Ck, K, Kw;
   int Cd, Cdv, dy_shuffle, Cnw;
   int rows_per_split, ktiles;
+  unsigned in_bytes, dy_bytes;  // raw-buffer ranges (see GArgs)
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
   __shared__ __attribute__((aligned(16))) float sD[2][32 * 64];
   __shared__ __attribute__((aligned(16))) float sX[2][32 * 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kt = blockIdx.x % a.ktiles, ntile = blockIdx.x / a.ktiles;
+  const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
+  const int ntile = srx_uniform(blockIdx.x / a.ktiles), kt = blockIdx.x - ntile * a.ktiles;
   const int k0 = kt * 64, n0 = ntile * 64;
   const int q = tid & 15, r0 = tid >> 4;
+  const __amdgpu_buffer_rsrc_t rx_ = srx_rsrc(a.in, a.in_bytes), rd_ = srx_rsrc(a.dy, a.dy_bytes);
 
   // this thread's fixed k (A gather) and fixed dy column
   const int k = k0 + 4 * q;
@@ -498,17 +502,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
       srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
       const int ih = mh * a.in_stride + dh, iw = mw * a.in_stride + dw;
       const bool okx = valid && kvalid && ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
-      const size_t offx = okx ? ((size_t)(n * a.Hi + ih) * a.Wi + iw) * a.Ci + kc : 0;
-      f32x4 vx = *reinterpret_cast<const f32x4*>(a.in + offx);
-      rx[p] = okx ? vx : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const unsigned offx = 4u * (unsigned)(((n * a.Hi + ih) * a.Wi + iw) * a.Ci + kc);
+      rx[p] = srx_bload(rx_, okx ? offx : 0xffffffffu, 0);  // out of range reads 0
       const bool okd = valid && cvalid;
-      size_t offd = 0;
-      if (okd) {
-        if (a.dy_shuffle) offd = ((size_t)(n * 2 * a.Hm + 2 * mh + sh_i) * (2 * a.Wm) + 2 * mw + sh_j) * a.Cd + sh_c;
-        else offd = (size_t)m * a.Cd + col;
-      }
-      f32x4 vd = *reinterpret_cast<const f32x4*>(a.dy + offd);
-      rd[p] = okd ? vd : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const unsigned offd = 4u * (unsigned)(a.dy_shuffle
+          ? ((n * 2 * a.Hm + 2 * mh + sh_i) * (2 * a.Wm) + 2 * mw + sh_j) * a.Cd + sh_c
+          : m * a.Cd + col);
+      rd[p] = srx_bload(rd_, okd ? offd : 0xffffffffu, 0);
     }
   };
   auto swrite = [&](int buf, const f32x4 (&rd)[2], const f32x4 (&rx)[2]) {
@@ -532,21 +532,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
     for (int s = 0; s < 16; ++s)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cD[s * 128], cX[s * 128], acc, 0, 0, 0);
   };
-  if (mbeg < mend) {
-    gload(mbeg, rd0, rx0);
-    if (mbeg + 32 < mend) gload(mbeg + 32, rd1, rx1);
-    swrite(0, rd0, rx0);
-  }
+  // every step issues the same four loads (rows past `mend` are pointed out of range and read 0), so
+  // the prefetch waits are exact vmcnt counts -- see gconv_body
+  gload(mbeg, rd0, rx0);
+  gload(mbeg + 32, rd1, rx1);
+  swrite(0, rd0, rx0);
   __syncthreads();
   for (int mb = mbeg; mb < mend; mb += 64) {
-    if (mb + 64 < mend) gload(mb + 64, rd0, rx0);
+    gload(mb + 64, rd0, rx0);
     compute(0);
-    if (mb + 32 < mend) swrite(1, rd1, rx1);
+    swrite(1, rd1, rx1);
     __syncthreads();
-    if (mb + 32 >= mend) break;
-    if (mb + 96 < mend) gload(mb + 96, rd1, rx1);
-    compute(1);
-    if (mb + 64 < mend) swrite(0, rd0, rx0);
+    gload(mb + 96, rd1, rx1);
+    if (mb + 32 < mend) compute(1);
+    swrite(0, rd0, rx0);
     __syncthreads();
   }
   float* slab = a.slab + (size_t)blockIdx.z * a.Cnw * a.Kw;
@@ -848,8 +847,46 @@ int launch_gconv_multi(const GMulti& m, size_t lds, hipStream_t st) {
   return SRX_OK;
 }
 
-// all problems use tile (BM, BN) of `p`; no K split (strided outputs cannot take the fix-up path)
+// Tile for a multi-problem launch.  The stride-parity classes of a data gradient have the same M but
+// 1x..4x different K, and their strided outputs cannot take the split-K fix-up path, so balance comes
+// from the tile size alone: every candidate's workgroups are list-scheduled heavy-first (the order
+// run_gconv_multi launches them in) over the CUs and the shortest makespan wins.
+void multi_tile(const GMulti& m, int Cnp, int& BM, int& BN) {
+  const int P = device_cus();
+  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+  const float eff[4] = {0.95f, 0.85f, 0.60f, 0.50f};
+  float best = 1e30f;
+  BM = 128; BN = Cnp == 32 ? 32 : 64;
+  std::vector<float> heap;
+  for (int i = 0; i < 4; ++i) {
+    const int bm = cand[i][0], bn = cand[i][1];
+    if (Cnp == 32) { if (bn != 32) continue; }
+    else if (bn == 32 || Cnp % bn != 0) continue;
+    heap.assign(P, 0.f);  // min-heap of CU finish times
+    auto later = [](float x, float y) { return x > y; };
+    float makespan = 0.f;
+    for (int pass = 4; pass >= 1; --pass)  // heavy-first: K of a class is 1..4 tap groups; order by chunk count
+      for (int c = 0; c < m.n; ++c) {
+        const int kch = m.g[c].Kp / BK;
+        int rank = 1;
+        for (int o = 0; o < m.n; ++o) rank += (m.g[o].Kp < m.g[c].Kp);
+        if (rank != pass) continue;
+        const float cost = 1.0f + 2.0f * bm * bn * (float)kch * BK / (4 * 64 * 2.1e3f) / eff[i];
+        const int tiles = (int)srx_cdiv(m.g[c].M, bm) * (int)srx_cdiv(m.g[c].Cn, bn);
+        for (int t = 0; t < tiles; ++t) {
+          std::pop_heap(heap.begin(), heap.end(), later);
+          heap.back() += cost;
+          if (heap.back() > makespan) makespan = heap.back();
+          std::push_heap(heap.begin(), heap.end(), later);
+        }
+      }
+    if (makespan < best) { best = makespan; BM = bm; BN = bn; }
+  }
+}
+
+// all problems use tile (BM, BN); no K split.  Problems are launched heaviest (largest K) first.
 int run_gconv_multi(GMulti& m, int BM, int BN, hipStream_t st) {
+  std::stable_sort(m.g, m.g + m.n, [](const GArgs& x, const GArgs& y) { return x.Kp > y.Kp; });
   int maxk = 0;
   m.first[0] = 0;
   for (int i = 0; i < m.n; ++i) {
@@ -969,8 +1006,17 @@ extern "C" int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out) {
     size_t total;
     const int nc = bwd_classes(d, cls, total);
     if (d->stride > 1 && nc <= 4) {
-      p = make_plan(d->N * cls[0].Hm * cls[0].Wm * nc, pad_rows(d->Cin), cls[0].Kp / BK, false);
-      p.ks = 1;
+      GMulti m{};
+      for (int i = 0; i < nc; ++i) {
+        if (cls[i].K == 0 || cls[i].Hm <= 0 || cls[i].Wm <= 0) continue;
+        m.g[m.n].M = d->N * cls[i].Hm * cls[i].Wm;
+        m.g[m.n].Cn = d->Cin;
+        m.g[m.n++].Kp = cls[i].Kp;
+      }
+      p = Plan{};
+      multi_tile(m, pad_rows(d->Cin), p.BM, p.BN);
+      p.split = 1; p.ks = 1; p.tail = 0;
+      for (int i = 0; i < m.n; ++i) p.full += (int)srx_cdiv(m.g[i].M, p.BM) * (int)srx_cdiv(d->Cin, p.BN);
       multi = 1;
     } else {
       p = bwd_plan(d, cls[0]);
@@ -1098,9 +1144,9 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     }
   }
   if (multi.n > 0) {
-    // tile choice: the classes are (nearly) equal sized; pick the tile for their combined work
-    const Plan p = make_plan(multi.g[0].M * multi.n, pad_rows(d->Cin), multi.g[0].Kp / BK, false);
-    if (int rc = run_gconv_multi(multi, p.BM, p.BN, st)) return rc;
+    int bm, bn;
+    multi_tile(multi, pad_rows(d->Cin), bm, bn);
+    if (int rc = run_gconv_multi(multi, bm, bn, st)) return rc;
   }
   return SRX_OK;
 }
@@ -1125,15 +1171,30 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
   a.dy_shuffle = g.cps;
   a.Cdv = d->shuffle ? d->Cout : d->Cout_s;
   a.ktiles = a.Kw / 64;
+  const size_t dyb = (size_t)d->N * g.Ho * g.Wo * (d->shuffle ? 4 : 1) * d->Cout_s * sizeof(float);
+  SRX_REQUIRE(dyb < 0xfffffff0ull, "conv2d_bwd_weight: gradient tensor above 4 GiB; tile the image");
+  a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin_s * sizeof(float));
+  a.dy_bytes = (unsigned)dyb;
   const int ntiles = a.Cnw / 64;
   static int cus = 0;
   if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
   const int64_t tiles = (int64_t)a.ktiles * ntiles;
-  int nsplit = (int)srx_cdiv(4 * cus, tiles);
+  // Row splits: the slabs cost a write + a read each, a workgroup alone on its CU runs latency-bound
+  // (~1 us per 32-row chunk, ~0.65 us with four co-resident), and workgroup counts just above a
+  // multiple of the CU count leave a nearly empty last round.  Calibrated on the SRGAN layer shapes
+  // (tools/bench_kernels.py --graph); SRX_WGRAD_NSPLIT overrides for experiments.
   const int max_by_rows = (int)srx_cdiv(a.M, 128);  // at least 128 rows per split
-  if (nsplit > max_by_rows) nsplit = max_by_rows;
-  if (nsplit > 64) nsplit = 64;
-  if (nsplit < 1) nsplit = 1;
+  int nsplit = 1;
+  float best_cost = 1e30f;
+  for (int ns = 1; ns <= 64 && ns <= max_by_rows; ++ns) {
+    const int rps = (int)srx_roundup(srx_cdiv(a.M, ns), 32);
+    if ((int)srx_cdiv(a.M, rps) != ns) continue;  // not reachable after rounding to whole chunks
+    const int L = (int)srx_cdiv(tiles * ns, cus);
+    const float hide = L >= 4 ? 0.65f : (L == 3 ? 0.7f : (L == 2 ? 0.8f : 1.0f));
+    const float cost = 1.07f * L * (rps / 32 + 6) * hide + (float)ns * a.Cnw * a.Kw * 8.0f / 3.0e6f;
+    if (cost < best_cost) { best_cost = cost; nsplit = ns; }
+  }
+  if (const char* e = getenv("SRX_WGRAD_NSPLIT")) { const int v = atoi(e); if (v > 0 && v <= 64) nsplit = v; }
   a.rows_per_split = (int)srx_roundup(srx_cdiv(a.M, nsplit), 32);
   nsplit = (int)srx_cdiv(a.M, a.rows_per_split);
   const size_t need = (size_t)nsplit * a.Cnw * a.Kw;
