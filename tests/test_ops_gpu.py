@@ -65,6 +65,14 @@ CONV_CASES = [
     (1, 8, 8, 32, 32, 1, 1, 0, True, 1, 0),        # 1x1
     (4, 96, 96, 16, 128, 3, 1, 1, False, 0, 0),    # large M: 128x128 tile
     (2, 11, 13, 24, 40, 3, 3, 1, True, 0, 0),      # stride 3
+    # 36-pixel row tiles (rowtile.hip): 3x3 64->64 with H*W % 36 == 0
+    (16, 24, 24, 64, 64, 3, 1, 1, True, 2, 0),     # the reference batch: 256 workgroups, bias + LeakyReLU
+    (3, 12, 12, 64, 64, 3, 1, 1, True, 1, 0),      # tiles span 4 image rows
+    (1, 6, 6, 64, 64, 3, 1, 1, False, 0, 0),       # one workgroup, 6-wide image
+    (2, 18, 10, 64, 64, 3, 1, 1, False, 0, 0),     # tiles start at any column
+    (1, 48, 48, 64, 64, 3, 1, 1, False, 0, 0),     # widest patch that still fits
+    (1, 9, 4, 64, 64, 3, 1, 1, True, 0, 0),        # 4-wide image
+    (2, 24, 26, 64, 64, 3, 1, 1, False, 0, 0),     # H*W % 36 != 0: generic kernel on the same layer
 ]
 
 
@@ -118,6 +126,22 @@ def test_conv2d_fwd_bwd(dev, case):
     assert rel_err(conv.weight.grad, wc.grad) < 2e-4
     if bias:
         assert rel_err(conv.bias.grad, bc.grad) < 2e-4
+
+
+def test_row_tile_plan(dev):
+    """The SRGAN residual conv at the reference batch runs as 256 workgroups of 36 pixels (forward and
+    data gradient); a layer the row tile does not cover falls back to the generic plan."""
+    from torchsr_amd import _lib
+    d = _lib.Conv2dDesc(16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0)
+    out = (C.c_int * 6)()
+    for which in (0, 1):
+        _lib.call('srx_conv2d_plan', C.byref(d), which, out)
+        assert list(out)[:4] == [36, 64, 1, 256]
+    assert _lib.lib().srx_conv2d_stat_rows(C.byref(d)) == 256
+    assert _lib.lib().srx_conv2d_fwd_ws_floats(C.byref(d)) == 0
+    d2 = _lib.Conv2dDesc(16, 24, 26, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0)
+    _lib.call('srx_conv2d_plan', C.byref(d2), 0, out)
+    assert out[0] in (64, 128)
 
 
 @pytest.mark.parametrize('cfg', [(2, 24, 24, 64, 'prelu', True), (2, 12, 12, 128, 'lrelu', False),

@@ -12,7 +12,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libsrx_hip.so')
-SOURCES = ['api.cpp', 'gconv.hip', 'thin.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'optim.hip']
+SOURCES = ['api.cpp', 'gconv.hip', 'thin.hip', 'rowtile.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'optim.hip']
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
 

@@ -46,14 +46,6 @@ struct GArgs {
   unsigned in_bytes, w_bytes;
 };
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t srx_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 srx_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-}
-__device__ __forceinline__ int srx_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 constexpr int BK = 32;           // floats per k-chunk (one 128-byte LDS row)
 constexpr int INVALID = -20000;  // coordinate that fails every bounds check
@@ -942,6 +934,7 @@ Plan bwd_plan(const srx_conv2d_t* d, const BwdClass& c) {
 }
 
 int stat_rows_for(const srx_conv2d_t* d) {
+  if (srx_rt36_applicable(d)) return srx_rt36_rows(d);
   const Geo g = fwd_geo(d);
   return fwd_plan(d, g).mtiles;
 }
@@ -965,13 +958,14 @@ extern "C" size_t srx_conv2d_packed_bwd_floats(const srx_conv2d_t* d) {
 
 extern "C" size_t srx_conv2d_fwd_ws_floats(const srx_conv2d_t* d) {
   if (check_desc(d)) return 0;
+  if (srx_rt36_applicable(d)) return 0;
   const Geo g = fwd_geo(d);
   return plan_ws_floats(fwd_plan(d, g));
 }
 
 extern "C" size_t srx_conv2d_bwd_data_ws_floats(const srx_conv2d_t* d) {
   if (check_desc(d)) return 0;
-  if (d->stride != 1) return 0;
+  if (d->stride != 1 || srx_rt36_applicable(d)) return 0;
   BwdClass cls[16];
   size_t total;
   bwd_classes(d, cls, total);
@@ -998,6 +992,10 @@ extern "C" int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out) {
   SRX_REQUIRE(out, "conv2d_plan: null pointer");
   Plan p;
   int multi = 0;
+  if (srx_rt36_applicable(d)) {  // 36-pixel row tiles (rowtile.hip), forward and data gradient alike
+    out[0] = 36; out[1] = 64; out[2] = 1; out[3] = srx_rt36_rows(d); out[4] = 1; out[5] = 0;
+    return SRX_OK;
+  }
   if (which == 0) {
     p = fwd_plan(d, fwd_geo(d));
   } else {
@@ -1071,6 +1069,7 @@ extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float
   SRX_REQUIRE(x && wpk && y, "conv2d_fwd: null pointer");
   hipStream_t st = srx_stream(stream);
   if (srx_thin_fwd_applicable(d) && !bn_partials) return srx_thin_fwd(d, x, wpk, bias, y, d->Cout, st);
+  if (srx_rt36_applicable(d)) return srx_rt36_run(d, x, wpk, bias, y, bn_partials, d->act, d->slope, st);
   const Geo g = fwd_geo(d);
   GArgs a{};
   a.in = x; a.w = wpk; a.bias = bias; a.part = nullptr;
@@ -1106,6 +1105,8 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
   BwdClass cls[16];
   size_t total;
   const int nc = bwd_classes(d, cls, total);
+  if (srx_rt36_applicable(d))  // 3x3 / stride 1 / pad 1: one class, same geometry as the forward, flipped taps
+    return srx_rt36_run(d, dy, wpk_bwd + cls[0].woff, nullptr, dx, nullptr, SRX_ACT_NONE, 0.f, st);
   bool any_empty = false;
   for (int i = 0; i < nc; ++i) any_empty |= (cls[i].K == 0);
   if (any_empty) {

@@ -1,0 +1,236 @@
+// 3x3, 64 -> 64, stride 1, pad 1 convolution on few pixels: the 32 + 2 convs of the SRGAN residual
+// tower (srgan/residual.py:64,67, srgan/generator.py:48) and their data gradients, on 16 x 24 x 24
+// low-resolution pixels at the reference batch size.
+//
+// That problem is 9216 x 64 x 576: only 144 of the generic 64x64 tiles, so 44 % of the chip idles and
+// the rest runs two latency-bound waves per SIMD.  Here every workgroup owns 36 consecutive pixels
+// (9216 = 256 CUs x 36) and all four SIMDs of its CU stay on the matrix pipe:
+//
+//   wave w:  output columns 32(w&1)..+31, input-channel half (w>>1) of every tap
+//     32 pixels  on v_mfma_f32_32x32x2_f32  (64 cycles per channel pair)
+//      4 pixels  on v_mfma_f32_4x4x1_16b_f32 ( 8 cycles per channel pair: the 16 blocks are the same 4
+//                pixels against 2 x 32 columns, even channels in lanes 0-31, odd in 32-63)
+//   Both MFMAs take the SAME weight operand register (lane = column, lane half = channel parity), which is
+//   streamed from L2 straight into registers -- every weight element is used by exactly one wave, so
+//   staging it in LDS would only add traffic.
+//
+// The input is staged once as a zero-padded 2-D patch (image rows r-1 .. r+span, columns -1 .. W) in LDS, so
+// a tap is a constant address offset and there are no bounds checks in the loop.  Pixel stride 68 floats
+// keeps the b128 fragment reads of 16 consecutive pixels on distinct banks.
+// The two channel halves are folded through LDS; bias, activation, BatchNorm partial sums and the store
+// follow the generic epilogue (gconv.hip).
+#include "srx_common.h"
+#include <mutex>
+
+namespace {
+
+constexpr int RT = 36;     // pixels per workgroup
+constexpr int PSTR = 68;   // floats per patch pixel (64 channels + 4 pad)
+constexpr int KTOT = 576;  // 9 taps x 64 channels
+constexpr int PF = 8;      // weight fragments in flight per wave
+constexpr int PB = 8;      // patch b128 loads per thread and batch
+
+struct RtArgs {
+  const float* in; const float* w; const float* bias; float* out; float* part;
+  int H, W, HW, M;
+  float slope;       // branch-free activation: v > 0 ? v : v * slope  (none: 1, ReLU: 0, LeakyReLU: its slope)
+  unsigned in_bytes, out_bytes;
+  int step_r, step_c;  // 16 / (W+2), 16 % (W+2): patch-fill stride of one thread
+};
+
+// NB = batches of PB patch loads per thread (1 up to 2048 b128 slots, 2 up to the 64 KB LDS limit): a
+// compile-time count, so that ALL input loads and the first weight fragments are in flight together
+// and the compiler can wait on them with exact vmcnt values (a runtime loop drains the queue per trip).
+template <int NB>
+__global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float patch[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
+  const int j = wave & 1, hk = wave >> 1;
+  const int i31 = lane & 31, h2 = lane >> 5;
+  const int m0 = blockIdx.x * RT;
+  const int n = m0 / a.HW, p0 = m0 - n * a.HW;  // HW % 36 == 0: a tile never crosses an image
+  const int r_first = p0 / a.W;
+  const int r_last = (p0 + RT - 1) / a.W;
+  const int W2 = a.W + 2;
+  const int prows = r_last - r_first + 3;
+  const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes);
+  const __amdgpu_buffer_rsrc_t rw = srx_rsrc(a.w, 64 * KTOT * 4);
+
+  // ---- input patch loads (out-of-image and surplus slots read 0 through the descriptor's range check)
+  // thread -> channel quad tid&15 of patch pixels (tid>>4) + 16u: the (row, column) of the pixel advances
+  // by the host-computed (16 / W2, 16 % W2) per step, no division in the loop
+  f32x4 v[NB * PB];
+  const unsigned quad16 = 16u * (tid & 15);
+  int pr = (tid >> 4) / W2, pc = (tid >> 4) - pr * W2, sidx = tid >> 4;
+  const int npix = prows * W2;
+#pragma unroll
+  for (int u = 0; u < NB * PB; ++u) {
+    const int ih = r_first - 1 + pr, iw = pc - 1;
+    const bool ok = sidx < npix && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+    v[u] = srx_bload(rin, ok ? (unsigned)((n * a.H + ih) * a.W + iw) * 256u + quad16 : 0xffffffffu, 0);
+    sidx += 16; pr += a.step_r; pc += a.step_c;
+    if (pc >= W2) { pc -= W2; pr += 1; }
+  }
+  // ---- weight stream: fragment `it` = (tap it>>2, channels 32hk + 8(it&3) + 4h2 .. +3) of column 32j+i31
+  const unsigned wvoff = 4u * (unsigned)((32 * j + i31) * KTOT + 32 * hk + 4 * h2);
+  f32x4 bq[PF];
+#pragma unroll
+  for (int it = 0; it < PF; ++it) bq[it] = srx_bload(rw, wvoff, (unsigned)(((it >> 2) * 64 + 8 * (it & 3)) * 4));
+  __builtin_amdgcn_sched_barrier(0);  // keep the weight loads ahead of the waits on the patch loads
+  // ---- patch -> LDS.  Surplus slots (e >= nslots) land in the slack the host adds behind the patch.
+#pragma unroll
+  for (int u = 0; u < NB * PB; ++u) {
+    const int e = u * 256 + tid;
+    *reinterpret_cast<f32x4*>(patch + (e >> 4) * PSTR + 4 * (e & 15)) = v[u];
+  }
+  __syncthreads();
+
+  // ---- per-lane patch addresses (tap (0,0) = one row up, one column left: the patch origin is (-1,-1))
+  auto slot = [&](int q) {  // pixel q of the image -> patch slot of its (-1,-1) neighbour
+    const int ih = q / a.W, iw = q - ih * a.W;
+    return ((ih - r_first) * W2 + iw) * PSTR;
+  };
+  const int choff = 32 * hk + 4 * h2;
+  const float* a32 = patch + slot(p0 + i31) + choff;
+  const float* a4 = patch + slot(p0 + 32 + (lane & 3)) + choff;
+  const int rowoff = W2 * PSTR;
+
+  // two accumulator chains: with one wave per SIMD a single dependent MFMA chain leaves issue gaps
+  f32x16 acc, accb;
+  f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
+
+  f32x4 fa[2], fb[2];  // A fragments of step it+1 are read while the MFMAs of step it run
+  auto frag = [&](int it, int set) {
+    const int tap = it >> 2, th = tap / 3, tw = tap - 3 * th;
+    const int off = th * rowoff + tw * PSTR + 8 * (it & 3);
+    fa[set] = *reinterpret_cast<const f32x4*>(a32 + off);
+    fb[set] = *reinterpret_cast<const f32x4*>(a4 + off);
+  };
+  frag(0, 0);
+#pragma unroll
+  for (int it = 0; it < 36; ++it) {
+    if (it + 1 < 36) frag(it + 1, (it + 1) & 1);
+    const f32x4 b = bq[it % PF];
+    if (it + PF < 36) {
+      const int nx = it + PF;
+      bq[it % PF] = srx_bload(rw, wvoff, (unsigned)(((nx >> 2) * 64 + 8 * (nx & 3)) * 4));
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e & 1) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[it & 1][e], b[e], accb, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[it & 1][e], b[e], acc, 0, 0, 0);
+      acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(fb[it & 1][e], b[e], acc4, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += accb[r];
+  // even / odd channel halves of the 4-pixel block live in lanes l and l+32
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc4[i] += __shfl_xor(acc4[i], 32, 64);
+
+  // ---- fold the two input-channel halves (the patch is dead now)
+  __syncthreads();
+  float* fold = patch;  // [j][20][64]
+  if (hk == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fold[(j * 20 + r) * 64 + lane] = acc[r];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fold[(j * 20 + 16 + i) * 64 + lane] = acc4[i];
+  }
+  __syncthreads();
+  if (hk == 1) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += fold[(j * 20 + r) * 64 + lane];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc4[i] += fold[(j * 20 + 16 + i) * 64 + lane];
+
+  // ---- epilogue.  32x32 accumulator: col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5);
+  //      4x4 accumulator: row 32+i, col = lane&31 (both lane halves hold the folded sum; half 0 stores)
+  //      (M is a multiple of 36: every row of the tile exists.)  Straight-line code: buffer stores with
+  //      32-bit offsets, activation as a select on a host-prepared slope.
+  const int col = 32 * j + i31;
+  const float bv = a.bias ? a.bias[col] : 0.f;
+  const __amdgpu_buffer_rsrc_t rout = srx_rsrc(a.out, a.out_bytes);
+  const unsigned obase = ((unsigned)m0 * 64u + (unsigned)col + 256u * h2) * 4u;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float v = acc[r] + bv;
+    s1 += v;
+    s2 += v * v;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v > 0.f ? v : v * a.slope), rout, obase, ((r & 3) + 8 * (r >> 2)) * 256, 0);
+  }
+  const unsigned obase4 = h2 == 0 ? ((unsigned)m0 * 64u + (unsigned)col) * 4u : 0xffffffffu;  // half 0 stores
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = acc4[i] + bv;
+    if (h2 == 0) { s1 += v; s2 += v * v; }
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v > 0.f ? v : v * a.slope), rout, obase4, (32 + i) * 256, 0);
+  }
+  if (a.part) {  // per-channel (sum, sum of squares) of this workgroup's 36 rows
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (h2 == 0) {
+      a.part[((size_t)blockIdx.x * 64 + col) * 2 + 0] = s1;
+      a.part[((size_t)blockIdx.x * 64 + col) * 2 + 1] = s2;
+    }
+  }
+}
+
+int patch_rows_max(int W) { return (W - 1 + RT - 1) / W + 3; }
+
+int patch_batches(int W) { return (int)srx_cdiv((int64_t)patch_rows_max(W) * (W + 2) * 16, 256 * PB); }
+
+size_t lds_bytes(int W) {  // every thread stores all its NB * PB slots: size for the rounded-up slot count
+  const size_t patch = (size_t)patch_batches(W) * (256 * PB / 16) * PSTR * sizeof(float);
+  const size_t fold = 2 * 20 * 64 * sizeof(float);
+  return patch > fold ? patch : fold;
+}
+
+}  // namespace
+
+extern "C" int srx_device_cus(void);
+
+bool srx_rt36_applicable(const srx_conv2d_t* d) {
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->shuffle || d->up) return false;
+  if (d->Cin != 64 || d->Cout != 64 || d->Cin_s != 64 || d->Cout_s != 64) return false;
+  const int64_t hw = (int64_t)d->H * d->W, m = hw * d->N;
+  if (hw % RT != 0 || d->W < 3) return false;
+  if (patch_batches(d->W) > 2 || lds_bytes(d->W) > 80 * 1024) return false;
+  // small problems only: above ~2 rounds of the chip the generic 128-row tiles re-read far less input
+  static int cus = 0;
+  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
+  if (getenv("SRX_NO_RT36")) return false;  // developer switch: force the generic kernel
+  return m / RT <= 2 * cus;
+}
+
+int srx_rt36_rows(const srx_conv2d_t* d) { return (int)((int64_t)d->N * d->H * d->W / RT); }
+
+int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, float* out, float* part,
+                 int act, float slope, hipStream_t st) {
+  RtArgs a{};
+  a.in = in; a.w = wpk; a.bias = bias; a.out = out; a.part = part;
+  a.H = d->H; a.W = d->W; a.HW = d->H * d->W; a.M = d->N * a.HW;
+  a.slope = act == SRX_ACT_RELU ? 0.f : (act == SRX_ACT_LRELU ? slope : 1.f);
+  a.in_bytes = (unsigned)((size_t)a.M * 64 * sizeof(float));
+  a.out_bytes = a.in_bytes;
+  a.step_r = 16 / (d->W + 2); a.step_c = 16 % (d->W + 2);
+  const size_t lds = lds_bytes(d->W);
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  });
+  if (patch_batches(d->W) == 1)
+    hipLaunchKernelGGL(rt36_conv3x3_c64_kernel<1>, dim3((unsigned)(a.M / RT)), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL(rt36_conv3x3_c64_kernel<2>, dim3((unsigned)(a.M / RT)), dim3(256), lds, st, a);
+  SRX_CHECK_LAUNCH("rt36_conv3x3_c64_kernel");
+  return SRX_OK;
+}

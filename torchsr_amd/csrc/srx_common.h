@@ -39,6 +39,12 @@ int srx_thin_pack(const srx_conv2d_t* d, const float* w, float* p, int mode, hip
 int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, float* out, int n_out,
                  hipStream_t st);
 
+// rowtile.hip: 3x3 / 64 -> 64 convolutions with few pixels (the SRGAN residual tower), 36 pixels per CU
+bool srx_rt36_applicable(const srx_conv2d_t* d);
+int srx_rt36_rows(const srx_conv2d_t* d);  // workgroups = rows of the BatchNorm partial table
+int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, float* out, float* part,
+                 int act, float slope, hipStream_t st);
+
 static inline hipStream_t srx_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t srx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t srx_roundup(int64_t a, int64_t b) { return srx_cdiv(a, b) * b; }
@@ -50,6 +56,18 @@ __device__ __forceinline__ void srx_divmod(int m, int d, float inv_d, int& q, in
   if (r < 0) { q -= 1; r += d; }
   if (r >= d) { q += 1; r -= d; }
 }
+
+// Raw buffer descriptor over [p, p + bytes): loads whose byte offset falls outside return 0, which is
+// how the conv kernels read padding taps -- no branch, no select, and every load is issued
+// unconditionally so the compiler can count outstanding loads exactly (s_waitcnt vmcnt(N)).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t srx_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 srx_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+// wave-uniform value into an SGPR (scalar branches / scalar address math)
+__device__ __forceinline__ int srx_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ float srx_wave_sum(float v) {
 #pragma unroll
