@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -280,53 +281,69 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
         }
     return;
   }
-  float* outp = a.out;
+  // Straight-line epilogue: the activation is a select on a host-prepared slope (none 1, ReLU 0), rows
+  // past M and padding columns are stored through a descriptor at an out-of-range offset (dropped by
+  // the hardware) instead of being branched around -- per-element branches used to cost more than
+  // the arithmetic.
+  auto out_elem = [&](int m) -> size_t {  // element offset of output row m
+    if (a.linear_out) return (size_t)m * a.Co;
+    int n, rem, mh, mw;
+    srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
+    srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
+    const int oh = mh * a.out_stride + a.oh_off, ow = mw * a.out_stride + a.ow_off;
+    return ((size_t)(n * a.Ho + oh) * a.Wo + ow) * a.Co;
+  };
+  // descriptor based at the tile's first row: offsets inside a tile are small and never negative
+  // (output rows are laid out in increasing m), so 32 bits are enough whatever the tensor size
+  const size_t tile_base = out_elem(m0);
+  const unsigned tb_lo = (unsigned)srx_uniform((int)(unsigned)(tile_base & 0xffffffffu));
+  const unsigned tb_hi = (unsigned)srx_uniform((int)(unsigned)(tile_base >> 32));
+  const __amdgpu_buffer_rsrc_t rout = srx_rsrc(a.out + (((size_t)tb_hi << 32) | tb_lo), 0xfffffff0u);
 
   float bv[TN];
-  int colv[TN], ocol[TN];
+  unsigned ocol[TN];  // byte offset of the column inside its output row
+  bool cok[TN];       // this lane stores the column
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * WN + j * 32 + l31;
-    colv[j] = col;
     int bidx = col, oc = col;
     if (a.out_shuffle) {
       const int ij = col / a.out_shuffle, cc = col - ij * a.out_shuffle;
       bidx = cc * 4 + ij;
       oc = (((ij >> 1) * a.Wo) + (ij & 1)) * a.Co + cc;  // offset inside the 2x2 output block
     }
-    ocol[j] = oc;
+    ocol[j] = 4u * (unsigned)oc;
+    cok[j] = lead && col < a.Cs;
     bv[j] = (a.bias && col < a.Cn) ? a.bias[bidx] : 0.f;
   }
   float csum[TN], csq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
 
+  auto store_tile = [&](auto linear) {  // one copy per output addressing mode, chosen by ONE branch
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const bool mok = m < a.M;
-      size_t obase;
-      if (a.linear_out) {
-        obase = (size_t)m * a.Co;
-      } else {
-        int n, rem, mh, mw;
-        srx_divmod(mok ? m : 0, a.HmWm, a.inv_HmWm, n, rem);
-        srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
-        const int oh = mh * a.out_stride + a.oh_off, ow = mw * a.out_stride + a.ow_off;
-        obase = ((size_t)(n * a.Ho + oh) * a.Wo + ow) * a.Co;
-      }
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool mok = m < a.M;
+        const unsigned rowoff = decltype(linear)::value ? 4u * (unsigned)((m - m0) * a.Co)
+                                                        : 4u * (unsigned)(out_elem(mok ? m : m0) - tile_base);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float v = acc[i][j][r] + bv[j];
-        if (mok) { csum[j] += v; csq[j] += v * v; }
-        if (a.act == SRX_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (a.act == SRX_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
-        if (lead && mok && colv[j] < a.Cs) outp[obase + ocol[j]] = v;
+        for (int j = 0; j < TN; ++j) {
+          float v = acc[i][j][r] + bv[j];
+          const float vs = mok ? v : 0.f;
+          csum[j] += vs;
+          csq[j] += vs * vs;
+          v = v > 0.f ? v : v * a.slope;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout,
+                                                (mok && cok[j]) ? rowoff + ocol[j] : 0xffffffffu, 0, 0);
+        }
       }
     }
-  }
+  };
+  if (a.linear_out) store_tile(std::true_type{});
+  else store_tile(std::false_type{});
 
   if (a.part) {  // per-channel sum / sum of squares of this row block (training-mode BatchNorm)
     __syncthreads();  // everyone is done with the staging buffers
@@ -410,8 +427,7 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const GArgs a) {
       s2 += v * v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (a.act == SRX_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-        else if (a.act == SRX_ACT_LRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+        v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
       }
       if (col < a.Cs) *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col) = v;  // Cs is a multiple of 4
     }
@@ -1078,7 +1094,8 @@ extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float
   a.in_stride = d->stride; a.nth = d->KH; a.ntw = d->KW; a.dh0 = -d->pad; a.dw0 = -d->pad;
   a.Ck = g.Ck; a.K = g.K; a.Kp = g.Kp;
   a.Cn = d->Cout;
-  a.act = d->act; a.slope = d->slope;
+  a.act = d->act;
+  a.slope = d->act == SRX_ACT_RELU ? 0.f : (d->act == SRX_ACT_LRELU ? d->slope : 1.f);  // v > 0 ? v : v * slope
   a.in_shuffle = 0;
   if (d->shuffle) {
     a.out_shuffle = g.cps; a.Cs = d->Cout; a.Ho = 2 * g.Ho; a.Wo = 2 * g.Wo; a.Co = d->Cout_s;
@@ -1131,7 +1148,7 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     a.Ho = d->H; a.Wo = d->W; a.Co = d->Cin_s;
     a.out_stride = d->stride; a.oh_off = c.ph; a.ow_off = c.pw;
     a.out_shuffle = 0;
-    a.act = SRX_ACT_NONE; a.slope = 0.f;
+    a.act = SRX_ACT_NONE; a.slope = 1.f;
     a.linear_out = (d->stride == 1);
     a.out = dx;
     a.in_bytes = (unsigned)dy_bytes;

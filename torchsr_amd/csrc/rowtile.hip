@@ -181,7 +181,14 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   }
 }
 
-int patch_rows_max(int W) { return (W - 1 + RT - 1) / W + 3; }
+int patch_rows_max(int W) {  // tiles start at columns (36 t) mod W only
+  int rows = 0;
+  for (int t = 0; t < W; ++t) {
+    const int r = ((RT * t) % W + RT - 1) / W + 3;
+    if (r > rows) rows = r;
+  }
+  return rows;
+}
 
 int patch_batches(int W) { return (int)srx_cdiv((int64_t)patch_rows_max(W) * (W + 2) * 16, 256 * PB); }
 
