@@ -464,6 +464,11 @@ struct WArgs {
   int Cd, Cdv, dy_shuffle, Cnw;
   int rows_per_split, ktiles;
   unsigned in_bytes, dy_bytes;  // raw-buffer ranges (see GArgs)
+  // A thread's rows advance by 32 per chunk; its pixel coordinates and both element offsets follow
+  // incrementally from these host-computed steps (no division in the loop):
+  //   s_c = 32 % Wm, s_rm = (32 / Wm) % Hm; dX0/dD0 plain step, dX1/dD1 extra on a column wrap
+  //   (mw -= Wm, mh += 1), dX2 extra on a row wrap (mh -= Hm, next image)
+  int s_c, s_rm, dX0, dX1, dX2, dD0, dD1;
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
@@ -499,24 +504,40 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
   const int mbeg = blockIdx.z * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
-  f32x4 rd0[2], rx0[2], rd1[2], rx1[2];  // two register stages, as in gconv_kernel
-  auto gload = [&](int mb, f32x4 (&rd)[2], f32x4 (&rx)[2]) {
+  // Four register stages: a workgroup that is alone on its CU (small layers: one row split per CU)
+  // multiplies a chunk in ~0.45 us but waits ~2 us for a load, so chunk c+4 is requested while c runs.
+  f32x4 rd0[2], rx0[2], rd1[2], rx1[2], rd2[2], rx2[2], rd3[2], rx3[2];
+  // row state of this thread's two rows (r0 + 16p of the current chunk); chunks are requested strictly in
+  // order, so every gload advances the state by one chunk
+  int rm[2], rmh[2], rmw[2];
+  unsigned rox[2], rod[2];  // element offsets: x at (n, mh*stride + dh, mw*stride + dw, kc); dy at the thread's column
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int m = mbeg + r0 + 16 * p;
+    int n, rem, mh, mw;
+    srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
+    srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
+    rm[p] = m; rmh[p] = mh; rmw[p] = mw;
+    rox[p] = (unsigned)(((n * a.Hi + mh * a.in_stride + dh) * a.Wi + mw * a.in_stride + dw) * a.Ci + kc);
+    rod[p] = (unsigned)(a.dy_shuffle ? ((n * 2 * a.Hm + 2 * mh + sh_i) * (2 * a.Wm) + 2 * mw + sh_j) * a.Cd + sh_c
+                                     : m * a.Cd + col);
+  }
+  auto gload = [&](f32x4 (&rd)[2], f32x4 (&rx)[2]) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const int m = mb + r0 + 16 * p;
-      const bool valid = m < mend;
-      int n, rem, mh, mw;
-      srx_divmod(valid ? m : 0, a.HmWm, a.inv_HmWm, n, rem);
-      srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
-      const int ih = mh * a.in_stride + dh, iw = mw * a.in_stride + dw;
+      const bool valid = rm[p] < mend;
+      const int ih = rmh[p] * a.in_stride + dh, iw = rmw[p] * a.in_stride + dw;
       const bool okx = valid && kvalid && ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
-      const unsigned offx = 4u * (unsigned)(((n * a.Hi + ih) * a.Wi + iw) * a.Ci + kc);
-      rx[p] = srx_bload(rx_, okx ? offx : 0xffffffffu, 0);  // out of range reads 0
-      const bool okd = valid && cvalid;
-      const unsigned offd = 4u * (unsigned)(a.dy_shuffle
-          ? ((n * 2 * a.Hm + 2 * mh + sh_i) * (2 * a.Wm) + 2 * mw + sh_j) * a.Cd + sh_c
-          : m * a.Cd + col);
-      rd[p] = srx_bload(rd_, okd ? offd : 0xffffffffu, 0);
+      rx[p] = srx_bload(rx_, okx ? 4u * rox[p] : 0xffffffffu, 0);  // out of range reads 0
+      rd[p] = srx_bload(rd_, (valid && cvalid) ? 4u * rod[p] : 0xffffffffu, 0);
+      // advance 32 rows
+      rm[p] += 32; rmw[p] += a.s_c; rmh[p] += a.s_rm; rox[p] += (unsigned)a.dX0; rod[p] += (unsigned)a.dD0;
+      const bool wc = rmw[p] >= a.Wm;
+      rmw[p] -= wc ? a.Wm : 0; rmh[p] += wc ? 1 : 0;
+      rox[p] += wc ? (unsigned)a.dX1 : 0u; rod[p] += wc ? (unsigned)a.dD1 : 0u;
+      const bool wr = rmh[p] >= a.Hm;
+      rmh[p] -= wr ? a.Hm : 0;
+      rox[p] += wr ? (unsigned)a.dX2 : 0u;
     }
   };
   auto swrite = [&](int buf, const f32x4 (&rd)[2], const f32x4 (&rx)[2]) {
@@ -542,17 +563,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
   };
   // every step issues the same four loads (rows past `mend` are pointed out of range and read 0), so
   // the prefetch waits are exact vmcnt counts -- see gconv_body
-  gload(mbeg, rd0, rx0);
-  gload(mbeg + 32, rd1, rx1);
+  gload(rd0, rx0);
+  gload(rd1, rx1);
+  gload(rd2, rx2);
+  gload(rd3, rx3);
   swrite(0, rd0, rx0);
   __syncthreads();
-  for (int mb = mbeg; mb < mend; mb += 64) {
-    gload(mb + 64, rd0, rx0);
+  for (int mb = mbeg; mb < mend; mb += 128) {
+    gload(rd0, rx0);  // chunk at mb + 128
     compute(0);
     swrite(1, rd1, rx1);
     __syncthreads();
-    gload(mb + 96, rd1, rx1);
+    gload(rd1, rx1);
     if (mb + 32 < mend) compute(1);
+    swrite(0, rd2, rx2);
+    __syncthreads();
+    gload(rd2, rx2);
+    if (mb + 64 < mend) compute(0);
+    swrite(1, rd3, rx3);
+    __syncthreads();
+    gload(rd3, rx3);
+    if (mb + 96 < mend) compute(1);
     swrite(0, rd0, rx0);
     __syncthreads();
   }
@@ -1193,6 +1224,20 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
   SRX_REQUIRE(dyb < 0xfffffff0ull, "conv2d_bwd_weight: gradient tensor above 4 GiB; tile the image");
   a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin_s * sizeof(float));
   a.dy_bytes = (unsigned)dyb;
+  {
+    const int s = d->stride, s_r = 32 / a.Wm, s_n = s_r / a.Hm;
+    a.s_c = 32 % a.Wm; a.s_rm = s_r % a.Hm;
+    a.dX0 = ((s_n * a.Hi + a.s_rm * s) * a.Wi + a.s_c * s) * a.Ci;
+    a.dX1 = (s * a.Wi - a.Wm * s) * a.Ci;
+    a.dX2 = (a.Hi - a.Hm * s) * a.Wi * a.Ci;
+    if (a.dy_shuffle) {
+      a.dD0 = ((s_n * 2 * a.Hm + 2 * a.s_rm) * (2 * a.Wm) + 2 * a.s_c) * a.Cd;
+      a.dD1 = 2 * a.Wm * a.Cd;
+    } else {
+      a.dD0 = 32 * a.Cd;
+      a.dD1 = 0;
+    }
+  }
   const int ntiles = a.Cnw / 64;
   static int cus = 0;
   if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
