@@ -48,55 +48,31 @@ def synth_batch(device, rank):
     return lr.to(device), hr.to(device)
 
 
-def conv_flops(d) -> float:
-    ho = (d.H + 2 * d.pad - d.KH) // d.stride + 1
-    wo = (d.W + 2 * d.pad - d.KW) // d.stride + 1
-    return 2.0 * d.N * ho * wo * d.Cout * d.Cin * d.KH * d.KW
-
-
 def roofline_pass(trainer, lr, hr, reps=2):
-    """Instrumented eager pass: every conv launch bracketed by HIP events on its stream."""
-    from torchsr_amd import _lib, functional as F
-    lib = _lib.lib()
+    """Eager pass with the library's launch profiler on: every conv kernel launch is bracketed by two
+    HIP events recorded on its own stream inside libsrx_hip.so (srx_prof_*), around that one kernel."""
+    from torchsr_amd import _lib
     was = trainer.use_graphs
     trainer.use_graphs = False
     trainer.gan_step(lr, hr)  # eager warm-up (repacks, allocator)
     torch.cuda.synchronize()
-    rec = []
-    F._conv_prof[0] = rec
+    _lib.call('srx_prof_start', 4096 * reps)
     try:
         for _ in range(reps):
-            torch.cuda._sleep(int(2.0e8))  # let the host run ahead so events do not time launch gaps
+            torch.cuda._sleep(int(2.0e8))  # let the host run ahead so that launches queue back to back
             trainer.gan_step(lr, hr)
         torch.cuda.synchronize()
     finally:
-        F._conv_prof[0] = None
+        n = _lib.lib().srx_prof_stop()
         trainer.use_graphs = was
     groups = {}
-    plan = (C.c_int * 6)()
-    wave_tile = {(128, 128): (64, 32), (128, 64): (32, 32), (64, 64): (32, 32), (128, 32): (32, 32)}
-    for kind, d, e0, e1 in rec:
-        ms = e0.elapsed_time(e1)
-        thin_out = d.Cout <= 4 and d.Cin == 64 and d.stride == 1 and d.KH in (3, 9) and not d.shuffle
-        thin_in = d.Cin <= 4 and d.Cout == 64 and d.stride == 1 and d.KH in (3, 9) and not d.shuffle
-        if kind == 'wgrad':
-            name = 'thin_wgrad_kernel' if (thin_out or thin_in) else 'wgrad_kernel'
-        elif (kind == 'fwd' and thin_out and d.act == 0) or (kind == 'dgrad' and thin_in):
-            name = f'thin_fwd_kernel<{d.KH}, {d.KW}>'
-        else:
-            lib.srx_conv2d_plan(C.byref(d), 0 if kind == 'fwd' else 1, plan)
-            wm, wn = wave_tile.get((plan[0], plan[1]), (0, 0))
-            if plan[0] == 36:  # row-tile kernel of the residual convs (rowtile.hip); <NB> = patch load batches
-                rows = max(((36 * t) % d.W + 35) // d.W + 3 for t in range(d.W))
-                nb = -(-(rows * (d.W + 2) * 16) // 2048)
-                name = f'rt36_conv3x3_c64_kernel<{nb}>'
-            elif plan[5]:
-                name = f'gconv_multi_kernel<{plan[0]}, {plan[1]}, {wm}, {wn}>'
-            else:
-                name = f'gconv_kernel<{plan[0]}, {plan[1]}, {wm}, {wn}, {plan[4]}>'
-        gsum = groups.setdefault(name, [0.0, 0.0, 0])
-        gsum[0] += ms
-        gsum[1] += conv_flops(d)
+    name = C.create_string_buffer(64)
+    ms, fl = C.c_float(), C.c_double()
+    for i in range(n):
+        _lib.call('srx_prof_get', i, name, 64, C.byref(ms), C.byref(fl))
+        gsum = groups.setdefault(name.value.decode(), [0.0, 0.0, 0])
+        gsum[0] += ms.value
+        gsum[1] += fl.value
         gsum[2] += 1
     total_ms = sum(v[0] for v in groups.values())
     name, (ms, fl, cnt) = max(groups.items(), key=lambda kv: kv[1][0])

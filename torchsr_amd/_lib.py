@@ -55,6 +55,9 @@ _SIGS = {
     'srx_version': (_I, []),
     'srx_last_error': (_I, [C.c_char_p, _Z]),
     'srx_device_cus': (_I, []),
+    'srx_prof_start': (_I, [_I]),
+    'srx_prof_stop': (_I, []),
+    'srx_prof_get': (_I, [_I, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     'srx_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     'srx_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     'srx_conv2d_packed_fwd_floats': (_Z, [_D]),
@@ -109,7 +112,7 @@ _SIGS = {
     'srx_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
 }
 # functions whose int return value is data, not a status
-_UNCHECKED = {'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows'}
+_UNCHECKED = {'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows'}
 
 EXPORTS = tuple(_SIGS.keys())
 

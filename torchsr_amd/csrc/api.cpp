@@ -3,6 +3,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -28,4 +30,70 @@ extern "C" int srx_device_cus(void) {
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
   return cus;
+}
+
+// ---------------------------------------------------------------------------
+// Per-launch timing of the convolution kernels: a pair of HIP events recorded on the launch stream
+// right around the ONE kernel named in the record (not its fix-up / reduce companions).  bench.py's
+// roofline leg reads these; off by default and never on inside a hipGraph capture.
+// ---------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t e0, e1; char name[64]; double flops; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+int g_prof_n = 0;
+bool g_prof_on = false;
+}  // namespace
+
+bool srx_prof_on() { return g_prof_on; }
+
+void srx_prof_begin_launch(const char* name, double flops, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_on || g_prof_n >= (int)g_prof.size()) return;
+  ProfRec& r = g_prof[g_prof_n];
+  strncpy(r.name, name, sizeof(r.name) - 1);
+  r.name[sizeof(r.name) - 1] = 0;
+  r.flops = flops;
+  (void)hipEventRecord(r.e0, st);
+}
+
+void srx_prof_end_launch(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_on || g_prof_n >= (int)g_prof.size()) return;
+  (void)hipEventRecord(g_prof[g_prof_n].e1, st);
+  ++g_prof_n;
+}
+
+extern "C" int srx_prof_start(int max_launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  SRX_REQUIRE(max_launches > 0 && max_launches <= (1 << 20), "prof_start: bad capacity");
+  while ((int)g_prof.size() < max_launches) {
+    ProfRec r{};
+    // device-scope release only: a system-scope fence per event would add microseconds to every bracket
+    if (hipEventCreateWithFlags(&r.e0, hipEventReleaseToDevice) != hipSuccess ||
+        hipEventCreateWithFlags(&r.e1, hipEventReleaseToDevice) != hipSuccess)
+      SRX_FAIL(SRX_E_HIP, "prof_start: hipEventCreate failed");
+    g_prof.push_back(r);
+  }
+  g_prof_n = 0;
+  g_prof_on = true;
+  return SRX_OK;
+}
+
+extern "C" int srx_prof_stop(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = false;
+  return g_prof_n;
+}
+
+extern "C" int srx_prof_get(int i, char* name, size_t n, float* ms, double* flops) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  SRX_REQUIRE(!g_prof_on && i >= 0 && i < g_prof_n && name && n > 0 && ms && flops, "prof_get: bad argument");
+  ProfRec& r = g_prof[i];
+  if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(ms, r.e0, r.e1) != hipSuccess)
+    SRX_FAIL(SRX_E_HIP, "prof_get: event query failed");
+  strncpy(name, r.name, n - 1);
+  name[n - 1] = 0;
+  *flops = r.flops;
+  return SRX_OK;
 }

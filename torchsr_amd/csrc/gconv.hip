@@ -864,7 +864,13 @@ int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(p.full + p.tail * p.split);
+  if (srx_prof_on()) {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "gconv_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, KS);
+    srx_prof_begin_launch(nm, 2.0 * a.M * a.Cn * a.K, st);
+  }
   hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN, KS>), grid, dim3((BM / WM) * (BN / WN) * 64 * KS), lds, st, a);
+  if (srx_prof_on()) srx_prof_end_launch(st);
   SRX_CHECK_LAUNCH("gconv_kernel");
   if (p.split > 1) {
     hipLaunchKernelGGL((tail_fixup_kernel<BM, BN>), dim3(p.tail * (BN / 16)), dim3(256), 0, st, a);
@@ -880,8 +886,16 @@ int launch_gconv_multi(const GMulti& m, size_t lds, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_multi_kernel<BM, BN, WM, WN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
+  if (srx_prof_on()) {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "gconv_multi_kernel<%d, %d, %d, %d>", BM, BN, WM, WN);
+    double fl = 0.0;
+    for (int i = 0; i < m.n; ++i) fl += 2.0 * m.g[i].M * m.g[i].Cn * m.g[i].K;
+    srx_prof_begin_launch(nm, fl, st);
+  }
   hipLaunchKernelGGL((gconv_multi_kernel<BM, BN, WM, WN>), dim3(m.first[m.n]), dim3((BM / WM) * (BN / WN) * 64), lds, st,
                      m);
+  if (srx_prof_on()) srx_prof_end_launch(st);
   SRX_CHECK_LAUNCH("gconv_multi_kernel");
   return SRX_OK;
 }
@@ -1263,7 +1277,9 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
   const size_t need = (size_t)nsplit * a.Cnw * a.Kw;
   if (need > ws_floats) SRX_FAIL(SRX_E_WORKSPACE, "conv2d_bwd_weight: workspace %zu < %zu floats", ws_floats, need);
   dim3 grid((unsigned)tiles, 1, nsplit);
+  if (srx_prof_on()) srx_prof_begin_launch("wgrad_kernel", 2.0 * a.M * d->Cout * a.K, st);
   hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, a);
+  if (srx_prof_on()) srx_prof_end_launch(st);
   SRX_CHECK_LAUNCH("wgrad_kernel");
   const int64_t n = (int64_t)d->Cout * g.K;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, st, ws, nsplit, a.Cnw, a.Kw,

@@ -234,10 +234,14 @@ int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   });
-  if (patch_batches(d->W) == 1)
+  const int nb = patch_batches(d->W);
+  if (srx_prof_on())
+    srx_prof_begin_launch(nb == 1 ? "rt36_conv3x3_c64_kernel<1>" : "rt36_conv3x3_c64_kernel<2>", 2.0 * a.M * 64 * KTOT, st);
+  if (nb == 1)
     hipLaunchKernelGGL(rt36_conv3x3_c64_kernel<1>, dim3((unsigned)(a.M / RT)), dim3(256), lds, st, a);
   else
     hipLaunchKernelGGL(rt36_conv3x3_c64_kernel<2>, dim3((unsigned)(a.M / RT)), dim3(256), lds, st, a);
+  if (srx_prof_on()) srx_prof_end_launch(st);
   SRX_CHECK_LAUNCH("rt36_conv3x3_c64_kernel");
   return SRX_OK;
 }

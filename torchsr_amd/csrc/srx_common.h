@@ -28,6 +28,11 @@ void srx_set_error(const char* fmt, ...);
     if (e__ != hipSuccess) SRX_FAIL(SRX_E_HIP, "%s: %s", name, hipGetErrorString(e__)); \
   } while (0)
 
+// api.cpp: optional per-launch event timing (srx_prof_start / srx_prof_stop / srx_prof_get)
+bool srx_prof_on();
+void srx_prof_begin_launch(const char* name, double flops, hipStream_t st);
+void srx_prof_end_launch(hipStream_t st);
+
 // thin.hip: 3-channel-side convolutions on v_mfma_f32_4x4x1 (internal, called from gconv.hip)
 bool srx_thin_wgrad_applicable(const srx_conv2d_t* d);
 size_t srx_thin_wgrad_ws_floats(const srx_conv2d_t* d);

@@ -9,6 +9,7 @@
 // the 64 lanes of B hold the wide side: 75 % of the pipe does useful work and the thin operand is a
 // 4-address broadcast.  Same 64 FLOP/clk/SIMD rate as the 32x32 MFMA, exact fp32.
 #include "srx_common.h"
+#include <cstdio>
 
 namespace {
 
@@ -269,6 +270,11 @@ int srx_thin_wgrad(const srx_conv2d_t* d, const float* x, const float* dy, float
     SRX_FAIL(SRX_E_WORKSPACE, "conv2d_bwd_weight(thin): workspace too small");
   a.nranges = nranges;
   const unsigned blocks = (unsigned)srx_cdiv((int64_t)nranges * groups, 4);
+  if (srx_prof_on()) {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "thin_wgrad_kernel<%d, %d, %d, %d>", d->KH, d->KW, groups, thin_out ? -1 : 1);
+    srx_prof_begin_launch(nm, 2.0 * d->N * d->H * d->W * d->KH * d->KW * 64 * (thin_out ? d->Cout : d->Cin), st);
+  }
   if (d->KH == 9) {
     if (thin_out) hipLaunchKernelGGL((thin_wgrad_kernel<9, 9, 3, -1>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((thin_wgrad_kernel<9, 9, 3, +1>), dim3(blocks), dim3(256), 0, st, a);
@@ -276,6 +282,7 @@ int srx_thin_wgrad(const srx_conv2d_t* d, const float* x, const float* dy, float
     if (thin_out) hipLaunchKernelGGL((thin_wgrad_kernel<3, 3, 1, -1>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((thin_wgrad_kernel<3, 3, 1, +1>), dim3(blocks), dim3(256), 0, st, a);
   }
+  if (srx_prof_on()) srx_prof_end_launch(st);
   SRX_CHECK_LAUNCH("thin_wgrad_kernel");
   const int taps = d->KH * d->KW;
   const int cthin = thin_out ? d->Cout : d->Cin;
@@ -314,7 +321,13 @@ static int launch_thin_fwd(const ThinF& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
+  if (srx_prof_on()) {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "thin_fwd_kernel<%d, %d>", K, K);
+    srx_prof_begin_launch(nm, 2.0 * a.N * a.H * a.W * K * K * 64 * a.Cout, st);
+  }
   hipLaunchKernelGGL((thin_fwd_kernel<K, K>), dim3((unsigned)(a.N * a.tiles_h * a.tiles_w)), dim3(256), lds, st, a);
+  if (srx_prof_on()) srx_prof_end_launch(st);
   SRX_CHECK_LAUNCH("thin_fwd_kernel");
   return SRX_OK;
 }

@@ -20,23 +20,6 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, Conv2dDesc, call
 import ctypes as C
 
 
-# developer / bench hook: when set to a list, every conv launch is bracketed with events and
-# appended as (kind, desc, start_event, end_event)
-_conv_prof = [None]
-
-
-def _prof_call(kind, d, name, *args):
-    rec = _conv_prof[0]
-    if rec is None:
-        return call(name, *args)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    r = call(name, *args)
-    e1.record()
-    rec.append((kind, d, e0, e1))
-    return r
-
-
 # When enabled (by the trainers, whose parameters' ``.grad`` are persistent views of one flat
 # buffer) parameter gradients are accumulated straight into ``param.grad`` by the kernels and the
 # Functions return ``None`` for them: no per-parameter AccumulateGrad add kernels (~200 per step).
@@ -235,7 +218,7 @@ class _Conv2d(Function):
         nws = L.srx_conv2d_fwd_ws_floats(dref)
         ws = _ws(nws, x) if nws else None
         b = None if bias is None else _chk(bias.detach(), 'conv2d.bias')
-        _prof_call('fwd', d, 'srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(b), _p(y), _p(part), _p(ws), nws, _stream())
+        call('srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(b), _p(y), _p(part), _p(ws), nws, _stream())
         ctx.st, ctx.d = st, d
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)
@@ -263,7 +246,7 @@ class _Conv2d(Function):
             dx = torch.empty_like(x)
             nws = L.srx_conv2d_bwd_data_ws_floats(dref)
             ws = _ws(nws, x) if nws else None
-            _prof_call('dgrad', d, 'srx_conv2d_bwd_data', dref, _p(dy), _p(ctx.wpk_bwd), _p(dx), _p(ws), nws, s)
+            call('srx_conv2d_bwd_data', dref, _p(dy), _p(ctx.wpk_bwd), _p(dx), _p(ws), nws, s)
         wparam, bparam = ctx.params
         if ctx.needs_input_grad[1]:
             sink = _sink(wparam)
@@ -275,13 +258,13 @@ class _Conv2d(Function):
                 side.wait_stream(main)          # dy (and x) are complete on the main stream
                 with torch.cuda.stream(side):
                     ws = _ws(nws, x)
-                    _prof_call('wgrad', d, 'srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(sink), 1, _p(ws), nws,
+                    call('srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(sink), 1, _p(ws), nws,
                                side.cuda_stream)
                 x.record_stream(side)
                 dy.record_stream(side)
             else:
                 ws = _ws(nws, x)
-                _prof_call('wgrad', d, 'srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw if sink is None else sink),
+                call('srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw if sink is None else sink),
                            0 if sink is None else 1, _p(ws), nws, s)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             sink = None if st.shuffle else _sink(bparam)
