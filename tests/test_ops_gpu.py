@@ -128,6 +128,19 @@ def test_conv2d_fwd_bwd(dev, case):
         assert rel_err(conv.bias.grad, bc.grad) < 2e-4
 
 
+@pytest.mark.parametrize('plan', ['144,64,1,1', '144,128,1,1', '144,64,4,1', '144,128,3,1'])
+@pytest.mark.parametrize('case', [(2, 24, 24, 128, 128, 3, 1, 1, False, 0, 0),    # BN statistics, whole 144-row tiles
+                                  (3, 13, 11, 64, 256, 3, 1, 1, True, 2, 0),     # ragged M, bias + LeakyReLU
+                                  (2, 12, 12, 64, 256, 3, 1, 1, True, 0, 2),     # PixelShuffle store
+                                  (2, 16, 16, 128, 128, 3, 2, 1, False, 0, 0)],  # stride 2 forward
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_conv2d_144_row_tiles(dev, case, plan, monkeypatch):
+    """The 128 + 16 row tile (16 extra rows on 16x16x4 MFMAs) forced on several layers, whole and K-split
+    (fix-up kernel); the data gradient of a stride-1 layer takes the same plan."""
+    monkeypatch.setenv('SRX_FORCE_PLAN', plan)
+    test_conv2d_fwd_bwd(dev, case)
+
+
 def test_row_tile_plan(dev):
     """The SRGAN residual conv at the reference batch runs as 256 workgroups of 36 pixels (forward and
     data gradient); a layer the row tile does not cover falls back to the generic plan."""
@@ -141,7 +154,7 @@ def test_row_tile_plan(dev):
     assert _lib.lib().srx_conv2d_fwd_ws_floats(C.byref(d)) == 0
     d2 = _lib.Conv2dDesc(16, 24, 26, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0)
     _lib.call('srx_conv2d_plan', C.byref(d2), 0, out)
-    assert out[0] in (64, 128)
+    assert out[0] in (64, 128, 144)
 
 
 @pytest.mark.parametrize('cfg', [(2, 24, 24, 64, 'prelu', True), (2, 12, 12, 128, 'lrelu', False),

@@ -58,10 +58,15 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--only', type=str, default='')
     ap.add_argument('--graph', action='store_true', help='time the forward as a replayed hipGraph of `reps` calls')
+    ap.add_argument('--shape', action='append', default=[], help='extra 3x3/s1/p1 layer: N,H,W,Cin,Cout (repeatable)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     print(f'{"layer":26s} {"GF":>7s} | {"fwd us":>8s} {"TF/s":>6s} | {"dgrad us":>8s} {"TF/s":>6s} | {"wgrad us":>8s} {"TF/s":>6s}')
-    for name, n, h, w, cin, cout, k, s, p, sh in SHAPES:
+    shapes = list(SHAPES)
+    for spec in args.shape:
+        n, h, w, cin, cout = (int(v) for v in spec.split(','))
+        shapes.append((f'custom {spec}', n, h, w, cin, cout, 3, 1, 1, 0))
+    for name, n, h, w, cin, cout, k, s, p, sh in shapes:
         if args.only and args.only not in name:
             continue
         conv = Conv2d(cin, cout, k, s, p, bias=False, shuffle=sh).to(dev)

@@ -58,8 +58,15 @@ constexpr int INVALID = -20000;  // coordinate that fails every bounds check
 // private pair of LDS staging buffers and covers the whole BM x BN tile); the groups' accumulators are
 // folded through LDS at the end.  Used when a launch has fewer tiles than CUs (e.g. the 16x24x24
 // residual convs: 144 tiles): it halves the serial chunk chain per wave and puts two waves on a SIMD.
-template <int BM, int BN, int WM, int WN, int KS>
+//
+// XR = 16: the tile carries 16 more rows (BM + 16 = 144), multiplied on v_mfma_f32_16x16x4_f32 as BN/16
+// blocks of 16x16 by the first BN/16 waves.  The SRGAN shapes have M = 2304 * 4^j pixels: with 144-row
+// tiles every layer cuts into a power-of-two number of tiles, i.e. whole rounds of the 256 CUs, where
+// 128-row tiles leave 12-25 % of a round idle and need the K-split fix-up pass.
+template <int BM, int BN, int WM, int WN, int KS, int XR>
 __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
+  static_assert(XR == 0 || (XR == 16 && KS == 1), "extra rows: 16, without the in-workgroup K split");
+  constexpr int BMT = BM + XR;  // rows of the tile
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
@@ -68,17 +75,18 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
                                               // SIMD holds two and one's MFMAs cover the other's loads/barriers
   static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
   constexpr int RPP = GT / 8;                 // tile rows staged per pass (8 threads x float4 = one 128-byte row)
-  constexpr int RA = BM / RPP, RB = BN / RPP;
+  constexpr int RA = (BMT + RPP - 1) / RPP, RB = BN / RPP;  // the last A pass may be partly past the tile
   static_assert(RA >= 1 && RB >= 1, "tile too small for the thread count");
+  static_assert(XR == 0 || BN / 16 <= GT / 64, "one extra 16x16 block per wave at most");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // wave-uniform quantities are forced into SGPRs (readfirstlane): loop control then compiles to
   // scalar branches instead of exec-mask juggling around the MFMA blocks
   const int ks = KS == 1 ? 0 : srx_uniform(threadIdx.x / GT);  // k-group of this wave (groups are contiguous)
   const int tid = threadIdx.x - ks * GT, lane = tid & 63, wave = srx_uniform(tid >> 6);
-  float* sA = reinterpret_cast<float*>(smem) + ks * 2 * (BM + BN) * BK;
-  float* sB = sA + 2 * BM * BK;
-  int2* ktab = reinterpret_cast<int2*>(reinterpret_cast<float*>(smem) + KS * 2 * (BM + BN) * BK);
+  float* sA = reinterpret_cast<float*>(smem) + ks * 2 * (BMT + BN) * BK;
+  float* sB = sA + 2 * BMT * BK;
+  int2* ktab = reinterpret_cast<int2*>(reinterpret_cast<float*>(smem) + KS * 2 * (BMT + BN) * BK);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int tile = bid, kc_beg = 0, kc_end = a.kchunks;
   bool raw = false;
@@ -90,12 +98,12 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       kc_beg = (t % a.tail_split) * a.kc_per_split;
       kc_end = min(a.kchunks, kc_beg + a.kc_per_split);
       raw = true;
-      slab = a.ws + (size_t)t * (BM * BN);
+      slab = a.ws + (size_t)t * (BMT * BN);
     }
   }
   tile = srx_uniform(tile); kc_beg = srx_uniform(kc_beg); kc_end = srx_uniform(kc_end);
   const int nt = srx_uniform(tile / a.mtiles), mt = tile - nt * a.mtiles;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = mt * BMT, n0 = nt * BN;
   const int q = tid & 7, r0 = tid >> 3;
   const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes), rw = srx_rsrc(a.w, a.w_bytes);
 
@@ -129,7 +137,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
 #pragma unroll
   for (int p = 0; p < RA; ++p) {
     const int m = m0 + r0 + RPP * p;
-    if (m < a.M) {
+    if (m < a.M && r0 + RPP * p < BMT) {
       int n, rem, mh, mw;
       srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
       srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
@@ -178,10 +186,12 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   };
   const int wchunk = (q ^ ((r0 >> 1) & 7)) * 4;
   auto swrite = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) {
-    float* dA = sA + buf * BM * BK;
+    float* dA = sA + buf * BMT * BK;
     float* dB = sB + buf * BN * BK;
 #pragma unroll
-    for (int p = 0; p < RA; ++p) *reinterpret_cast<f32x4*>(dA + (r0 + RPP * p) * BK + wchunk) = ra[p];
+    for (int p = 0; p < RA; ++p)
+      if (RPP * (p + 1) <= BMT || r0 + RPP * p < BMT)  // (compile-time true except in a partial last pass)
+        *reinterpret_cast<f32x4*>(dA + (r0 + RPP * p) * BK + wchunk) = ra[p];
 #pragma unroll
     for (int p = 0; p < RB; ++p) *reinterpret_cast<f32x4*>(dB + (r0 + RPP * p) * BK + wchunk) = rb[p];
   };
@@ -189,9 +199,26 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   const int h = lane >> 5, l31 = lane & 31;
   const int xr = (l31 >> 1) & 7;
   const int arow = (wm * WM + l31) * BK, brow = (wn * WN + l31) * BK;
+  // extra 16 rows: wave w < BN/16 owns the 16x16 block of columns 16w..16w+15
+  //   v_mfma_f32_16x16x4_f32: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D: col = l&15, row = 4(l>>4) + reg
+  const bool has_x = XR > 0 && wave < BN / 16;
+  const int xi = lane & 15, xg = lane >> 4;
+  const int xra = BM + xi, xrb = 16 * wave + xi;  // LDS rows of this lane's A / B fragments
+  f32x4 accx = {0.f, 0.f, 0.f, 0.f};
   auto compute = [&](int buf) {
-    const float* cA = sA + buf * BM * BK + arow;
+    const float* cA = sA + buf * BMT * BK + arow;
     const float* cB = sB + buf * BN * BK + brow;
+    if (XR > 0 && has_x) {  // each b128 holds k = 4Q..4Q+3 of one row; MFMA e of read u contracts k = {4(g + 4u) + e}
+      const float* xA = sA + buf * BMT * BK + xra * BK;
+      const float* xB = sB + buf * BN * BK + xrb * BK;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 fa = *reinterpret_cast<const f32x4*>(xA + (((xg + 4 * u) ^ ((xra >> 1) & 7)) * 4));
+        const f32x4 fb = *reinterpret_cast<const f32x4*>(xB + (((xg + 4 * u) ^ ((xrb >> 1) & 7)) * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accx = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[e], accx, 0, 0, 0);
+      }
+    }
     // fragments of step s+1 are read while the MFMAs of step s run (two register sets)
     f32x4 af[2][TM], bf[2][TN];
     auto frag = [&](int s, int set) {
@@ -279,6 +306,10 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
           const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           slab[row * BN + wn * WN + j * 32 + l31] = acc[i][j][r];
         }
+    if (XR > 0 && has_x) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(BM + 4 * xg + r) * BN + 16 * wave + xi] = accx[r];
+    }
     return;
   }
   // Straight-line epilogue: the activation is a select on a host-prepared slope (none 1, ReLU 0), rows
@@ -345,9 +376,45 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   if (a.linear_out) store_tile(std::true_type{});
   else store_tile(std::false_type{});
 
+  float xs1 = 0.f, xs2 = 0.f;
+  if (XR > 0 && has_x) {  // the extra 16x16 block: rows BM + 4(l>>4) + reg, column 16 wave + (l&15)
+    const int col = n0 + 16 * wave + xi;
+    int bidx = col, oc = col;
+    if (a.out_shuffle) {
+      const int ij = col / a.out_shuffle, cc = col - ij * a.out_shuffle;
+      bidx = cc * 4 + ij;
+      oc = (((ij >> 1) * a.Wo) + (ij & 1)) * a.Co + cc;
+    }
+    const float xb = (a.bias && col < a.Cn) ? a.bias[bidx] : 0.f;
+    const bool xok = col < a.Cs;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + BM + 4 * xg + r;
+      const bool mok = m < a.M;
+      const unsigned rowoff = a.linear_out ? 4u * (unsigned)((m - m0) * a.Co)
+                                           : 4u * (unsigned)(out_elem(mok ? m : m0) - tile_base);
+      float v = accx[r] + xb;
+      const float vs = mok ? v : 0.f;
+      xs1 += vs;
+      xs2 += vs * vs;
+      v = v > 0.f ? v : v * a.slope;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout,
+                                            (mok && xok) ? rowoff + 4u * (unsigned)oc : 0xffffffffu, 0, 0);
+    }
+  }
+
   if (a.part) {  // per-channel sum / sum of squares of this row block (training-mode BatchNorm)
+    constexpr int RED_ROWS = WAVES_M + (XR > 0 ? 1 : 0);
     __syncthreads();  // everyone is done with the staging buffers
-    float* red = reinterpret_cast<float*>(smem);  // [WAVES_M][BN][2]
+    float* red = reinterpret_cast<float*>(smem);  // [RED_ROWS][BN][2]
+    if (XR > 0 && has_x) {
+      xs1 += __shfl_xor(xs1, 16, 64); xs1 += __shfl_xor(xs1, 32, 64);
+      xs2 += __shfl_xor(xs2, 16, 64); xs2 += __shfl_xor(xs2, 32, 64);
+      if (xg == 0) {
+        red[(WAVES_M * BN + 16 * wave + xi) * 2 + 0] = xs1;
+        red[(WAVES_M * BN + 16 * wave + xi) * 2 + 1] = xs2;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       float s = csum[j] + __shfl_xor(csum[j], 32, 64);
@@ -362,7 +429,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
     if (lead && tid < BN) {
       float s = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < WAVES_M; ++w) { s += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
+      for (int w = 0; w < RED_ROWS; ++w) { s += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
       const int col = n0 + tid;
       if (col < a.Cn) {
         a.part[((size_t)mt * a.Cn + col) * 2 + 0] = s;
@@ -372,9 +439,9 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int KS>
+template <int BM, int BN, int WM, int WN, int KS, int XR>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KS) void gconv_kernel(const GArgs a) {
-  gconv_body<BM, BN, WM, WN, KS>(a, blockIdx.x);
+  gconv_body<BM, BN, WM, WN, KS, XR>(a, blockIdx.x);
 }
 
 // several independent gather-GEMMs in one launch: the stride-parity classes of a strided data
@@ -389,7 +456,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_multi_kernel
   int ci = 0;
   while (ci + 1 < m.n && (int)blockIdx.x >= m.first[ci + 1]) ++ci;
   const GArgs a = m.g[ci];
-  gconv_body<BM, BN, WM, WN, 1>(a, blockIdx.x - m.first[ci]);
+  gconv_body<BM, BN, WM, WN, 1, 0>(a, blockIdx.x - m.first[ci]);
 }
 
 // finishes the K-split tail tiles: out = act(sum_z partial[z] + bias) and, when asked, the tile's
@@ -801,11 +868,12 @@ int device_cus() {
 
 Plan make_plan(int M, int Cnp, int kchunks, bool can_split) {
   const int P = device_cus();
-  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
-  const float eff[4] = {0.95f, 0.85f, 0.60f, 0.50f};  // measured MFMA efficiency of each tile in steady state
+  constexpr int NC = 6;
+  const int cand[NC][2] = {{144, 128}, {144, 64}, {128, 128}, {128, 64}, {64, 64}, {128, 32}};
+  const float eff[NC] = {0.91f, 0.82f, 0.95f, 0.85f, 0.60f, 0.50f};  // measured MFMA efficiency of each tile in steady state
   Plan best{};
   best.cost = 1e30f;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int bm = cand[i][0], bn = cand[i][1];
     if (Cnp == 32) { if (bn != 32) continue; }
     else if (bn == 32 || Cnp % bn != 0) continue;
@@ -853,27 +921,27 @@ Plan make_plan(int M, int Cnp, int kchunks, bool can_split) {
 
 size_t plan_ws_floats(const Plan& p) { return p.split > 1 ? (size_t)p.tail * p.split * p.BM * p.BN : 0; }
 
-template <int BM, int BN, int WM, int WN, int KS>
+template <int BM, int BN, int WM, int WN, int KS, int XR>
 int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
   const int ktab_chunks = p.full > 0 || p.split == 1 ? a.kchunks : p.kc_per_split;
-  const size_t lds = (size_t)(KS * 2 * (BM + BN) * BK) * sizeof(float) + (size_t)ktab_chunks * 8 * sizeof(int2);
+  const size_t lds = (size_t)(KS * 2 * (BM + XR + BN) * BK) * sizeof(float) + (size_t)ktab_chunks * 8 * sizeof(int2);
   if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN, KS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN, KS, XR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(p.full + p.tail * p.split);
   if (srx_prof_on()) {
     char nm[64];
-    snprintf(nm, sizeof(nm), "gconv_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, KS);
+    snprintf(nm, sizeof(nm), "gconv_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, KS, XR);
     srx_prof_begin_launch(nm, 2.0 * a.M * a.Cn * a.K, st);
   }
-  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN, KS>), grid, dim3((BM / WM) * (BN / WN) * 64 * KS), lds, st, a);
+  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN, KS, XR>), grid, dim3((BM / WM) * (BN / WN) * 64 * KS), lds, st, a);
   if (srx_prof_on()) srx_prof_end_launch(st);
   SRX_CHECK_LAUNCH("gconv_kernel");
   if (p.split > 1) {
-    hipLaunchKernelGGL((tail_fixup_kernel<BM, BN>), dim3(p.tail * (BN / 16)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((tail_fixup_kernel<BM + XR, BN>), dim3(p.tail * (BN / 16)), dim3(256), 0, st, a);
     SRX_CHECK_LAUNCH("tail_fixup_kernel");
   }
   return SRX_OK;
@@ -973,11 +1041,13 @@ int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t 
   a.full_tiles = p.full;
   a.tail_split = p.split;
   a.ws = ws;
-  if (p.BM == 128 && p.BN == 128) return launch_gconv<128, 128, 64, 32, 1>(a, p, st);
-  if (p.BM == 128 && p.BN == 64) return launch_gconv<128, 64, 32, 32, 1>(a, p, st);
+  if (p.BM == 144 && p.BN == 128) return launch_gconv<128, 128, 64, 32, 1, 16>(a, p, st);
+  if (p.BM == 144 && p.BN == 64) return launch_gconv<128, 64, 32, 32, 1, 16>(a, p, st);
+  if (p.BM == 128 && p.BN == 128) return launch_gconv<128, 128, 64, 32, 1, 0>(a, p, st);
+  if (p.BM == 128 && p.BN == 64) return launch_gconv<128, 64, 32, 32, 1, 0>(a, p, st);
   if (p.BM == 64 && p.BN == 64)
-    return p.ks == 2 ? launch_gconv<64, 64, 32, 32, 2>(a, p, st) : launch_gconv<64, 64, 32, 32, 1>(a, p, st);
-  return launch_gconv<128, 32, 32, 32, 1>(a, p, st);
+    return p.ks == 2 ? launch_gconv<64, 64, 32, 32, 2, 0>(a, p, st) : launch_gconv<64, 64, 32, 32, 1, 0>(a, p, st);
+  return launch_gconv<128, 32, 32, 32, 1, 0>(a, p, st);
 }
 
 void set_mgrid(GArgs& a, int N, int Hm, int Wm) {
