@@ -84,9 +84,10 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   // scalar branches instead of exec-mask juggling around the MFMA blocks
   const int ks = KS == 1 ? 0 : srx_uniform(threadIdx.x / GT);  // k-group of this wave (groups are contiguous)
   const int tid = threadIdx.x - ks * GT, lane = tid & 63, wave = srx_uniform(tid >> 6);
-  float* sA = reinterpret_cast<float*>(smem) + ks * 2 * (BMT + BN) * BK;
-  float* sB = sA + 2 * BMT * BK;
-  int2* ktab = reinterpret_cast<int2*>(reinterpret_cast<float*>(smem) + KS * 2 * (BMT + BN) * BK);
+  constexpr int RING = 3;  // LDS chunk buffers per k-group
+  float* sA = reinterpret_cast<float*>(smem) + ks * RING * (BMT + BN) * BK;
+  float* sB = sA + RING * BMT * BK;
+  int2* ktab = reinterpret_cast<int2*>(reinterpret_cast<float*>(smem) + KS * RING * (BMT + BN) * BK);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int tile = bid, kc_beg = 0, kc_end = a.kchunks;
   bool raw = false;
@@ -166,7 +167,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   // Two register stages: while chunk k is multiplied out of LDS, chunk k+1 waits in registers and
   // the loads of chunk k+2 are in flight.  With one workgroup per CU (most launches here have fewer
   // tiles than 2 x CUs) a single stage leaves ~0.5 us of L2/HBM latency exposed per chunk.
-  f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
+  f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB], ra2[RA], rb2[RB];
   // Every step issues the same RA + RB loads -- past the end of the k range they are pointed out of
   // range and cost nothing -- so that the compiler can count outstanding loads exactly (s_waitcnt
   // vmcnt(N) for the older register stage only) instead of draining both stages at every step.
@@ -205,43 +206,66 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   const int xi = lane & 15, xg = lane >> 4;
   const int xra = BM + xi, xrb = 16 * wave + xi;  // LDS rows of this lane's A / B fragments
   f32x4 accx = {0.f, 0.f, 0.f, 0.f};
-  auto compute = [&](int buf) {
-    const float* cA = sA + buf * BMT * BK + arow;
-    const float* cB = sB + buf * BN * BK + brow;
-    if (XR > 0 && has_x) {  // each b128 holds k = 4Q..4Q+3 of one row; MFMA e of read u contracts k = {4(g + 4u) + e}
-      const float* xA = sA + buf * BMT * BK + xra * BK;
-      const float* xB = sB + buf * BN * BK + xrb * BK;
+  // ---- the pipelined k loop -----------------------------------------------------------------
+  // LDS holds a ring of three chunk buffers.  In step k a wave
+  //   1. writes chunk k+1 (in registers since the previous step) into ring slot (k+1) % 3,
+  //   2. requests chunk k+3 from global memory into the register stage that just became free (three
+  //      stages: a load has two full steps to arrive before it is written to LDS),
+  //   3. multiplies chunk k out of slot k % 3, with the step's ONE barrier in the middle.
+  // Chunk k+1 is therefore complete in LDS half a step before anyone needs it: the barrier has slack
+  // for skew between waves instead of standing between the last MFMA of a chunk and the first LDS
+  // read of the next, and that first read (fragment 0 of chunk k+1) is issued under the last MFMAs of
+  // chunk k.  Slot (k+1) % 3 was last read in step k-2; the barrier of step k-1 separates the two.
+  // (With two slots the write had to wait for the end of the step and every chunk boundary cost the
+  // matrix pipe a barrier + a write + a read latency: 28 % idle with one workgroup per CU.)
+  f32x4 af[2][TM], bf[2][TN];  // fragment register sets: step s+1 is read while step s is multiplied
+  auto frag = [&](int slot, int s, int set) {
+    const float* cA = sA + slot * BMT * BK + arow;
+    const float* cB = sB + slot * BN * BK + brow;
+    const int ch = ((2 * s + h) ^ xr) * 4;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const f32x4 fa = *reinterpret_cast<const f32x4*>(xA + (((xg + 4 * u) ^ ((xra >> 1) & 7)) * 4));
-        const f32x4 fb = *reinterpret_cast<const f32x4*>(xB + (((xg + 4 * u) ^ ((xrb >> 1) & 7)) * 4));
+    for (int i = 0; i < TM; ++i) af[set][i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * BK + ch);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) accx = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[e], accx, 0, 0, 0);
-      }
+    for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * BK + ch);
+  };
+  auto mma = [&](int set) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][i][e], bf[set][j][e], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto extra = [&](int slot) {  // each b128 holds k = 4Q..4Q+3 of one row; MFMA e of read u contracts k = {4(g + 4u) + e}
+    const float* xA = sA + slot * BMT * BK + xra * BK;
+    const float* xB = sB + slot * BN * BK + xrb * BK;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(xA + (((xg + 4 * u) ^ ((xra >> 1) & 7)) * 4));
+      const f32x4 fb = *reinterpret_cast<const f32x4*>(xB + (((xg + 4 * u) ^ ((xrb >> 1) & 7)) * 4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) accx = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[e], accx, 0, 0, 0);
     }
-    // fragments of step s+1 are read while the MFMAs of step s run (two register sets)
-    f32x4 af[2][TM], bf[2][TN];
-    auto frag = [&](int s, int set) {
-      const int ch = ((2 * s + h) ^ xr) * 4;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[set][i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * BK + ch);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * BK + ch);
-    };
-    frag(0, 0);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s + 1 < 4) frag(s + 1, (s + 1) & 1);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i][e], bf[s & 1][j][e], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
+  };
+  // one step; `slot` = ring slot of chunk kc, fragment 0 of which already sits in register set 0
+  auto step = [&](int kc, int slot, f32x4 (&ra_next)[RA], f32x4 (&rb_next)[RB], f32x4 (&ra_free)[RA], f32x4 (&rb_free)[RB]) {
+    const int nslot = slot == 2 ? 0 : slot + 1;
+    swrite(nslot, ra_next, rb_next);          // chunk kc + KS (zeros past the end of the range: never multiplied)
+    gload(kc + 3 * KS, ra_free, rb_free);
+    const bool live = kc < kc_end;            // wave-uniform
+    frag(slot, 1, 1);
+    if (live) mma(0);
+    frag(slot, 2, 0);
+    if (live) mma(1);
+    __syncthreads();
+    frag(slot, 3, 1);
+    if (live) mma(0);
+    frag(nslot, 0, 0);
+    if (XR > 0 && has_x && live) extra(slot);
+    if (live) mma(1);
   };
 
   // this group's chunks: kc_beg + ks, + KS, ...; every group runs the same number of steps (barriers)
@@ -249,23 +273,20 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   const int nsteps = (kc_end - kc_beg + KS - 1) / KS;
   gload(c0, ra0, rb0);
   gload(c0 + KS, ra1, rb1);
+  gload(c0 + 2 * KS, ra2, rb2);
   swrite(0, ra0, rb0);
   __syncthreads();
-
-  for (int j = 0; j < nsteps; j += 2) {
+  frag(0, 0, 0);
+  // three steps per trip (ring slots and register stages rotate statically); all three run even past
+  // the end of the range: an early exit would make the loop's load count path-dependent and cost the
+  // exact vmcnt waits
+  for (int j = 0; j < nsteps; j += 3) {
     const int kc = c0 + j * KS;
-    // even step: chunk kc sits in LDS buffer 0, chunk kc+KS in register stage 1
-    gload(kc + 2 * KS, ra0, rb0);
-    if (kc < kc_end) compute(0);
-    swrite(1, ra1, rb1);  // (zeros past the end of the range: never multiplied)
-    __syncthreads();
-    // odd step (runs even when nsteps is odd: an early exit here would make the loop's load count
-    // path-dependent and cost the exact vmcnt waits): chunk kc+KS in LDS buffer 1, chunk kc+2KS in register stage 0
-    gload(kc + 3 * KS, ra1, rb1);
-    if (kc + KS < kc_end) compute(1);
-    swrite(0, ra0, rb0);
-    __syncthreads();
+    step(kc, 0, ra1, rb1, ra0, rb0);
+    step(kc + KS, 1, ra2, rb2, ra1, rb1);
+    step(kc + 2 * KS, 2, ra0, rb0, ra2, rb2);
   }
+  __syncthreads();  // the ring is reused below (fold / statistics)
 
   if (KS > 1) {  // fold the k-groups' accumulators into group 0 (staging buffers are free now)
     float* fold = reinterpret_cast<float*>(smem);
@@ -924,7 +945,7 @@ size_t plan_ws_floats(const Plan& p) { return p.split > 1 ? (size_t)p.tail * p.s
 template <int BM, int BN, int WM, int WN, int KS, int XR>
 int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
   const int ktab_chunks = p.full > 0 || p.split == 1 ? a.kchunks : p.kc_per_split;
-  const size_t lds = (size_t)(KS * 2 * (BM + XR + BN) * BK) * sizeof(float) + (size_t)ktab_chunks * 8 * sizeof(int2);
+  const size_t lds = (size_t)(KS * 3 * (BM + XR + BN) * BK) * sizeof(float) + (size_t)ktab_chunks * 8 * sizeof(int2);
   if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
   static std::once_flag once;
   std::call_once(once, [] {
@@ -1022,7 +1043,7 @@ int run_gconv_multi(GMulti& m, int BM, int BN, hipStream_t st) {
     m.first[i + 1] = m.first[i] + tiles;
     if (a.kchunks > maxk) maxk = a.kchunks;
   }
-  const size_t lds = (size_t)(2 * (BM + BN) * BK) * sizeof(float) + (size_t)maxk * 8 * sizeof(int2);
+  const size_t lds = (size_t)(3 * (BM + BN) * BK) * sizeof(float) + (size_t)maxk * 8 * sizeof(int2);
   if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
   if (BM == 128 && BN == 128) return launch_gconv_multi<128, 128, 64, 32>(m, lds, st);
   if (BM == 128 && BN == 64) return launch_gconv_multi<128, 64, 32, 32>(m, lds, st);
