@@ -472,12 +472,12 @@ struct GMulti {
   int first[5];  // first[i] = first workgroup of problem i; first[n] = grid size
   GArgs g[4];
 };
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int XR>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_multi_kernel(const GMulti m) {
   int ci = 0;
   while (ci + 1 < m.n && (int)blockIdx.x >= m.first[ci + 1]) ++ci;
   const GArgs a = m.g[ci];
-  gconv_body<BM, BN, WM, WN, 1, 0>(a, blockIdx.x - m.first[ci]);
+  gconv_body<BM, BN, WM, WN, 1, XR>(a, blockIdx.x - m.first[ci]);
 }
 
 // finishes the K-split tail tiles: out = act(sum_z partial[z] + bias) and, when asked, the tile's
@@ -968,21 +968,21 @@ int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
   return SRX_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int XR>
 int launch_gconv_multi(const GMulti& m, size_t lds, hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_multi_kernel<BM, BN, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_multi_kernel<BM, BN, WM, WN, XR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   if (srx_prof_on()) {
     char nm[64];
-    snprintf(nm, sizeof(nm), "gconv_multi_kernel<%d, %d, %d, %d>", BM, BN, WM, WN);
+    snprintf(nm, sizeof(nm), "gconv_multi_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, XR);
     double fl = 0.0;
     for (int i = 0; i < m.n; ++i) fl += 2.0 * m.g[i].M * m.g[i].Cn * m.g[i].K;
     srx_prof_begin_launch(nm, fl, st);
   }
-  hipLaunchKernelGGL((gconv_multi_kernel<BM, BN, WM, WN>), dim3(m.first[m.n]), dim3((BM / WM) * (BN / WN) * 64), lds, st,
+  hipLaunchKernelGGL((gconv_multi_kernel<BM, BN, WM, WN, XR>), dim3(m.first[m.n]), dim3((BM / WM) * (BN / WN) * 64), lds, st,
                      m);
   if (srx_prof_on()) srx_prof_end_launch(st);
   SRX_CHECK_LAUNCH("gconv_multi_kernel");
@@ -995,12 +995,13 @@ int launch_gconv_multi(const GMulti& m, size_t lds, hipStream_t st) {
 // run_gconv_multi launches them in) over the CUs and the shortest makespan wins.
 void multi_tile(const GMulti& m, int Cnp, int& BM, int& BN) {
   const int P = device_cus();
-  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
-  const float eff[4] = {0.95f, 0.85f, 0.60f, 0.50f};
+  constexpr int NC = 6;
+  const int cand[NC][2] = {{144, 128}, {144, 64}, {128, 128}, {128, 64}, {64, 64}, {128, 32}};
+  const float eff[NC] = {0.91f, 0.82f, 0.95f, 0.85f, 0.60f, 0.50f};
   float best = 1e30f;
   BM = 128; BN = Cnp == 32 ? 32 : 64;
   std::vector<float> heap;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int bm = cand[i][0], bn = cand[i][1];
     if (Cnp == 32) { if (bn != 32) continue; }
     else if (bn == 32 || Cnp % bn != 0) continue;
@@ -1045,10 +1046,12 @@ int run_gconv_multi(GMulti& m, int BM, int BN, hipStream_t st) {
   }
   const size_t lds = (size_t)(3 * (BM + BN) * BK) * sizeof(float) + (size_t)maxk * 8 * sizeof(int2);
   if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
-  if (BM == 128 && BN == 128) return launch_gconv_multi<128, 128, 64, 32>(m, lds, st);
-  if (BM == 128 && BN == 64) return launch_gconv_multi<128, 64, 32, 32>(m, lds, st);
-  if (BM == 64 && BN == 64) return launch_gconv_multi<64, 64, 32, 32>(m, lds, st);
-  return launch_gconv_multi<128, 32, 32, 32>(m, lds, st);
+  if (BM == 144 && BN == 128) return launch_gconv_multi<128, 128, 64, 32, 16>(m, lds, st);
+  if (BM == 144 && BN == 64) return launch_gconv_multi<128, 64, 32, 32, 16>(m, lds, st);
+  if (BM == 128 && BN == 128) return launch_gconv_multi<128, 128, 64, 32, 0>(m, lds, st);
+  if (BM == 128 && BN == 64) return launch_gconv_multi<128, 64, 32, 32, 0>(m, lds, st);
+  if (BM == 64 && BN == 64) return launch_gconv_multi<64, 64, 32, 32, 0>(m, lds, st);
+  return launch_gconv_multi<128, 32, 32, 32, 0>(m, lds, st);
 }
 
 int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t st) {
