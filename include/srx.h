@@ -103,7 +103,7 @@ int srx_conv2d_stat_rows(const srx_conv2d_t* d);
 /* launch plan the library will use (for profiling / the bench's roofline bookkeeping):
  * which = 0 forward, 1 data gradient; out[6] = {tile rows BM, tile cols BN, tail split-K factor, workgroups,
  * KS (wave groups splitting K inside a workgroup), multi (1: stride-parity classes in one launch)}.
- * The kernel launched is `gconv_kernel<BM, BN, WM, WN, KS>` or `gconv_multi_kernel<BM, BN, WM, WN>`. */
+ * BM = 144 is the 128 + 16 row tile, BM = 36 the row-tile kernel of rowtile.hip. */
 int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out);
 
 /* OIHW master weights -> packed forward ([Cout_p][K_p], K=(kh,kw,ci)) and, when
@@ -116,9 +116,12 @@ int srx_conv2d_pack(const srx_conv2d_t* d, const float* w_oihw, float* wpk_fwd, 
  * follows (srgan/residual.py:65,68; srgan/discriminator.py:36-60). */
 int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float* wpk_fwd, const float* bias,
                    float* y, float* bn_partials, float* ws, size_t ws_floats, void* stream);
-/* dx = conv_transpose(dy, W)  (autograd of nn.Conv2d wrt its input) */
+/* dx = conv_transpose(dy, W)  (autograd of nn.Conv2d wrt its input).  accumulate != 0 adds into dx
+ * (stride-1 layers on the generic kernel): the dense block's convs share one 192-channel input buffer
+ * (channel stride Cin_s, the first Cin channels are this layer's input), so their input gradients sum in
+ * place of the torch.cat adjoint (esrgan/residual.py:81-85). */
 int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
-                        float* ws, size_t ws_floats, void* stream);
+                        int accumulate, float* ws, size_t ws_floats, void* stream);
 /* dw (OIHW) = autograd of nn.Conv2d wrt its weight; accumulate != 0 adds into dw (a .grad buffer)
  * instead of overwriting it.  The same flag exists on srx_colsum, srx_linear_bwd_weight,
  * srx_prelu_bwd; srx_bn_act_bwd_reduce takes optional accumulation targets. */
@@ -132,6 +135,11 @@ int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, int accumul
                void* stream);
 /* dx = dy * act'(y) for sign-recoverable activations fused into a conv epilogue (ReLU, LeakyReLU) */
 int srx_act_bwd_from_out(const float* dy, const float* y, float* dx, int64_t n, int act, float slope, void* stream);
+/* the same on a channel slice of wider NHWC tensors (rows M, channels [0, C), row strides ldy / ly / ldx in
+ * floats; dx may alias dy): the LeakyReLU of the dense block's conv1..4, whose outputs and gradients live
+ * in shared 192-channel buffers instead of torch.cat copies (esrgan/residual.py:81-85) */
+int srx_act_bwd_from_out_strided(const float* dy, int ldy, const float* y, int ly, float* dx, int ldx, int64_t M, int C,
+                                 int act, float slope, void* stream);
 /* nn.PReLU (one shared slope): srgan/generator.py:39, srgan/residual.py:29,66 */
 int srx_prelu_fwd(const float* x, const float* slope, float* y, int64_t n, void* stream);
 /* dx and d(slope); ws >= 1024 floats */

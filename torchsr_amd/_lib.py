@@ -69,11 +69,12 @@ _SIGS = {
     'srx_conv2d_plan': (_I, [_D, _I, C.POINTER(C.c_int)]),
     'srx_conv2d_pack': (_I, [_D, _P, _P, _P, _P]),
     'srx_conv2d_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
-    'srx_conv2d_bwd_data': (_I, [_D, _P, _P, _P, _P, _Z, _P]),
+    'srx_conv2d_bwd_data': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
     'srx_conv2d_bwd_weight': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
     'srx_colsum_ws_floats': (_Z, [_L, _I]),
     'srx_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     'srx_act_bwd_from_out': (_I, [_P, _P, _P, _L, _I, _F, _P]),
+    'srx_act_bwd_from_out_strided': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _I, _F, _P]),
     'srx_prelu_fwd': (_I, [_P, _P, _P, _L, _P]),
     'srx_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _I, _L, _P, _P]),
     'srx_lrelu_fwd': (_I, [_P, _P, _L, _F, _P]),

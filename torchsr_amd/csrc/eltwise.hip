@@ -63,6 +63,24 @@ __global__ void act_bwd_from_out_kernel(const float* __restrict__ dy, const floa
   }
 }
 
+// the same on a channel slice of wider NHWC tensors: row m, channels [0, C) at strides ldy / ly / ldx
+__global__ void act_bwd_from_out_strided_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ y, int ly,
+                                                float* __restrict__ dx, int ldx, int64_t M, int C, int act,
+                                                float slope) {
+  const int cq = C / 4;
+  const int64_t total = M * cq;
+  GRID_STRIDE(i, total) {
+    const int64_t m = i / cq;
+    const int q = (int)(i - m * cq);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + m * ldy + q * 4);
+    const f32x4 o = *reinterpret_cast<const f32x4*>(y + m * ly + q * 4);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = o[e] > 0.f ? g[e] : (act == SRX_ACT_RELU ? 0.f : g[e] * slope);
+    *reinterpret_cast<f32x4*>(dx + m * ldx + q * 4) = r;
+  }
+}
+
 __global__ void leaky_fwd_kernel(const float* __restrict__ x, const float* __restrict__ slope_ptr, float slope,
                                  float* __restrict__ y, int64_t n) {
   if (slope_ptr) slope = slope_ptr[0];
@@ -391,6 +409,18 @@ extern "C" int srx_act_bwd_from_out(const float* dy, const float* y, float* dx, 
   hipLaunchKernelGGL(act_bwd_from_out_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, srx_stream(stream), dy, y, dx, n,
                      act, slope);
   SRX_CHECK_LAUNCH("act_bwd_from_out_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_act_bwd_from_out_strided(const float* dy, int ldy, const float* y, int ly, float* dx, int ldx,
+                                            int64_t M, int C, int act, float slope, void* stream) {
+  SRX_REQUIRE(dy && y && dx && M > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0 && ly % 4 == 0 && ldx % 4 == 0 &&
+                  ldy >= C && ly >= C && ldx >= C,
+              "act_bwd_from_out_strided: bad argument");
+  SRX_REQUIRE(act == SRX_ACT_RELU || act == SRX_ACT_LRELU, "act_bwd_from_out_strided: act must be RELU or LRELU");
+  hipLaunchKernelGGL(act_bwd_from_out_strided_kernel, dim3(stream_grid(M * (C / 4))), dim3(256), 0, srx_stream(stream),
+                     dy, ldy, y, ly, dx, ldx, M, C, act, slope);
+  SRX_CHECK_LAUNCH("act_bwd_from_out_strided_kernel");
   return SRX_OK;
 }
 

@@ -45,6 +45,7 @@ struct GArgs {
   // sizes of the `in` and `w` buffers: both are read through raw buffer descriptors, whose range
   // check returns 0 for the padding taps (no branch, no select, statically countable loads)
   unsigned in_bytes, w_bytes;
+  int accum;  // epilogue adds to what `out` already holds (data gradients summed into a shared dense-block buffer)
 };
 
 
@@ -372,7 +373,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
 
-  auto store_tile = [&](auto linear) {  // one copy per output addressing mode, chosen by ONE branch
+  auto store_tile = [&](auto linear, auto accum) {  // one copy per addressing / accumulate mode, chosen by ONE branch
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -388,14 +389,21 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
           csum[j] += vs;
           csq[j] += vs * vs;
           v = v > 0.f ? v : v * a.slope;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout,
-                                                (mok && cok[j]) ? rowoff + ocol[j] : 0xffffffffu, 0, 0);
+          const unsigned off = (mok && cok[j]) ? rowoff + ocol[j] : 0xffffffffu;
+          if (decltype(accum)::value)
+            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rout, (int)off, 0, 0));
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
         }
       }
     }
   };
-  if (a.linear_out) store_tile(std::true_type{});
-  else store_tile(std::false_type{});
+  if (a.accum) {
+    if (a.linear_out) store_tile(std::true_type{}, std::true_type{});
+    else store_tile(std::false_type{}, std::true_type{});
+  } else {
+    if (a.linear_out) store_tile(std::true_type{}, std::false_type{});
+    else store_tile(std::false_type{}, std::false_type{});
+  }
 
   float xs1 = 0.f, xs2 = 0.f;
   if (XR > 0 && has_x) {  // the extra 16x16 block: rows BM + 4(l>>4) + reg, column 16 wave + (l&15)
@@ -419,8 +427,9 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       xs1 += vs;
       xs2 += vs * vs;
       v = v > 0.f ? v : v * a.slope;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout,
-                                            (mok && xok) ? rowoff + 4u * (unsigned)oc : 0xffffffffu, 0, 0);
+      const unsigned off = (mok && xok) ? rowoff + 4u * (unsigned)oc : 0xffffffffu;
+      if (a.accum) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rout, (int)off, 0, 0));
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
     }
   }
 
@@ -517,7 +526,11 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const GArgs a) {
       for (int e = 0; e < 4; ++e) {
         v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
       }
-      if (col < a.Cs) *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col) = v;  // Cs is a multiple of 4
+      if (col < a.Cs) {  // Cs is a multiple of 4
+        f32x4* o = reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col);
+        if (a.accum) v += *o;
+        *o = v;
+      }
     }
   }
   if (a.part) {
@@ -849,8 +862,12 @@ int class_taps(int par, int pad, int stride, int Kd, int& dmin) {
   return cnt;
 }
 
+// channels per tap of the data gradient's K axis: the layer's output channels, NOT the channel stride of
+// the gradient tensor (a conv may write a 32-channel slice of a 192-channel dense-block buffer)
+int bwd_ck(const srx_conv2d_t* d) { return d->shuffle ? d->Cout : (int)srx_roundup(d->Cout, 4); }
+
 int bwd_classes(const srx_conv2d_t* d, BwdClass* cls, size_t& total_floats) {
-  const int Ck = d->shuffle ? d->Cout : d->Cout_s;
+  const int Ck = bwd_ck(d);
   const int Cnp = pad_rows(d->Cin);
   int n = 0;
   total_floats = 0;
@@ -1202,7 +1219,7 @@ extern "C" int srx_conv2d_pack(const srx_conv2d_t* d, const float* w, float* wpk
     BwdClass cls[16];
     size_t total;
     const int nc = bwd_classes(d, cls, total);
-    const int Ck = d->shuffle ? d->Cout : d->Cout_s;
+    const int Ck = bwd_ck(d);
     const int Cnp = pad_rows(d->Cin);
     for (int i = 0; i < nc; ++i) {
       const BwdClass& c = cls[i];
@@ -1250,11 +1267,13 @@ extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float
   return run_gconv(a, fwd_plan(d, g), ws, ws_floats, st);
 }
 
-extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx, float* ws,
-                                   size_t ws_floats, void* stream) {
+extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
+                                   int accumulate, float* ws, size_t ws_floats, void* stream) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(dy && wpk_bwd && dx, "conv2d_bwd_data: null pointer");
   SRX_REQUIRE(d->stride <= 4, "conv2d_bwd_data: stride > 4 unsupported");
+  if (accumulate && (d->stride != 1 || srx_thin_dgrad_applicable(d) || srx_rt36_applicable(d)))
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: accumulate is implemented for stride-1 layers on the generic kernel only");
   hipStream_t st = srx_stream(stream);
   if (srx_thin_dgrad_applicable(d)) return srx_thin_fwd(d, dy, wpk_bwd, nullptr, dx, d->Cin, st);
   const Geo g = fwd_geo(d);
@@ -1280,7 +1299,7 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     set_mgrid(a, d->N, c.Hm, c.Wm);
     a.Hi = g.Ho; a.Wi = g.Wo; a.Ci = d->Cout_s;
     a.in_stride = 1; a.nth = c.nth; a.ntw = c.ntw; a.dh0 = c.dminh; a.dw0 = c.dminw;
-    a.Ck = d->shuffle ? d->Cout : d->Cout_s;
+    a.Ck = bwd_ck(d);
     a.K = c.K; a.Kp = c.Kp;
     a.in_shuffle = g.cps;
     a.Cn = d->Cin; a.Cs = (int)srx_roundup(d->Cin, 4);
@@ -1292,6 +1311,7 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     a.out = dx;
     a.in_bytes = (unsigned)dy_bytes;
     a.w_bytes = (unsigned)((size_t)pad_rows(d->Cin) * c.Kp * sizeof(float));
+    a.accum = accumulate;
     if (d->stride == 1) {
       if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st)) return rc;
     } else if (nc <= 4) {
@@ -1326,7 +1346,7 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
   a.Cnw = (int)srx_roundup(d->Cout, 64);
   a.Cd = d->Cout_s;
   a.dy_shuffle = g.cps;
-  a.Cdv = d->shuffle ? d->Cout : d->Cout_s;
+  a.Cdv = bwd_ck(d);
   a.ktiles = a.Kw / 64;
   const size_t dyb = (size_t)d->N * g.Ho * g.Wo * (d->shuffle ? 4 : 1) * d->Cout_s * sizeof(float);
   SRX_REQUIRE(dyb < 0xfffffff0ull, "conv2d_bwd_weight: gradient tensor above 4 GiB; tile the image");

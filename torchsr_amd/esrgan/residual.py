@@ -9,9 +9,9 @@ class ResidualDenseBlock(nn.Module):
     """Five dense 3x3 convs (torchsr/esrgan/residual.py:31-86).
 
     ``convK`` sees ``cat(x, conv1..convK-1)``; LeakyReLU(0.2) is fused into the first four conv
-    epilogues; the output is ``conv5 * scale_ratio + x``.  The concatenations are explicit NHWC
-    channel copies in this round (a shared 192-channel buffer written in place by each conv is the
-    planned next step: the conv kernels already take separate channel stride / channel count).
+    epilogues; the output is ``conv5 * scale_ratio + x``.  The concatenations are not materialised:
+    every conv reads a prefix of one shared 192-channel buffer and writes its outputs behind it
+    (``functional._DenseBlock``).
     Initialisation reproduces the reference: kaiming_normal_ * 0.1, zero bias (:58-63).
     """
 
@@ -35,12 +35,9 @@ class ResidualDenseBlock(nn.Module):
                     module.bias.data.zero_()
 
     def forward(self, x: Tensor) -> Tensor:
-        conv1 = self.conv1[0](x)
-        conv2 = self.conv2[0](F.concat_channels((x, conv1)))
-        conv3 = self.conv3[0](F.concat_channels((x, conv1, conv2)))
-        conv4 = self.conv4[0](F.concat_channels((x, conv1, conv2, conv3)))
-        conv5 = self.conv5(F.concat_channels((x, conv1, conv2, conv3, conv4)))
-        return F.axpby(conv5, x, self.scale_ratio, 1.0)  # conv5 * scale_ratio + x, :86
+        # one autograd node, one shared 192-channel buffer instead of the four torch.cat copies (:81-86)
+        return F.dense_block(x, self.scale_ratio,
+                             (self.conv1[0], self.conv2[0], self.conv3[0], self.conv4[0], self.conv5))
 
 
 class ResidualInResidualDenseBlock(nn.Module):

@@ -246,7 +246,7 @@ class _Conv2d(Function):
             dx = torch.empty_like(x)
             nws = L.srx_conv2d_bwd_data_ws_floats(dref)
             ws = _ws(nws, x) if nws else None
-            call('srx_conv2d_bwd_data', dref, _p(dy), _p(ctx.wpk_bwd), _p(dx), _p(ws), nws, s)
+            call('srx_conv2d_bwd_data', dref, _p(dy), _p(ctx.wpk_bwd), _p(dx), 0, _p(ws), nws, s)
         wparam, bparam = ctx.params
         if ctx.needs_input_grad[1]:
             sink = _sink(wparam)
@@ -700,6 +700,118 @@ class _ConcatChannels(Function):
 
 def concat_channels(xs) -> Tensor:
     return _ConcatChannels.apply(*xs)
+
+
+class _DenseBlock(Function):
+    """ESRGAN's ResidualDenseBlock as ONE autograd node (esrgan/residual.py:65-86).
+
+    ``c_k = LeakyReLU(conv_k(cat(x, c_1..c_{k-1})))`` for k = 1..4, ``y = conv_5(cat(x, c_1..c_4)) * scale + x``.
+    The five ``torch.cat`` copies (64+96+128+160+192 channels per pixel, and as many again in the
+    backward) are replaced by one ``[N,H,W,64+4*32]`` buffer: conv_k reads its first ``64 + 32(k-1)``
+    channels (channel stride 192) and writes its 32 outputs right behind them; in the backward the
+    input gradients of all five convs are summed in place in a second buffer of the same shape
+    (``srx_conv2d_bwd_data(..., accumulate=1)``), which is exactly the adjoint of the concatenations.
+    """
+
+    @staticmethod
+    def forward(ctx, x: Tensor, scale: float, states, masters, *wb):
+        ctx.set_materialize_grads(False)
+        x = _chk(x, 'dense_block.input')
+        n, h, w, c0 = x.shape
+        g = states[0].cout
+        total = c0 + 4 * g
+        m = n * h * w
+        L = _lib.lib()
+        s = _stream()
+        dev = x.device
+        buf = torch.empty((n, h, w, total), dtype=torch.float32, device=dev)
+        call('srx_copy_channels', _p(x), c0, 0, _p(buf), total, 0, c0, m, 0, s)
+        descs = []
+        for k in range(5):
+            st = states[k]
+            cin = c0 + k * g
+            last = k == 4
+            d = Conv2dDesc(n, h, w, cin, total, st.cout, st.cout if last else total, st.k, st.k, st.stride, st.pad, 0,
+                           st.act, st.slope, 0)
+            descs.append(d)
+            dref = C.byref(d)
+            st.pack(masters[k], d)
+            bias = wb[2 * k + 1]
+            bp = None if bias is None else _p(_chk(bias.detach(), 'dense_block.bias'))
+            nws = L.srx_conv2d_fwd_ws_floats(dref)
+            ws = _ws(nws, x) if nws else None
+            if last:
+                out5 = torch.empty((n, h, w, st.cout), dtype=torch.float32, device=dev)
+                call('srx_conv2d_fwd', dref, _p(buf), _p(st.wpk_fwd), bp, _p(out5), None, _p(ws), nws, s)
+            else:
+                call('srx_conv2d_fwd', dref, _p(buf), _p(st.wpk_fwd), bp, buf.data_ptr() + 4 * cin, None, _p(ws), nws, s)
+        y = torch.empty_like(x)
+        call('srx_axpby', _p(out5), _p(x), _p(y), x.numel(), float(scale), 1.0, s)
+        ctx.states, ctx.descs, ctx.scale = states, descs, float(scale)
+        ctx.dims = (n, h, w, c0, g, total, m)
+        ctx.params = wb
+        ctx.packs = [st.wpk_bwd for st in states]
+        ctx.save_for_backward(buf)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        (buf,) = ctx.saved_tensors
+        dy = _chk(dy, 'dense_block.grad')
+        n, h, w, c0, g, total, m = ctx.dims
+        L = _lib.lib()
+        s = _stream()
+        dev = dy.device
+        gbuf = torch.empty((n, h, w, total), dtype=torch.float32, device=dev)
+        g5 = torch.empty_like(dy)
+        call('srx_axpby', _p(dy), _p(dy), _p(g5), dy.numel(), ctx.scale, 0.0, s)
+        grads = [None] * 10
+        for k in (4, 3, 2, 1, 0):
+            st, d = ctx.states[k], ctx.descs[k]
+            dref = C.byref(d)
+            cin = c0 + k * g
+            if k == 4:
+                gk, ldg = g5.data_ptr(), st.cout
+            else:  # this conv's output gradient is complete now: apply the LeakyReLU mask in place
+                gk, ldg = gbuf.data_ptr() + 4 * cin, total
+                call('srx_act_bwd_from_out_strided', gk, total, buf.data_ptr() + 4 * cin, total, gk, total, m, g,
+                     st.act, st.slope, s)
+            wparam, bparam = ctx.params[2 * k], ctx.params[2 * k + 1]
+            if ctx.needs_input_grad[4 + 2 * k]:
+                sink = _sink(wparam)
+                dw = None if sink is not None else torch.empty((st.cout, st.cin, st.k, st.k), dtype=torch.float32,
+                                                                 device=dev)
+                nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
+                call('srx_conv2d_bwd_weight', dref, _p(buf), gk, _p(dw if sink is None else sink),
+                     0 if sink is None else 1, _p(_ws(nws, dy)), nws, s)
+                grads[2 * k] = dw
+            if bparam is not None and ctx.needs_input_grad[5 + 2 * k]:
+                sink = _sink(bparam)
+                db = None if sink is not None else torch.empty(st.cout, dtype=torch.float32, device=dev)
+                nws = L.srx_colsum_ws_floats(m, st.cout)
+                call('srx_colsum', gk, _p(db if sink is None else sink), m, st.cout, ldg, 0 if sink is None else 1,
+                     _p(_ws(nws, dy)), nws, s)
+                grads[2 * k + 1] = db
+            if k > 0 or ctx.needs_input_grad[0]:
+                nws = L.srx_conv2d_bwd_data_ws_floats(dref)
+                ws = _ws(nws, dy) if nws else None
+                # conv5 writes all `total` channels; the others add their share to the first `cin`
+                call('srx_conv2d_bwd_data', dref, gk, _p(ctx.packs[k]), _p(gbuf), 0 if k == 4 else 1, _p(ws), nws, s)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(dy)
+            call('srx_copy_channels', _p(gbuf), total, 0, _p(dx), c0, 0, c0, m, 0, s)
+            call('srx_axpby', _p(dx), _p(dy), _p(dx), dy.numel(), 1.0, 1.0, s)
+        return (dx, None, None, None, *grads)
+
+
+def dense_block(x: Tensor, scale: float, convs) -> Tensor:
+    """``convs``: the block's five ``layers.Conv2d`` modules (conv1..conv5)."""
+    from .layers import _w
+    wb = []
+    for c in convs:
+        wb += [_w(c.weight), _w(c.bias)]
+    return _DenseBlock.apply(x, scale, [c._st for c in convs], [c.weight for c in convs], *wb)
 
 
 class _Upsample2x(Function):
