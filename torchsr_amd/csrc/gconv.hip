@@ -833,7 +833,7 @@ int check_desc(const srx_conv2d_t* d) {
   return SRX_OK;
 }
 
-int pad_rows(int c) { return c <= 32 ? 32 : (c <= 64 ? 64 : (int)srx_roundup(c, 128)); }
+int pad_rows(int c) { return c <= 32 ? 32 : (int)srx_roundup(c, 64); }  // rows of a packed operand: whole 64-column tiles (32 for the narrow tile)
 
 Geo fwd_geo(const srx_conv2d_t* d) {
   Geo g;
