@@ -134,3 +134,40 @@ def test_segmented_step_equals_fused(dev):
         for k in la:
             assert la[k].item() == pytest.approx(lb[k].item(), rel=1e-5, abs=1e-7), (step, k)
     assert {'gan.disc', 'gan.content', 'gan.gen', 'gan.gopt'} <= set(tb._graphs)
+
+
+def test_checkpoint_resume_continues_the_run(dev, tmp_path):
+    """A checkpoint written by this package carries the discriminator, the three Adam states, both LR
+    schedules, best PSNR and the RNG state next to the reference's {epoch, phase, state}: a fresh trainer
+    restored from it takes the same next step as the run that wrote it."""
+    gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
+    lr, hr = torch.from_numpy(gold['low_res']).to(dev), torch.from_numpy(gold['high_res']).to(dev)
+    a = make_trainer(dev, use_graphs=False)
+    a.pretrain_step(lr, hr)
+    a.gan_step(lr, hr)
+    a.gen_scheduler.step()
+    a.disc_scheduler.step()
+    a.best_psnr = 12.5
+    path = str(tmp_path / 'srgan-gan-latest.pth')
+    torch.save(a._model_state(3, 'srgan-gan'), path)
+    la = {k: float(v) for k, v in a.gan_step(lr, hr).items() if k.startswith('gan/')}
+
+    ckpt = torch.load(path, map_location='cpu')
+    assert set(ckpt) >= {'epoch', 'phase', 'state'} and ckpt['epoch'] == 3      # the reference's three keys
+    b = make_trainer(dev, use_graphs=False)
+    with torch.no_grad():                                                        # start b somewhere else
+        for p in list(b.generator.parameters()) + list(b.discriminator.parameters()):
+            p.mul_(0.5)
+    loaded = b._load_checkpoint(path)
+    b.generator.load_state_dict(loaded['state'])
+    assert b._restore_resume_state(loaded)
+    assert b.best_psnr == 12.5
+    assert b.gen_scheduler.last_epoch == 1 and b.gen_optimizer.lr == a.gen_optimizer.lr
+    assert int(b.gen_optimizer.step_count) == 1 and int(b.psnr_optimizer.step_count) == 1
+    lb = {k: float(v) for k, v in b.gan_step(lr, hr).items() if k.startswith('gan/')}
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-6 * max(abs(la[k]), 1e-3), (k, la[k], lb[k])
+    for (ka, pa), (kb, pb) in zip(a.generator.state_dict().items(), b.generator.state_dict().items()):
+        assert torch.equal(pa, pb), ka
+    for (ka, pa), (kb, pb) in zip(a.discriminator.state_dict().items(), b.discriminator.state_dict().items()):
+        assert torch.equal(pa, pb), ka

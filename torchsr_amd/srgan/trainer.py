@@ -168,9 +168,34 @@ class SRGANTrainer:
             wandb.finish()
 
     def _model_state(self, epoch: int, phase: str) -> dict:
-        """trainer.py:233-258: generator only, {"epoch", "phase", "state"}."""
-        return {'epoch': epoch, 'phase': phase,
-                'state': {k: v.detach().clone().cpu() for k, v in self.generator.state_dict().items()}}
+        """trainer.py:233-258 writes {"epoch", "phase", "state"} with the generator only, so a resumed run
+        restarts the discriminator, all three Adam states and both schedules from scratch.  The same three
+        keys are written here (the reference loads these files unchanged) plus a ``resume`` entry with
+        everything else a run needs to continue where it stopped."""
+        cpu = lambda sd: {k: (v.detach().clone().cpu() if torch.is_tensor(v) else v) for k, v in sd.items()}  # noqa: E731
+        return {'epoch': epoch, 'phase': phase, 'state': cpu(self.generator.state_dict()),
+                'resume': {'discriminator': cpu(self.discriminator.state_dict()),
+                           'psnr_optimizer': cpu(self.psnr_optimizer.state_dict()),
+                           'gen_optimizer': cpu(self.gen_optimizer.state_dict()),
+                           'disc_optimizer': cpu(self.disc_optimizer.state_dict()),
+                           'gen_scheduler': self.gen_scheduler.state_dict(),
+                           'disc_scheduler': self.disc_scheduler.state_dict(),
+                           'best_psnr': self.best_psnr,
+                           'rng': torch.get_rng_state(), 'cuda_rng': torch.cuda.get_rng_state(self.device)}}
+
+    def _restore_resume_state(self, checkpoint: Optional[dict]) -> bool:
+        """Everything beyond the generator, when the checkpoint was written by this package."""
+        extra = (checkpoint or {}).get('resume')
+        if not extra:
+            return False
+        self.discriminator.load_state_dict(extra['discriminator'])
+        for name in ('psnr_optimizer', 'gen_optimizer', 'disc_optimizer', 'gen_scheduler', 'disc_scheduler'):
+            getattr(self, name).load_state_dict(extra[name])
+        self.best_psnr = float(extra['best_psnr'])
+        torch.set_rng_state(extra['rng'])
+        torch.cuda.set_rng_state(extra['cuda_rng'], self.device)
+        F.bump_pack_epoch()
+        return True
 
     def _load_checkpoint(self, path: str) -> Optional[dict]:
         """trainer.py:104-126, plus map_location and tolerance for DDP's 'module.' key prefix."""
@@ -264,6 +289,8 @@ class SRGANTrainer:
             self.generator.load_state_dict(checkpoint['state'])
             F.bump_pack_epoch()
             epoch = checkpoint['epoch']
+            if self._restore_resume_state(checkpoint):
+                epoch += 1
         step = 0
         for epoch in range(epoch, self.pre_epochs + 1):
             self._log('-' * 80)
@@ -380,6 +407,9 @@ class SRGANTrainer:
         if checkpoint:
             self.generator.load_state_dict(checkpoint['state'])
             epoch = checkpoint['epoch']
+            if self._restore_resume_state(checkpoint):
+                epoch += 1  # the checkpoint is written AFTER its epoch: continue with the next one
+                            # (the reference re-runs the saved epoch, trainer.py:483-497)
         else:
             checkpoint = self._load_checkpoint(f'{self.phase_prefix}-psnr-latest.pth')
             if checkpoint:
