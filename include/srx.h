@@ -160,6 +160,18 @@ int srx_upsample_nearest2x_bwd(const float* dy, float* dx, int N, int H, int W, 
 int srx_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream);
 int srx_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 
+/* ------------------------------------------------ on-device data pipeline */
+/* TrainData.__getitem__ of the reference (dataset.py:88-99,121-125: RandomCrop, RandomHorizontalFlip,
+ * RandomVerticalFlip, ToTensor) for a batch of decoded images resident in device memory.
+ * imgs: device array of N pointers to HWC uint8 RGB images; meta: device int32 [N][6] =
+ * {H, W, top, left, hflip, vflip}; out: [N][3][crop][crop] float in [0, 1]. */
+int srx_crop_flip_u8(const void* const* imgs, const int32_t* meta, float* out_nchw, int N, int crop, void* stream);
+/* Resize(crop // scale, BICUBIC) of the reference's low-resolution branch (dataset.py:93-96): antialiased
+ * Keys bicubic (a = -0.5) reduction by an integer factor on NCHW floats; quantize != 0 rounds the result
+ * to 8 bits like the PIL image the reference converts back with ToTensor. */
+int srx_bicubic_down(const float* in_nchw, float* out_nchw, int N, int C, int H, int W, int scale, int quantize,
+                     void* stream);
+
 /* -------------------------------------------------------------- batch norm */
 /* nn.BatchNorm2d(C), eps 1e-5, momentum 0.1 (srgan/residual.py:65,68;
  * srgan/generator.py:49; srgan/discriminator.py:36-60).

@@ -21,7 +21,8 @@ def test_train_then_test_cli(dev, tmp_path, monkeypatch):
               'output/SR_epoch1.png'):
         assert os.path.exists(f), f
     ckpt = torch.load('srgan-gan-latest.pth', map_location='cpu')
-    assert set(ckpt) == {'epoch', 'phase', 'state'} and ckpt['phase'] == 'srgan-gan' and len(ckpt['state']) == 225
+    # the reference's three keys (its loader reads nothing else) plus this package's resume state
+    assert set(ckpt) == {'epoch', 'phase', 'state', 'resume'} and ckpt['phase'] == 'srgan-gan' and len(ckpt['state']) == 225
     Image.fromarray((np.random.rand(20, 28, 3) * 255).astype('uint8')).save('lr.png')
     main(['test', 'lr.png', '--model', 'srgan'])
     out = Image.open('upres-lr.png')
@@ -43,3 +44,20 @@ def test_tiled_inference_equals_untiled(dev):
     tiled = upscale(gen, lr, halo=48, max_tile_pixels=150 * 110)
     assert whole.shape == (1, 3, 600, 840)
     assert (whole - tiled).abs().max().item() <= 1e-4 * whole.abs().max().item()
+
+
+def test_device_data_pipeline_cli(dev, tmp_path, monkeypatch):
+    """--device-data: images decoded once, crop / flips / bicubic x1/4 on the GPU."""
+    from PIL import Image
+    from torchsr_amd.torchsr import main
+    monkeypatch.chdir(tmp_path)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'SLURM_NTASKS'):
+        monkeypatch.delenv(k, raising=False)
+    os.makedirs('imgs')
+    rng = np.random.RandomState(0)
+    for i, (h, w) in enumerate([(120, 150), (97, 96), (200, 130), (96, 96), (140, 101), (60, 80), (128, 128), (110, 99),
+                                (100, 100), (150, 97)]):
+        Image.fromarray((rng.rand(h, w, 3) * 255).astype('uint8')).save(f'imgs/{i}.png')
+    main(['train', '--model', 'srgan', '--train-dir', 'imgs', '--batch-size', '4', '--epochs', '1',
+          '--pretrain-epochs', '1', '--disable-amp', '--seed', '5', '--device-data', '--skip-image-save'])
+    assert os.path.exists('srgan-gan-latest.pth')

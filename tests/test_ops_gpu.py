@@ -335,3 +335,38 @@ def test_adam_matches_torch(dev):
     assert int(step) == 5
     assert (p[:n].cpu() - pc.detach()).abs().max().item() < 2e-7
     assert float(p[n:].abs().max()) == 0.0
+
+
+def test_device_augmentation_kernels(dev):
+    """srx_crop_flip_u8 against numpy indexing (exact); srx_bicubic_down against torch's antialiased bicubic
+    (the Keys a=-0.5 filter PIL's BICUBIC uses) on the CPU, unquantised to 2e-6 and quantised to one 8-bit step."""
+    from torchsr_amd import _lib
+    rng = np.random.RandomState(3)
+    shapes = [(100, 130), (96, 96), (150, 97)]
+    imgs = [torch.from_numpy((rng.rand(h, w, 3) * 255).astype('uint8')) for h, w in shapes]
+    dimgs = [im.to(dev) for im in imgs]
+    crop = 96
+    meta = [[100, 130, 3, 20, 1, 0], [96, 96, 0, 0, 0, 1], [150, 97, 54, 1, 1, 1]]
+    ptrs = torch.tensor([im.data_ptr() for im in dimgs], dtype=torch.int64, device=dev)
+    meta_t = torch.tensor(meta, dtype=torch.int32, device=dev)
+    hr = torch.empty((3, 3, crop, crop), device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.call('srx_crop_flip_u8', ptrs.data_ptr(), meta_t.data_ptr(), hr.data_ptr(), 3, crop, s)
+    for n, (im, (h, w, top, left, hf, vf)) in enumerate(zip(imgs, meta)):
+        ref = im[top:top + crop, left:left + crop].numpy()
+        if hf:
+            ref = ref[:, ::-1]
+        if vf:
+            ref = ref[::-1]
+        ref = torch.from_numpy(ref.copy()).permute(2, 0, 1).float() / 255.0
+        assert torch.equal(hr[n].cpu(), ref)
+    for scale, size in ((4, 96), (4, 128), (2, 50), (3, 99)):
+        x = rnd((2, 3, size, size + 4 * scale), 7, 0.0, 1.0)
+        want = TF.interpolate(x, scale_factor=1.0 / scale, mode='bicubic', antialias=True, align_corners=False)
+        out = torch.empty(want.shape, device=dev)
+        _lib.call('srx_bicubic_down', x.to(dev).data_ptr(), out.data_ptr(), 2, 3, size, size + 4 * scale, scale, 0, s)
+        assert float((out.cpu() - want).abs().max()) < 2e-6
+        _lib.call('srx_bicubic_down', x.to(dev).data_ptr(), out.data_ptr(), 2, 3, size, size + 4 * scale, scale, 1, s)
+        q = (want.clamp(0, 1) * 255).round() / 255
+        assert float((out.cpu() - q).abs().max()) <= 1.0 / 255 + 1e-6       # ties may round either way
+        assert float(((out.cpu() - q).abs() > 1e-6).float().mean()) < 1e-3

@@ -12,7 +12,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libsrx_hip.so')
-SOURCES = ['api.cpp', 'gconv.hip', 'thin.hip', 'rowtile.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'optim.hip']
+SOURCES = ['api.cpp', 'gconv.hip', 'thin.hip', 'rowtile.hip', 'augment.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'optim.hip']
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
 
@@ -73,6 +73,8 @@ _SIGS = {
     'srx_conv2d_bwd_weight': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
     'srx_colsum_ws_floats': (_Z, [_L, _I]),
     'srx_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
+    'srx_crop_flip_u8': (_I, [_P, _P, _P, _I, _I, _P]),
+    'srx_bicubic_down': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'srx_act_bwd_from_out': (_I, [_P, _P, _P, _L, _I, _F, _P]),
     'srx_act_bwd_from_out_strided': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _I, _F, _P]),
     'srx_prelu_fwd': (_I, [_P, _P, _P, _L, _P]),

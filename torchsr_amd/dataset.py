@@ -71,6 +71,108 @@ class _Synthetic(Dataset):
         return lr, hr
 
 
+class DeviceLoader:
+    """Train / test batches produced ON the MI355X.
+
+    The reference runs RandomCrop + flips + PIL bicubic x1/4 in 16 DataLoader workers per GPU for every
+    sample (dataset.py:88-99,121-125); at ~11 ms per batch-16 step that pipeline, not the GPU, sets the
+    pace.  Here every image is decoded once, kept in HBM as uint8 HWC, and a batch is two kernels:
+    ``srx_crop_flip_u8`` (crop + flips + ToTensor) and ``srx_bicubic_down`` (antialiased Keys bicubic, the
+    filter PIL's BICUBIC and ``F.interpolate(..., antialias=True)`` use; LR rounded to 8 bits like the PIL
+    image the reference converts back).  PIL's resampler also rounds its horizontal pass to 8 bits, so
+    low-resolution pixels agree with the reference's to the last 8-bit step, not bit for bit.
+    Same contract as the DataLoader it replaces: ``len()``, iteration yields ``(low_res, high_res)`` or
+    ``(low_res, bicubic, high_res)`` float NCHW in [0, 1], last partial batch dropped.
+    """
+
+    def __init__(self, images, device, batch_size: int, crop_size: int, upscale_factor: int, test: bool, seed: int,
+                 multiplier: int = 1, rank: int = 0, world_size: int = 1):
+        from . import _lib
+        self._lib = _lib
+        self.device, self.batch, self.crop, self.up, self.test = device, batch_size, crop_size, upscale_factor, test
+        self.images = [self._fit(im).to(device) for im in images]          # uint8 [H][W][3]
+        self.sizes = [(int(im.shape[0]), int(im.shape[1])) for im in self.images]
+        self.order = [i for _ in range(multiplier) for i in range(len(self.images))]
+        self.rank, self.world = rank, world_size
+        self.rng = random.Random(seed * 7919 + rank)
+        self.epoch = 0
+
+    def _fit(self, im: torch.Tensor) -> torch.Tensor:
+        """Images smaller than the crop are enlarged first (the reference's RandomCrop would raise)."""
+        h, w = int(im.shape[0]), int(im.shape[1])
+        if h >= self.crop and w >= self.crop:
+            return im.contiguous()
+        f = torch.nn.functional.interpolate(im.permute(2, 0, 1)[None].float(), size=(max(h, self.crop), max(w, self.crop)),
+                                            mode='bicubic', align_corners=False)
+        return f[0].permute(1, 2, 0).clamp(0, 255).round().to(torch.uint8).contiguous()
+
+    def __len__(self) -> int:
+        return len(self.order) // self.world // self.batch
+
+    def __iter__(self):
+        order = list(self.order)
+        if not self.test:
+            random.Random(self.epoch * 104729 + 17).shuffle(order)  # same permutation on every rank
+        self.epoch += 1
+        order = order[self.rank::self.world]
+        call, dev = self._lib.call, self.device
+        for b in range(len(self)):
+            idx = order[b * self.batch:(b + 1) * self.batch]
+            meta = []
+            for i in idx:
+                h, w = self.sizes[i]
+                top, left = self.rng.randint(0, h - self.crop), self.rng.randint(0, w - self.crop)
+                hflip = 0 if self.test else int(self.rng.random() < 0.5)
+                vflip = 0 if self.test else int(self.rng.random() < 0.5)
+                meta.append([h, w, top, left, hflip, vflip])
+            ptrs = torch.tensor([self.images[i].data_ptr() for i in idx], dtype=torch.int64).to(dev)
+            meta_t = torch.tensor(meta, dtype=torch.int32).to(dev)
+            stream = torch.cuda.current_stream().cuda_stream
+            hr = torch.empty((len(idx), 3, self.crop, self.crop), dtype=torch.float32, device=dev)
+            call('srx_crop_flip_u8', ptrs.data_ptr(), meta_t.data_ptr(), hr.data_ptr(), len(idx), self.crop, stream)
+            lc = self.crop // self.up
+            lr = torch.empty((len(idx), 3, lc, lc), dtype=torch.float32, device=dev)
+            call('srx_bicubic_down', hr.data_ptr(), lr.data_ptr(), len(idx), 3, self.crop, self.crop, self.up, 1, stream)
+            if self.test:  # the bicubic up-sampled image of TestData (dataset.py:175-190): only ever displayed
+                bic = torch.nn.functional.interpolate(lr, size=(self.crop, self.crop), mode='bicubic',
+                                                      align_corners=False).clamp(0, 1)
+                yield lr, bic, hr
+            else:
+                yield lr, hr
+
+
+def _decode(path: str) -> torch.Tensor:
+    import numpy as np
+    from PIL import Image
+    return torch.from_numpy(np.asarray(Image.open(path).convert('RGB'), dtype='uint8').copy())
+
+
+def initialize_device_datasets(train_directory: str, device, batch_size: int = 64, crop_size: int = 96,
+                               upscale_factor: int = 4, dataset_multiplier: int = 1, distributed: bool = False,
+                               seed: int = 0, rank: int = 0, world_size: int = 1):
+    """``initialize_datasets`` with the augmentation on the device (``--device-data``).  ``synthetic:N`` draws N
+    seeded random 2*crop x 2*crop images."""
+    if train_directory.startswith('synthetic:'):
+        n = int(train_directory.split(':')[1])
+        g = torch.Generator().manual_seed(seed)
+        images = [torch.randint(0, 256, (2 * crop_size, 2 * crop_size, 3), generator=g, dtype=torch.uint8)
+                  for _ in range(n + max(1, n // 10))]
+    else:
+        paths = _image_dataset(train_directory)
+        if not paths:
+            raise RuntimeError(f'no images ({", ".join(SUPPORTED_IMAGES)}) found in {train_directory}')
+        random.Random(seed or None).shuffle(paths)
+        images = [_decode(p) for p in paths]
+    n_test = max(1, len(images) // 10)
+    if not distributed:
+        rank, world_size = 0, 1
+    train = DeviceLoader(images[n_test:] or images, device, batch_size, crop_size, upscale_factor, False, seed,
+                         dataset_multiplier, rank, world_size)
+    test = DeviceLoader(images[:n_test] * max(1, -(-batch_size // n_test)), device, batch_size, crop_size, upscale_factor,
+                        True, seed + 1)
+    return train, test, len(train.order), len(test.order)
+
+
 def initialize_datasets(train_directory: str, batch_size: int = 64, crop_size: int = 96, upscale_factor: int = 4,
                         dataset_multiplier: int = 1, workers: int = 16, distributed: bool = False,
                         seed: int = 0) -> Tuple[DataLoader, DataLoader, int, int]:

@@ -91,6 +91,8 @@ def parse_args(argv=None) -> Namespace:
     train.add_argument('--train-dir', type=str, default=TRAIN_DIR)
     train.add_argument('--vgg-weights', type=str, default=None, help='path to vgg19-dcbb9e9d.pth')
     train.add_argument('--no-graphs', action='store_true', help='run the step eagerly instead of as a hipGraph')
+    train.add_argument('--device-data', action='store_true',
+                       help='keep the decoded images in HBM and crop / flip / bicubic-downsample on the GPU')
     test = commands.add_parser('test', help='Generate a super resolution image from a trained model.')
     test.add_argument('image', type=str)
     test.add_argument('--model', type=str, default=MODEL, choices=MODELS.keys())
@@ -117,11 +119,17 @@ def main(argv=None) -> None:
             os.environ['MASTER_PORT'] = args.master_port
         dist.init_process_group(backend='nccl' if device.type == 'cuda' else 'gloo')
     args.use_graphs = not args.no_graphs
-    from torchsr_amd.dataset import initialize_datasets
-    train_loader, test_loader, train_len, test_len = initialize_datasets(
-        args.train_dir, batch_size=args.batch_size, crop_size=crop_size, upscale_factor=4,
-        dataset_multiplier=args.dataset_multiplier, workers=args.data_workers, distributed=distributed,
-        seed=args.seed)
+    from torchsr_amd.dataset import initialize_datasets, initialize_device_datasets
+    if args.device_data:
+        train_loader, test_loader, train_len, test_len = initialize_device_datasets(
+            args.train_dir, device, batch_size=args.batch_size, crop_size=crop_size, upscale_factor=4,
+            dataset_multiplier=args.dataset_multiplier, distributed=distributed, seed=args.seed,
+            rank=max(int(args.rank), 0) if distributed else 0, world_size=int(args.world_size) if distributed else 1)
+    else:
+        train_loader, test_loader, train_len, test_len = initialize_datasets(
+            args.train_dir, batch_size=args.batch_size, crop_size=crop_size, upscale_factor=4,
+            dataset_multiplier=args.dataset_multiplier, workers=args.data_workers, distributed=distributed,
+            seed=args.seed)
     trainer = model_class(device, args, train_loader, test_loader, train_len, test_len, distributed)
     trainer.train()
     if distributed:
