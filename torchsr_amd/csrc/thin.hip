@@ -10,6 +10,7 @@
 // 4-address broadcast.  Same 64 FLOP/clk/SIMD rate as the 32x32 MFMA, exact fp32.
 #include "srx_common.h"
 #include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -130,76 +131,99 @@ struct ThinF {
   float* out;         // [N][H][W][4]
   int N, H, W, Cout;
   int tiles_w, tiles_h;
+  unsigned in_bytes;
 };
 
-template <int KH, int KW>
-__global__ __launch_bounds__(256) void thin_fwd_kernel(const ThinF a) {
-  constexpr int TH = 16, TW = 32;  // output pixels per workgroup: 4 waves x (2 groups of 64 = 2 rows x 32)
-  constexpr int PH = TH + KH - 1, PW = TW + KW - 1;
-  constexpr int PAD = (KH - 1) / 2;
-  constexpr int CS = 20;  // floats per pixel slot in LDS (16 channels + 4 pad)
-  constexpr int TAPS = KH * KW;
+// Forward kernel (also the data gradient of the 3-channel-input layers, with flipped taps).  A first
+// version read three LDS b128 operands for every eight MFMAs and was LDS-bandwidth bound (136 B/clk per CU
+// asked, 128 available; 168 us for conv3 at batch 16).  Here a lane owns R output rows of one column
+// and one half (4) of the 8 channels staged per round:
+//   * for a fixed kernel column kw the nine (KH) weight fragments live in registers,
+//   * every input pixel fragment read from LDS (rows r .. r+R+KH-2 of column c+kw) feeds all the
+//     output rows it touches (kh = input row - output row),
+// i.e. (K + R + K - 1) b128 reads per 4 R K MFMAs (21 per 144 at R = 4, where the first version needed 54).  Lanes 0-31 / 32-63 hold the two channel halves of the
+// same 32 pixels and are summed at the end; pixels are stored 32 B apart so a wave's read is one
+// contiguous 2 KB block.  Output tile 4R x 32 pixels per workgroup (4 waves x R rows); 84 us for conv3.
+template <int K, int R>
+__global__ __launch_bounds__(256) void thin_fwd2_kernel(const ThinF a) {
+  constexpr int TH = 4 * R, TW = 32, CS = 8;  // CS: channels staged per round
+  constexpr int PH = TH + K - 1, PW = TW + K - 1, PAD = (K - 1) / 2, TAPS = K * K;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sx = reinterpret_cast<float*>(smem);         // [PH][PW][CS]
-  float* sw = sx + PH * PW * CS;                      // [4][TAPS][16]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* sx = reinterpret_cast<float*>(smem);  // [PH][PW][CS]
+  float* sw = sx + PH * PW * CS;               // [4][TAPS][CS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
   int b = blockIdx.x;
   const int tw_i = b % a.tiles_w; b /= a.tiles_w;
   const int th_i = b % a.tiles_h;
   const int n = b / a.tiles_h;
   const int h0 = th_i * TH, w0 = tw_i * TW;
-  // this lane's two pixels: group g -> rows (wave*4 + 2g + lane/32), column lane%32
-  const int pc = lane & 31, pr0 = wave * 4 + (lane >> 5);
-  const int wc = lane & 3;
+  const int pc = lane & 31, hh = lane >> 5, r0 = wave * R, wc = lane & 3;
+  const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes);
+  const __amdgpu_buffer_rsrc_t rw = srx_rsrc(a.w, 4 * TAPS * 64 * 4);
 
-  f32x4 acc[2];
-  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int cc = 0; cc < 64; cc += 16) {
-    __syncthreads();
-    // stage the input patch slice: PH*PW pixels x 16 channels = 4 float4 per pixel
-    for (int i = tid; i < PH * PW * 4; i += 256) {
-      const int q = i & 3, pix = i >> 2;
+  constexpr int NPX = PH * PW * 2;                      // b128 units of the patch (pixel, channel quad)
+  constexpr int LP = (NPX + 255) / 256;                 // loads per thread (all issued before any is written)
+  constexpr int NWQ = 4 * TAPS * 2, LW = (NWQ + 255) / 256;
+  for (int cc = 0; cc < 64; cc += CS) {
+    f32x4 vp[LP], vw[LW];
+#pragma unroll
+    for (int u = 0; u < LP; ++u) {
+      const int i = u * 256 + tid;
+      const int q = i & 1, pix = i >> 1;
       const int pw = pix % PW, ph = pix / PW;
       const int ih = h0 - PAD + ph, iw = w0 - PAD + pw;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-        v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(n * a.H + ih) * a.W + iw) * 64 + cc + q * 4);
-      *reinterpret_cast<f32x4*>(sx + pix * CS + q * 4) = v;
+      const bool ok = i < NPX && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      vp[u] = srx_bload(rin, ok ? 4u * (unsigned)(((n * a.H + ih) * a.W + iw) * 64 + cc + q * 4) : 0xffffffffu, 0);
     }
-    for (int i = tid; i < 4 * TAPS * 4; i += 256) {
-      const int q = i & 3, ct = i >> 2;  // ct = c*TAPS + tap
-      *reinterpret_cast<f32x4*>(sw + ct * 16 + q * 4) =
-          *reinterpret_cast<const f32x4*>(a.w + (size_t)ct * 64 + cc + q * 4);
+#pragma unroll
+    for (int u = 0; u < LW; ++u) {
+      const int i = u * 256 + tid;  // (c*TAPS + tap) * 2 + q
+      vw[u] = srx_bload(rw, i < NWQ ? 4u * (unsigned)((i >> 1) * 64 + cc + (i & 1) * 4) : 0xffffffffu, 0);
+    }
+    __syncthreads();  // the previous round's reads are done
+#pragma unroll
+    for (int u = 0; u < LP; ++u) {
+      const int i = u * 256 + tid;
+      if (i < NPX) *reinterpret_cast<f32x4*>(sx + i * 4) = vp[u];
+    }
+#pragma unroll
+    for (int u = 0; u < LW; ++u) {
+      const int i = u * 256 + tid;
+      if (i < NWQ) *reinterpret_cast<f32x4*>(sw + i * 4) = vw[u];
     }
     __syncthreads();
 #pragma unroll 1
-    for (int kh = 0; kh < KH; ++kh) {
+    for (int kw = 0; kw < K; ++kw) {
+      f32x4 wr[K];
 #pragma unroll
-      for (int kw = 0; kw < KW; ++kw) {
-        const float* wp = sw + (wc * TAPS + kh * KW + kw) * 16;
-        const float* x0 = sx + ((pr0 + kh) * PW + pc + kw) * CS;
-        const float* x1 = x0 + 2 * PW * CS;
+      for (int kh = 0; kh < K; ++kh)
+        wr[kh] = *reinterpret_cast<const f32x4*>(sw + ((wc * TAPS + kh * K + kw) * CS + 4 * hh));
+      const float* xp = sx + ((r0 * PW) + pc + kw) * CS + 4 * hh;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + q * 4);
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(x0 + q * 4);
-          const f32x4 v1 = *reinterpret_cast<const f32x4*>(x1 + q * 4);
+      for (int ir = 0; ir < R + K - 1; ++ir) {  // input row r0 + ir of the patch
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + ir * PW * CS);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], v0[e], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], v1[e], acc[1], 0, 0, 0);
+        for (int j = 0; j < R; ++j) {
+          const int kh = ir - j;
+          if (kh >= 0 && kh < K) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[kh][e], xv[e], acc[j], 0, 0, 0);
           }
         }
       }
     }
   }
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int oh = h0 + pr0 + 2 * g, ow = w0 + pc;
-    if (oh < a.H && ow < a.W) {
-      f32x4 v = acc[g];
+  for (int j = 0; j < R; ++j) {
+    f32x4 v = acc[j];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] += __shfl_xor(v[c], 32, 64);  // the other channel half
+    const int oh = h0 + r0 + j, ow = w0 + pc;
+    if (hh == 0 && oh < a.H && ow < a.W) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = c < a.Cout ? v[c] + (a.bias ? a.bias[c] : 0.f) : 0.f;
       *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.H + oh) * a.W + ow) * 4) = v;
@@ -311,24 +335,18 @@ int srx_thin_pack(const srx_conv2d_t* d, const float* w, float* p, int mode, hip
   return SRX_OK;
 }
 
-template <int K>
-static int launch_thin_fwd(const ThinF& a, hipStream_t st) {
-  constexpr int PH = 16 + K - 1, PW = 32 + K - 1;
-  const size_t lds = (size_t)(PH * PW * 20 + 4 * K * K * 16) * sizeof(float);
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel<K, K>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    once = true;
-  }
+template <int K, int R>
+static int launch_thin_fwd2(const ThinF& a, hipStream_t st) {
+  constexpr int PH = 4 * R + K - 1, PW = 32 + K - 1;
+  const size_t lds = (size_t)(PH * PW * 8 + 4 * K * K * 8) * sizeof(float);
   if (srx_prof_on()) {
     char nm[64];
-    snprintf(nm, sizeof(nm), "thin_fwd_kernel<%d, %d>", K, K);
+    snprintf(nm, sizeof(nm), "thin_fwd2_kernel<%d, %d>", K, R);
     srx_prof_begin_launch(nm, 2.0 * a.N * a.H * a.W * K * K * 64 * a.Cout, st);
   }
-  hipLaunchKernelGGL((thin_fwd_kernel<K, K>), dim3((unsigned)(a.N * a.tiles_h * a.tiles_w)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((thin_fwd2_kernel<K, R>), dim3((unsigned)(a.N * a.tiles_h * a.tiles_w)), dim3(256), lds, st, a);
   if (srx_prof_on()) srx_prof_end_launch(st);
-  SRX_CHECK_LAUNCH("thin_fwd_kernel");
+  SRX_CHECK_LAUNCH("thin_fwd2_kernel");
   return SRX_OK;
 }
 
@@ -338,7 +356,16 @@ int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const
   ThinF a;
   a.in = in; a.w = wpk; a.bias = bias; a.out = out;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cout = n_out;
-  a.tiles_h = (int)srx_cdiv(d->H, 16);
   a.tiles_w = (int)srx_cdiv(d->W, 32);
-  return d->KH == 9 ? launch_thin_fwd<9>(a, st) : launch_thin_fwd<3>(a, st);
+  a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * 64 * sizeof(float));
+  // rows per lane: 6 reads LDS least (23 b128 per 216 MFMAs) and wins whenever there are plenty of tiles; small
+  // images balance better over the CUs with 12-row tiles (R = 3).  SRX_THIN_FWD_ROWS overrides (3, 4, 6).
+  static const char* dev = getenv("SRX_THIN_FWD_ROWS");
+  static int cus = 0;
+  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
+  const int64_t big_tiles = (int64_t)d->N * srx_cdiv(d->H, 24) * a.tiles_w;
+  const int R = dev ? atoi(dev) : (big_tiles >= 4 * cus ? 6 : 3);
+  a.tiles_h = (int)srx_cdiv(d->H, 4 * R);
+  if (d->KH == 9) return R == 3 ? launch_thin_fwd2<9, 3>(a, st) : (R == 6 ? launch_thin_fwd2<9, 6>(a, st) : launch_thin_fwd2<9, 4>(a, st));
+  return R == 3 ? launch_thin_fwd2<3, 3>(a, st) : (R == 6 ? launch_thin_fwd2<3, 6>(a, st) : launch_thin_fwd2<3, 4>(a, st));
 }
