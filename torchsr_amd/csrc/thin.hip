@@ -33,11 +33,14 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinW a) {
   constexpr int RPG = KH / GROUPS;  // kernel rows per wave
   constexpr int PAD = (KH - 1) / 2;
   constexpr int NT = 16 + KW - 1;
-  const int lane = threadIdx.x & 63;
-  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int group = gw % GROUPS, range = gw / GROUPS;
-  if (range >= a.nranges) return;  // grid is rounded up to whole workgroups
-  const int sbeg = range * a.segs_per_range;
+  // the four waves of a workgroup share the group of kernel rows and take four consecutive segment
+  // ranges; their accumulators are folded through LDS before the slab is written (the slabs are
+  // 4 x taps x 64 floats each -- 83 KB for 9x9 -- and used to cost more traffic than the operands)
+  __shared__ float fold[2][RPG * KW * 4 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int group = blockIdx.x % GROUPS, rb = blockIdx.x / GROUPS;
+  const int range = rb * 4 + wave;
+  const int sbeg = min(a.nseg, range * a.segs_per_range);  // ranges past the end are empty
   const int send = min(a.nseg, sbeg + a.segs_per_range);
   const int tc = lane & 3;
 
@@ -77,7 +80,28 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinW a) {
         }
     }
   }
-  float* o = a.slab + (size_t)range * (4 * KH * KW * 64);
+  // fold: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and writes the slab
+  auto put = [&](int slot) {
+#pragma unroll
+    for (int t = 0; t < RPG * KW; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) fold[slot][(t * 4 + c) * 64 + lane] = acc[t][c];
+  };
+  auto add = [&](int slot) {
+#pragma unroll
+    for (int t = 0; t < RPG * KW; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[t][c] += fold[slot][(t * 4 + c) * 64 + lane];
+  };
+  if (wave >= 2) put(wave - 2);
+  __syncthreads();
+  if (wave < 2) add(wave);
+  __syncthreads();
+  if (wave == 1) put(0);
+  __syncthreads();
+  if (wave != 0) return;
+  add(0);
+  float* o = a.slab + (size_t)rb * (4 * KH * KW * 64);
 #pragma unroll
   for (int dr = 0; dr < RPG; ++dr)
 #pragma unroll
@@ -273,7 +297,7 @@ bool srx_thin_wgrad_applicable(const srx_conv2d_t* d) {
 size_t srx_thin_wgrad_ws_floats(const srx_conv2d_t* d) {
   const int nseg = d->N * d->H * (int)srx_cdiv(d->W, 16);
   const int groups = d->KH == 9 ? 3 : 1;
-  return (size_t)thin_ranges(nseg, groups) * 4 * d->KH * d->KW * 64;
+  return (size_t)srx_cdiv(thin_ranges(nseg, groups), 4) * 4 * d->KH * d->KW * 64;  // one slab per workgroup
 }
 
 int srx_thin_wgrad(const srx_conv2d_t* d, const float* x, const float* dy, float* dw, int accumulate, float* ws,
@@ -290,10 +314,11 @@ int srx_thin_wgrad(const srx_conv2d_t* d, const float* x, const float* dy, float
   const int ranges = thin_ranges(a.nseg, groups);
   a.segs_per_range = (int)srx_cdiv(a.nseg, ranges);
   const int nranges = (int)srx_cdiv(a.nseg, a.segs_per_range);
-  if ((size_t)nranges * 4 * d->KH * d->KW * 64 > ws_floats)
+  const int nslabs = (int)srx_cdiv(nranges, 4);
+  if ((size_t)nslabs * 4 * d->KH * d->KW * 64 > ws_floats)
     SRX_FAIL(SRX_E_WORKSPACE, "conv2d_bwd_weight(thin): workspace too small");
   a.nranges = nranges;
-  const unsigned blocks = (unsigned)srx_cdiv((int64_t)nranges * groups, 4);
+  const unsigned blocks = (unsigned)(nslabs * groups);
   if (srx_prof_on()) {
     char nm[64];
     snprintf(nm, sizeof(nm), "thin_wgrad_kernel<%d, %d, %d, %d>", d->KH, d->KW, groups, thin_out ? -1 : 1);
@@ -311,7 +336,7 @@ int srx_thin_wgrad(const srx_conv2d_t* d, const float* x, const float* dy, float
   const int taps = d->KH * d->KW;
   const int cthin = thin_out ? d->Cout : d->Cin;
   hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((unsigned)(cthin * taps)), dim3(256), 0, st, ws,
-                     nranges, taps, cthin, 64, thin_out ? 1 : 0, dw, accumulate);
+                     nslabs, taps, cthin, 64, thin_out ? 1 : 0, dw, accumulate);
   SRX_CHECK_LAUNCH("thin_wgrad_reduce_kernel");
   return SRX_OK;
 }
