@@ -86,3 +86,31 @@ def test_esrgan_gan_steps_vs_reference_trainer(dev):
         for g, w in zip(got, want):
             assert abs(g - w) <= tol * max(abs(w), 1e-3), (step, got, list(want))
         assert abs(got[4] - gold['gan_ref_gen_losses'][step]) <= tol * gold['gan_ref_gen_losses'][step]
+
+
+def test_esrgan_gan_step_with_bf16_products(dev):
+    """Without --disable-amp the trainers multiply bf16-rounded conv operands (fp32 accumulation, fp32
+    everything else).  The first GAN step must then land within bf16 rounding of the fp32 golden losses:
+    2e-2 relative (bf16 carries 8 bits of mantissa: 4e-3 per operand, deep networks compound it)."""
+    from torchsr_amd.esrgan.trainer import ESRGANTrainer
+    from torchsr_amd.layers import Conv2d
+    gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
+    args = Namespace(disable_amp=False, batch_size=2, epochs=8, gan_checkpoint=None, local_rank=0, pretrain_epochs=1,
+                     psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1, use_graphs=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        t = ESRGANTrainer(dev, args, [], [], 2, 2, distributed=False)
+    assert all(m._st.precision == 1 for m in t.generator.modules() if isinstance(m, Conv2d))
+    t.generator.load_state_dict(closed_form_state(t.generator.state_dict()))
+    t.discriminator.load_state_dict(closed_form_state(t.discriminator.state_dict()))
+    t.vgg_loss.features.load_state_dict(closed_form_state(t.vgg_loss.features.state_dict(), prefix='features.'))
+    t.generator.train()
+    t.discriminator.train()
+    lr, hr = torch.from_numpy(gold['low_res']).to(dev), torch.from_numpy(gold['high_res']).to(dev)
+    losses = t.gan_step(lr, hr)
+    got = [losses[k].item() for k in ('gan/disc-loss', 'gan/pixel-loss', 'gan/content-loss', 'gan/adversarial-loss',
+                                       'gan/train-loss')]
+    want = gold['gan_losses'][0]
+    for g, w in zip(got, want):
+        assert np.isfinite(g) and abs(g - w) <= 2e-2 * max(abs(w), 1e-3), (got, list(want))
+    assert any(abs(g - w) > 1e-7 * max(abs(w), 1e-3) for g, w in zip(got, want))  # it really is a different precision

@@ -141,6 +141,46 @@ def test_conv2d_144_row_tiles(dev, case, plan, monkeypatch):
     test_conv2d_fwd_bwd(dev, case)
 
 
+@pytest.mark.parametrize('case', [(2, 24, 24, 64, 64, 3, 1, 1, True), (2, 16, 16, 128, 256, 3, 1, 1, False),
+                                  (3, 13, 11, 96, 32, 3, 1, 1, True), (1, 32, 32, 192, 64, 3, 1, 1, True),
+                                  (2, 12, 12, 512, 512, 3, 1, 1, False), (2, 20, 20, 64, 64, 3, 2, 1, False)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_conv2d_bf16_products(dev, case):
+    """precision = 1 (the autocast region of the reference): operands rounded to bf16, products exact,
+    fp32 accumulation.  Oracle: the fp32 CPU conv on operands rounded the same way -- agreement to fp32
+    accumulation-order noise.  The weight gradient (and a strided data gradient) stays fp32."""
+    from torchsr_amd.layers import Conv2d, set_conv_precision
+    n, h, w, cin, cout, k, s, p, bias = case
+    seed = hash(case) % 1000
+    x = rnd((n, cin, h, w), seed)
+    conv = Conv2d(cin, cout, k, s, p, bias=bias)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(conv.weight.shape, seed + 1) * (2.0 / (cin * k * k)) ** 0.5 * 1.7)
+        if bias:
+            conv.bias.copy_(rnd(conv.bias.shape, seed + 2) * 0.3)
+    set_conv_precision(conv, 'bf16')
+    r16 = lambda t: t.detach().bfloat16().float()  # noqa: E731
+    bc = conv.bias.detach().clone() if bias else None
+    yc = TF.conv2d(r16(x), r16(conv.weight), bc, s, p)
+    gy = rnd(yc.shape, seed + 3)
+    wr = r16(conv.weight).requires_grad_(False)
+    xa = x.clone().requires_grad_(True)
+    if s == 1:
+        TF.conv2d(xa, wr, None, s, p).backward(r16(gy))      # dx = conv_transpose(bf16(dy), bf16(W))
+    else:
+        TF.conv2d(xa, conv.weight.detach(), None, s, p).backward(gy)   # strided data gradient: fp32
+    wa = conv.weight.detach().clone().requires_grad_(True)
+    TF.conv2d(x, wa, None, s, p).backward(gy)                # dW: fp32 operands
+
+    conv = conv.to(dev)
+    xg = nhwc(x).to(dev).requires_grad_(True)
+    yg = conv(xg)
+    assert rel_err(nchw(yg.cpu(), cout), yc) < 2e-5
+    yg.backward(nhwc(gy, yg.shape[-1]).to(dev))
+    assert rel_err(nchw(xg.grad.cpu(), cin), xa.grad) < 2e-5
+    assert rel_err(conv.weight.grad, wa.grad) < 2e-4
+
+
 def test_row_tile_plan(dev):
     """The SRGAN residual conv at the reference batch runs as 256 workgroups of 36 pixels (forward and
     data gradient); a layer the row tile does not cover falls back to the generic plan."""

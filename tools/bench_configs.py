@@ -4,7 +4,7 @@ quoted in DESIGN.md).
     python tools/bench_configs.py [pretrain] [esrgan] [infer]
 
   pretrain : SRGAN SRResNet pre-training step, 96x96 crops, batch 16 and batch 2 (config 1 on the GPU)
-  esrgan   : ESRGAN full GAN step, 128x128 crops, batch 16 (config 4; fp32 this round)
+  esrgan   : ESRGAN full GAN step, 128x128 crops, batch 16 (config 4), fp32 and with bf16 conv products (amp)
   infer    : SRGAN generator 1080p -> 8K, batch 1, eval mode, tiled (config 5)
 """
 import os
@@ -20,8 +20,8 @@ warnings.simplefilter('ignore')
 dev = torch.device('cuda:0')
 
 
-def targs(batch):
-    return Namespace(disable_amp=True, batch_size=batch, epochs=8, gan_checkpoint=None, local_rank=0, pretrain_epochs=1,
+def targs(batch, amp=False):
+    return Namespace(disable_amp=not amp, batch_size=batch, epochs=8, gan_checkpoint=None, local_rank=0, pretrain_epochs=1,
                      psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1, use_graphs=True)
 
 
@@ -56,12 +56,15 @@ if 'pretrain' in which:
 if 'esrgan' in which:
     from torchsr_amd.esrgan.trainer import ESRGANTrainer
     torch.manual_seed(0)
-    t = ESRGANTrainer(dev, targs(16), [], [], 16, 16)
-    lr, hr = batch(16, 128)
-    dt = timed(lambda: t.gan_step(lr, hr), 10, warm=4)
-    print(f'ESRGAN GAN step      batch 16: {dt * 1e3:7.3f} ms/step  {16 / dt:8.1f} crops/s  {3622.0 / dt / 1e3:6.1f} TFLOP/s '
-          f'(fp32, as-executed 3622 GFLOP/step)', flush=True)
-    del t
+    for amp in (False, True):
+        torch.manual_seed(0)
+        t = ESRGANTrainer(dev, targs(16, amp), [], [], 16, 16)
+        lr, hr = batch(16, 128)
+        dt = timed(lambda: t.gan_step(lr, hr), 10, warm=4)
+        what = 'bf16 products (amp)' if amp else 'fp32'
+        print(f'ESRGAN GAN step      batch 16: {dt * 1e3:7.3f} ms/step  {16 / dt:8.1f} crops/s  {3622.0 / dt / 1e3:6.1f} TFLOP/s '
+              f'({what}, as-executed 3622 GFLOP/step)', flush=True)
+        del t
 if 'infer' in which:
     from torchsr_amd.srgan.generator import Generator
     from torchsr_amd.test import upscale

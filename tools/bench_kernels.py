@@ -58,6 +58,7 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--only', type=str, default='')
     ap.add_argument('--graph', action='store_true', help='time the forward as a replayed hipGraph of `reps` calls')
+    ap.add_argument('--bf16', action='store_true', help='bf16 products (srx_conv2d_t::precision = 1)')
     ap.add_argument('--shape', action='append', default=[], help='extra 3x3/s1/p1 layer: N,H,W,Cin,Cout (repeatable)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -70,6 +71,7 @@ def main():
         if args.only and args.only not in name:
             continue
         conv = Conv2d(cin, cout, k, s, p, bias=False, shuffle=sh).to(dev)
+        conv._st.precision = 1 if args.bf16 else 0
         cin_s = (cin + 3) // 4 * 4
         x = torch.rand(n, h, w, cin_s, device=dev).requires_grad_(True)
         y = conv(x)

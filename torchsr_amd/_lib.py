@@ -24,6 +24,7 @@ class Conv2dDesc(C.Structure):
         ('Cin', C.c_int32), ('Cin_s', C.c_int32), ('Cout', C.c_int32), ('Cout_s', C.c_int32),
         ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
         ('shuffle', C.c_int32), ('act', C.c_int32), ('slope', C.c_float), ('up', C.c_int32),
+        ('precision', C.c_int32),
     ]
 
 

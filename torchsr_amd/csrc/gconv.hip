@@ -64,9 +64,17 @@ constexpr int INVALID = -20000;  // coordinate that fails every bounds check
 // blocks of 16x16 by the first BN/16 waves.  The SRGAN shapes have M = 2304 * 4^j pixels: with 144-row
 // tiles every layer cuts into a power-of-two number of tiles, i.e. whole rounds of the 256 CUs, where
 // 128-row tiles leave 12-25 % of a round idle and need the K-split fix-up pass.
-template <int BM, int BN, int WM, int WN, int KS, int XR>
+//
+// PR = 1: bf16 products, fp32 accumulation (srx_conv2d_t::precision).  Global memory stays fp32; a chunk's
+// 32 k-values are rounded to bf16 when they are written to LDS (64-byte rows) and multiplied by two
+// v_mfma_f32_32x32x16_bf16 per 32x32 block instead of sixteen fp32 MFMAs -- the loop is then bound by the
+// L2 -> LDS stream, not by the matrix pipe.
+template <int BM, int BN, int WM, int WN, int KS, int XR, int PR>
 __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   static_assert(XR == 0 || (XR == 16 && KS == 1), "extra rows: 16, without the in-workgroup K split");
+  static_assert(PR == 0 || XR == 0, "the 16-row extension is fp32 only");
+  constexpr int BKL = PR ? BK / 2 : BK;  // floats per LDS row
+  constexpr int NS = PR ? 2 : 4;         // MFMA sub-steps per chunk
   constexpr int BMT = BM + XR;  // rows of the tile
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
@@ -86,9 +94,9 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   const int ks = KS == 1 ? 0 : srx_uniform(threadIdx.x / GT);  // k-group of this wave (groups are contiguous)
   const int tid = threadIdx.x - ks * GT, lane = tid & 63, wave = srx_uniform(tid >> 6);
   constexpr int RING = 3;  // LDS chunk buffers per k-group
-  float* sA = reinterpret_cast<float*>(smem) + ks * RING * (BMT + BN) * BK;
-  float* sB = sA + RING * BMT * BK;
-  int2* ktab = reinterpret_cast<int2*>(reinterpret_cast<float*>(smem) + KS * RING * (BMT + BN) * BK);
+  float* sA = reinterpret_cast<float*>(smem) + ks * RING * (BMT + BN) * BKL;
+  float* sB = sA + RING * BMT * BKL;
+  int2* ktab = reinterpret_cast<int2*>(reinterpret_cast<float*>(smem) + KS * RING * (BMT + BN) * BKL);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int tile = bid, kc_beg = 0, kc_end = a.kchunks;
   bool raw = false;
@@ -186,21 +194,32 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
     for (int p = 0; p < RB; ++p)
       rb[p] = srx_bload(rw, live ? wvoff[p] : 0xffffffffu, (unsigned)srx_uniform(live ? kc * (BK * 4) : 0));
   };
-  const int wchunk = (q ^ ((r0 >> 1) & 7)) * 4;
+  // fp32: 16-byte quad q of the row at quad q ^ ((row>>1)&7).  bf16: the quad shrinks to 8 bytes; quads 2g, 2g+1
+  // form the 16-byte group g (k = 8g..8g+7, one MFMA operand), stored at group g ^ ((row>>2)&3).
+  const int wchunk = PR ? (((q >> 1) ^ ((r0 >> 2) & 3)) * 4 + (q & 1) * 2) : (q ^ ((r0 >> 1) & 7)) * 4;
+  auto put = [&](float* dst, const f32x4& v) {
+    if (PR) {
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      const bf16x2 lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
+      *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  };
   auto swrite = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) {
-    float* dA = sA + buf * BMT * BK;
-    float* dB = sB + buf * BN * BK;
+    float* dA = sA + buf * BMT * BKL;
+    float* dB = sB + buf * BN * BKL;
 #pragma unroll
     for (int p = 0; p < RA; ++p)
       if (RPP * (p + 1) <= BMT || r0 + RPP * p < BMT)  // (compile-time true except in a partial last pass)
-        *reinterpret_cast<f32x4*>(dA + (r0 + RPP * p) * BK + wchunk) = ra[p];
+        put(dA + (r0 + RPP * p) * BKL + wchunk, ra[p]);
 #pragma unroll
-    for (int p = 0; p < RB; ++p) *reinterpret_cast<f32x4*>(dB + (r0 + RPP * p) * BK + wchunk) = rb[p];
+    for (int p = 0; p < RB; ++p) put(dB + (r0 + RPP * p) * BKL + wchunk, rb[p]);
   };
 
   const int h = lane >> 5, l31 = lane & 31;
-  const int xr = (l31 >> 1) & 7;
-  const int arow = (wm * WM + l31) * BK, brow = (wn * WN + l31) * BK;
+  const int xr = PR ? (l31 >> 2) & 3 : (l31 >> 1) & 7;
+  const int arow = (wm * WM + l31) * BKL, brow = (wn * WN + l31) * BKL;
   // extra 16 rows: wave w < BN/16 owns the 16x16 block of columns 16w..16w+15
   //   v_mfma_f32_16x16x4_f32: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D: col = l&15, row = 4(l>>4) + reg
   const bool has_x = XR > 0 && wave < BN / 16;
@@ -221,16 +240,27 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   // matrix pipe a barrier + a write + a read latency: 28 % idle with one workgroup per CU.)
   f32x4 af[2][TM], bf[2][TN];  // fragment register sets: step s+1 is read while step s is multiplied
   auto frag = [&](int slot, int s, int set) {
-    const float* cA = sA + slot * BMT * BK + arow;
-    const float* cB = sB + slot * BN * BK + brow;
-    const int ch = ((2 * s + h) ^ xr) * 4;
+    const float* cA = sA + slot * BMT * BKL + arow;
+    const float* cB = sB + slot * BN * BKL + brow;
+    const int ch = ((2 * s + h) ^ xr) * 4;  // fp32: quad of 4 k;  bf16: group of 8 k (one 32x32x16 operand)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[set][i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * BK + ch);
+    for (int i = 0; i < TM; ++i) af[set][i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * BKL + ch);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * BK + ch);
+    for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * BKL + ch);
   };
   auto mma = [&](int set) {
     __builtin_amdgcn_s_setprio(1);
+    if (PR) {
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[set][i]),
+                                                              __builtin_bit_cast(bf16x8, bf[set][j]), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -241,8 +271,8 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
     __builtin_amdgcn_s_setprio(0);
   };
   auto extra = [&](int slot) {  // each b128 holds k = 4Q..4Q+3 of one row; MFMA e of read u contracts k = {4(g + 4u) + e}
-    const float* xA = sA + slot * BMT * BK + xra * BK;
-    const float* xB = sB + slot * BN * BK + xrb * BK;
+    const float* xA = sA + slot * BMT * BKL + xra * BKL;
+    const float* xB = sB + slot * BN * BKL + xrb * BKL;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const f32x4 fa = *reinterpret_cast<const f32x4*>(xA + (((xg + 4 * u) ^ ((xra >> 1) & 7)) * 4));
@@ -257,6 +287,14 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
     swrite(nslot, ra_next, rb_next);          // chunk kc + KS (zeros past the end of the range: never multiplied)
     gload(kc + 3 * KS, ra_free, rb_free);
     const bool live = kc < kc_end;            // wave-uniform
+    if (NS == 2) {  // bf16: two MFMA sub-steps per chunk
+      frag(slot, 1, 1);
+      if (live) mma(0);
+      __syncthreads();
+      frag(nslot, 0, 0);
+      if (live) mma(1);
+      return;
+    }
     frag(slot, 1, 1);
     if (live) mma(0);
     frag(slot, 2, 0);
@@ -469,9 +507,9 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int XR>
+template <int BM, int BN, int WM, int WN, int KS, int XR, int PR>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KS) void gconv_kernel(const GArgs a) {
-  gconv_body<BM, BN, WM, WN, KS, XR>(a, blockIdx.x);
+  gconv_body<BM, BN, WM, WN, KS, XR, PR>(a, blockIdx.x);
 }
 
 // several independent gather-GEMMs in one launch: the stride-parity classes of a strided data
@@ -486,7 +524,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_multi_kernel
   int ci = 0;
   while (ci + 1 < m.n && (int)blockIdx.x >= m.first[ci + 1]) ++ci;
   const GArgs a = m.g[ci];
-  gconv_body<BM, BN, WM, WN, 1, XR>(a, blockIdx.x - m.first[ci]);
+  gconv_body<BM, BN, WM, WN, 1, XR, 0>(a, blockIdx.x - m.first[ci]);
 }
 
 // finishes the K-split tail tiles: out = act(sum_z partial[z] + bias) and, when asked, the tile's
@@ -824,6 +862,7 @@ int check_desc(const srx_conv2d_t* d) {
     SRX_REQUIRE(d->Cout_s >= d->Cout && d->Cout_s % 4 == 0, "conv2d: Cout_s must be a multiple of 4 and >= Cout");
   }
   SRX_REQUIRE(d->act == SRX_ACT_NONE || d->act == SRX_ACT_RELU || d->act == SRX_ACT_LRELU, "conv2d: bad act");
+  SRX_REQUIRE(d->precision == 0 || d->precision == 1, "conv2d: precision must be 0 (fp32) or 1 (bf16 products)");
   const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
   SRX_REQUIRE(Ho > 0 && Wo > 0, "conv2d: empty output");
   SRX_REQUIRE((int64_t)d->N * d->H * d->W < (1 << 24) && (int64_t)d->N * Ho * Wo < (1 << 24),
@@ -904,7 +943,7 @@ int device_cus() {
   return cus;
 }
 
-Plan make_plan(int M, int Cnp, int kchunks, bool can_split) {
+Plan make_plan(int M, int Cnp, int kchunks, bool can_split, bool bf16 = false) {
   const int P = device_cus();
   constexpr int NC = 6;
   const int cand[NC][2] = {{144, 128}, {144, 64}, {128, 128}, {128, 64}, {64, 64}, {128, 32}};
@@ -913,6 +952,7 @@ Plan make_plan(int M, int Cnp, int kchunks, bool can_split) {
   best.cost = 1e30f;
   for (int i = 0; i < NC; ++i) {
     const int bm = cand[i][0], bn = cand[i][1];
+    if (bf16 && bm == 144) continue;
     if (Cnp == 32) { if (bn != 32) continue; }
     else if (bn == 32 || Cnp % bn != 0) continue;
     Plan p{};
@@ -959,23 +999,24 @@ Plan make_plan(int M, int Cnp, int kchunks, bool can_split) {
 
 size_t plan_ws_floats(const Plan& p) { return p.split > 1 ? (size_t)p.tail * p.split * p.BM * p.BN : 0; }
 
-template <int BM, int BN, int WM, int WN, int KS, int XR>
+template <int BM, int BN, int WM, int WN, int KS, int XR, int PR = 0>
 int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
   const int ktab_chunks = p.full > 0 || p.split == 1 ? a.kchunks : p.kc_per_split;
-  const size_t lds = (size_t)(KS * 3 * (BM + XR + BN) * BK) * sizeof(float) + (size_t)ktab_chunks * 8 * sizeof(int2);
+  const size_t lds = (size_t)(KS * 3 * (BM + XR + BN) * BK) * (PR ? 2 : 4) + (size_t)ktab_chunks * 8 * sizeof(int2);
   if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN, KS, XR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN, KS, XR, PR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(p.full + p.tail * p.split);
   if (srx_prof_on()) {
     char nm[64];
-    snprintf(nm, sizeof(nm), "gconv_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, KS, XR);
+    snprintf(nm, sizeof(nm), PR ? "gconv_kernel<%d, %d, %d, %d, %d, %d, 1>" : "gconv_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, WM,
+             WN, KS, XR);
     srx_prof_begin_launch(nm, 2.0 * a.M * a.Cn * a.K, st);
   }
-  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN, KS, XR>), grid, dim3((BM / WM) * (BN / WN) * 64 * KS), lds, st, a);
+  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN, KS, XR, PR>), grid, dim3((BM / WM) * (BN / WN) * 64 * KS), lds, st, a);
   if (srx_prof_on()) srx_prof_end_launch(st);
   SRX_CHECK_LAUNCH("gconv_kernel");
   if (p.split > 1) {
@@ -1071,7 +1112,7 @@ int run_gconv_multi(GMulti& m, int BM, int BN, hipStream_t st) {
   return launch_gconv_multi<128, 32, 32, 32, 0>(m, lds, st);
 }
 
-int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t st) {
+int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t st, int precision = 0) {
   a.kchunks = a.Kp / BK;
   const size_t need = plan_ws_floats(p);
   if (need && (!ws || need > ws_floats))
@@ -1082,6 +1123,14 @@ int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t 
   a.full_tiles = p.full;
   a.tail_split = p.split;
   a.ws = ws;
+  if (precision) {  // bf16 products (plans made with `bf16 = true` never ask for the 144-row tiles)
+    if (p.BM == 128 && p.BN == 128) return launch_gconv<128, 128, 64, 32, 1, 0, 1>(a, p, st);
+    if (p.BM == 128 && p.BN == 64) return launch_gconv<128, 64, 32, 32, 1, 0, 1>(a, p, st);
+    if (p.BM == 64 && p.BN == 64)
+      return p.ks == 2 ? launch_gconv<64, 64, 32, 32, 2, 0, 1>(a, p, st) : launch_gconv<64, 64, 32, 32, 1, 0, 1>(a, p, st);
+    if (p.BM == 128 && p.BN == 32) return launch_gconv<128, 32, 32, 32, 1, 0, 1>(a, p, st);
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: no bf16 kernel for tile %dx%d", p.BM, p.BN);
+  }
   if (p.BM == 144 && p.BN == 128) return launch_gconv<128, 128, 64, 32, 1, 16>(a, p, st);
   if (p.BM == 144 && p.BN == 64) return launch_gconv<128, 64, 32, 32, 1, 16>(a, p, st);
   if (p.BM == 128 && p.BN == 128) return launch_gconv<128, 128, 64, 32, 1, 0>(a, p, st);
@@ -1098,11 +1147,11 @@ void set_mgrid(GArgs& a, int N, int Hm, int Wm) {
 }
 
 Plan fwd_plan(const srx_conv2d_t* d, const Geo& g) {
-  return make_plan(d->N * g.Ho * g.Wo, g.Cnp, g.Kp / BK, !d->shuffle);
+  return make_plan(d->N * g.Ho * g.Wo, g.Cnp, g.Kp / BK, !d->shuffle, d->precision != 0);
 }
 
 Plan bwd_plan(const srx_conv2d_t* d, const BwdClass& c) {
-  return make_plan(d->N * c.Hm * c.Wm, pad_rows(d->Cin), c.Kp / BK, d->stride == 1);
+  return make_plan(d->N * c.Hm * c.Wm, pad_rows(d->Cin), c.Kp / BK, d->stride == 1, d->precision != 0);
 }
 
 int stat_rows_for(const srx_conv2d_t* d) {
@@ -1264,7 +1313,7 @@ extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float
   a.out = y;
   a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin_s * sizeof(float));
   a.w_bytes = (unsigned)((size_t)g.Cnp * g.Kp * sizeof(float));
-  return run_gconv(a, fwd_plan(d, g), ws, ws_floats, st);
+  return run_gconv(a, fwd_plan(d, g), ws, ws_floats, st, d->precision);
 }
 
 extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
@@ -1313,7 +1362,7 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     a.w_bytes = (unsigned)((size_t)pad_rows(d->Cin) * c.Kp * sizeof(float));
     a.accum = accumulate;
     if (d->stride == 1) {
-      if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st)) return rc;
+      if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st, d->precision)) return rc;
     } else if (nc <= 4) {
       multi.g[multi.n++] = a;
     } else {  // stride > 2: one launch per class

@@ -203,7 +203,7 @@ size_t lds_bytes(int W) {  // every thread stores all its NB * PB slots: size fo
 extern "C" int srx_device_cus(void);
 
 bool srx_rt36_applicable(const srx_conv2d_t* d) {
-  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->shuffle || d->up) return false;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->shuffle || d->up || d->precision) return false;
   if (d->Cin != 64 || d->Cout != 64 || d->Cin_s != 64 || d->Cout_s != 64) return false;
   const int64_t hw = (int64_t)d->H * d->W, m = hw * d->N;
   if (hw % RT != 0 || d->W < 3) return false;

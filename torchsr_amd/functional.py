@@ -149,16 +149,17 @@ class ConvState:
         self.cin_s = round4(cin)
         self.cout_s = round4(cout // 4) if shuffle else round4(cout)
         self._descs = {}
+        self.precision = 0  # 1: bf16 products in the forward / stride-1 data gradient (srx_conv2d_t::precision)
         self.wpk_fwd = None
         self.wpk_bwd = None
         self._key = None
 
     def desc(self, n, h, w) -> Conv2dDesc:
-        d = self._descs.get((n, h, w))
+        d = self._descs.get((n, h, w, self.precision))
         if d is None:
             d = Conv2dDesc(n, h, w, self.cin, self.cin_s, self.cout, self.cout_s, self.k, self.k, self.stride,
-                           self.pad, self.shuffle, self.act, self.slope, 0)
-            self._descs[(n, h, w)] = d
+                           self.pad, self.shuffle, self.act, self.slope, 0, self.precision)
+            self._descs[(n, h, w, self.precision)] = d
         return d
 
     def out_shape(self, n, h, w):
@@ -732,7 +733,7 @@ class _DenseBlock(Function):
             cin = c0 + k * g
             last = k == 4
             d = Conv2dDesc(n, h, w, cin, total, st.cout, st.cout if last else total, st.k, st.k, st.stride, st.pad, 0,
-                           st.act, st.slope, 0)
+                           st.act, st.slope, 0, st.precision)
             descs.append(d)
             dref = C.byref(d)
             st.pack(masters[k], d)

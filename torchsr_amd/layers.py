@@ -70,6 +70,16 @@ class Conv2d(nn.Conv2d):
         return new
 
 
+def set_conv_precision(module: nn.Module, precision: str) -> None:
+    """``'bf16'``: every conv of ``module`` multiplies bf16-rounded operands and accumulates in fp32 (forward
+    and stride-1 data gradient) -- this package's reading of the reference's ``autocast`` region
+    (srgan/trainer.py:379-383).  ``'fp32'`` restores exact fp32."""
+    p = {'fp32': 0, 'bf16': 1}[precision]
+    for m in module.modules():
+        if isinstance(m, Conv2d):
+            m._st.precision = p
+
+
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d parameter holder; applied through ``functional.bn_act``."""
 

@@ -62,7 +62,11 @@ class SRGANTrainer:
 
     def __init__(self, device, args: Namespace, train_loader, test_loader, train_len: int, test_len: int,
                  distributed: bool = False) -> None:
-        self.amp = not args.disable_amp  # accepted; the MI355X path is exact fp32 in both phases
+        # The reference wraps its forward passes in torch.cuda.amp.autocast unless --disable-amp is given
+        # (trainer.py:379-383,438-462).  Here that selects bf16 products with fp32 accumulation in every
+        # convolution (forward + stride-1 data gradient, srx_conv2d_t::precision); tensors, BatchNorm, the
+        # losses, the weight gradients and Adam stay fp32, so no GradScaler is needed.
+        self.amp = not args.disable_amp
         self.batch_size = args.batch_size
         self.best_psnr = -1.0
         self.device = torch.device(device)
@@ -109,6 +113,10 @@ class SRGANTrainer:
         self._initialize_models()
         self._initialize_loss()
         self._initialize_optimizers()
+        if self.amp:
+            from ..layers import set_conv_precision
+            for module in (self.generator, self.discriminator, self.vgg_loss):
+                set_conv_precision(module, 'bf16')
 
     def _initialize_models(self) -> None:
         """trainer.py:136-157.  DDP wrapping is replaced by flat buffers + explicit all-reduce."""
