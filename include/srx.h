@@ -91,8 +91,8 @@ typedef struct srx_conv2d {
   int32_t precision;  /* 0: exact fp32 MFMAs.  1: bf16 products with fp32 accumulation for the forward
                          and the stride-1 data gradient -- the reference's torch.cuda.amp.autocast
                          region (srgan/trainer.py:379-383, esrgan/trainer.py:418-484); tensors stay
-                         fp32 in memory, operands are rounded when staged into LDS; the weight
-                         gradient and strided data gradients remain fp32 */
+                         fp32 in memory, operands are rounded when staged into LDS; strided data
+                         gradients and the 3-channel (thin) layers remain fp32 */
 } srx_conv2d_t;
 
 /* sizes (in floats) of the packed weight copies and of scratch buffers */

@@ -610,9 +610,15 @@ struct WArgs {
   int s_c, s_rm, dX0, dX1, dX2, dD0, dD1;
 };
 
+// PR = 1: bf16 products (the autocast mode).  The contraction runs over pixels, so an MFMA operand is eight
+// CONSECUTIVE ROWS of one column.  A thread therefore loads two adjacent rows (2 r0, 2 r0 + 1), rounds them
+// to bf16 and stores them interleaved -- one 32-bit word per (row pair, column) -- so that a lane collects
+// its eight rows as four words; two v_mfma_f32_32x32x16_bf16 per chunk replace sixteen fp32 MFMAs.
+template <int PR>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
-  __shared__ __attribute__((aligned(16))) float sD[2][32 * 64];
-  __shared__ __attribute__((aligned(16))) float sX[2][32 * 64];
+  constexpr int LROWS = PR ? 16 : 32;  // LDS rows per chunk (row pairs for bf16)
+  __shared__ __attribute__((aligned(16))) float sD[2][LROWS * 64];
+  __shared__ __attribute__((aligned(16))) float sX[2][LROWS * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
   const int ntile = srx_uniform(blockIdx.x / a.ktiles), kt = blockIdx.x - ntile * a.ktiles;
   const int k0 = kt * 64, n0 = ntile * 64;
@@ -646,13 +652,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
   // Four register stages: a workgroup that is alone on its CU (small layers: one row split per CU)
   // multiplies a chunk in ~0.45 us but waits ~2 us for a load, so chunk c+4 is requested while c runs.
   f32x4 rd0[2], rx0[2], rd1[2], rx1[2], rd2[2], rx2[2], rd3[2], rx3[2];
-  // row state of this thread's two rows (r0 + 16p of the current chunk); chunks are requested strictly in
-  // order, so every gload advances the state by one chunk
+  // row state of this thread's two rows (r0 + 16p of the current chunk; 2 r0 + p for bf16); chunks are
+  // requested strictly in order, so every gload advances the state by one chunk
   int rm[2], rmh[2], rmw[2];
   unsigned rox[2], rod[2];  // element offsets: x at (n, mh*stride + dh, mw*stride + dw, kc); dy at the thread's column
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    const int m = mbeg + r0 + 16 * p;
+    const int m = PR ? mbeg + 2 * r0 + p : mbeg + r0 + 16 * p;
     int n, rem, mh, mw;
     srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
     srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
@@ -680,6 +686,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
     }
   };
   auto swrite = [&](int buf, const f32x4 (&rd)[2], const f32x4 (&rx)[2]) {
+    if (PR) {  // word (pair row r0, column 4q + e) = (bf16 of row 2 r0, bf16 of row 2 r0 + 1)
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 wd, wx;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bf16x2 pd = {(__bf16)rd[0][e], (__bf16)rd[1][e]}, px = {(__bf16)rx[0][e], (__bf16)rx[1][e]};
+        wd[e] = __builtin_bit_cast(unsigned, pd);
+        wx[e] = __builtin_bit_cast(unsigned, px);
+      }
+      *reinterpret_cast<u32x4*>(&sD[buf][r0 * 64 + q * 4]) = wd;
+      *reinterpret_cast<u32x4*>(&sX[buf][r0 * 64 + q * 4]) = wx;
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       *reinterpret_cast<f32x4*>(&sD[buf][(r0 + 16 * p) * 64 + q * 4]) = rd[p];
@@ -694,6 +714,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
   const int wn = wave >> 1, wk = wave & 1;
 
   auto compute = [&](int buf) {
+    if (PR) {  // MFMA s takes rows 16 s + 8 h .. + 7 = pair rows 8 s + 4 h + {0..3}
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      const float* cD = &sD[buf][4 * h * 64 + wn * 32 + l31];
+      const float* cX = &sX[buf][4 * h * 64 + wk * 32 + l31];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f32x4 fd, fx;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { fd[t] = cD[(8 * s + t) * 64]; fx[t] = cX[(8 * s + t) * 64]; }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc, 0,
+                                                      0, 0);
+      }
+      return;
+    }
     const float* cD = &sD[buf][h * 64 + wn * 32 + l31];
     const float* cX = &sX[buf][h * 64 + wk * 32 + l31];
 #pragma unroll
@@ -1440,8 +1474,9 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
   const size_t need = (size_t)nsplit * a.Cnw * a.Kw;
   if (need > ws_floats) SRX_FAIL(SRX_E_WORKSPACE, "conv2d_bwd_weight: workspace %zu < %zu floats", ws_floats, need);
   dim3 grid((unsigned)tiles, 1, nsplit);
-  if (srx_prof_on()) srx_prof_begin_launch("wgrad_kernel", 2.0 * a.M * d->Cout * a.K, st);
-  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, a);
+  if (srx_prof_on()) srx_prof_begin_launch(d->precision ? "wgrad_kernel<1>" : "wgrad_kernel<0>", 2.0 * a.M * d->Cout * a.K, st);
+  if (d->precision) hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wgrad_kernel<0>, grid, dim3(256), 0, st, a);
   if (srx_prof_on()) srx_prof_end_launch(st);
   SRX_CHECK_LAUNCH("wgrad_kernel");
   const int64_t n = (int64_t)d->Cout * g.K;

@@ -286,7 +286,7 @@ int thin_ranges(int nseg, int groups) {
 }  // namespace
 
 // ---- internal entry points used by gconv.hip's C ABI functions ------------------------------------
-bool srx_thin_wgrad_applicable(const srx_conv2d_t* d) {  // (the weight gradient is fp32 at either precision)
+bool srx_thin_wgrad_applicable(const srx_conv2d_t* d) {  // (the 3-channel layers are fp32 at either precision)
   if (d->stride != 1 || d->shuffle || d->KH != d->KW || (d->KH != 3 && d->KH != 9) || d->pad != (d->KH - 1) / 2)
     return false;
   const bool thin_out = d->Cout <= 4 && d->Cout_s == 4 && d->Cin == 64 && d->Cin_s == 64;
