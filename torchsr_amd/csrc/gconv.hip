@@ -979,9 +979,11 @@ int device_cus() {
 
 Plan make_plan(int M, int Cnp, int kchunks, bool can_split, bool bf16 = false) {
   const int P = device_cus();
-  constexpr int NC = 6;
-  const int cand[NC][2] = {{144, 128}, {144, 64}, {128, 128}, {128, 64}, {64, 64}, {128, 32}};
-  const float eff[NC] = {0.91f, 0.82f, 0.95f, 0.85f, 0.60f, 0.50f};  // measured MFMA efficiency of each tile in steady state
+  constexpr int NC = 7;
+  // (64, 32): narrow layers (the 32-channel growth convs of ESRGAN's dense blocks) on twice as many tiles, the
+  // k-chunks of each tile split over 2 (fp32) / 4 (bf16) wave groups inside the workgroup -- no fix-up pass
+  const int cand[NC][2] = {{144, 128}, {144, 64}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 32}};
+  const float eff[NC] = {0.91f, 0.82f, 0.95f, 0.85f, 0.60f, 0.50f, 0.50f};  // measured MFMA efficiency in steady state
   Plan best{};
   best.cost = 1e30f;
   for (int i = 0; i < NC; ++i) {
@@ -1023,11 +1025,13 @@ Plan make_plan(int M, int Cnp, int kchunks, bool can_split, bool bf16 = false) {
       if (sp > 1 && can_split) { p.full = 0; p.tail = p.tiles; p.kc_per_split = (int)srx_cdiv(kchunks, sp); p.split = (int)srx_cdiv(kchunks, p.kc_per_split); }
       else { p.full = p.tiles; p.tail = 0; p.split = 1; p.kc_per_split = kchunks; }
       p.ks = (bm == 64 && bn == 64 && ks == 2) ? 2 : 1;
+      if (bm == 64 && bn == 32) p.ks = bf16 ? 4 : 2;
       return p;
     }
   }
   // fewer workgroups than CUs and a 4-wave tile: split its k-chunks over two wave groups (KS = 2)
   best.ks = (best.BM == 64 && best.BN == 64 && best.full + best.tail * best.split <= P && best.kc_per_split >= 4) ? 2 : 1;
+  if (best.BM == 64 && best.BN == 32) best.ks = bf16 ? 4 : 2;
   return best;
 }
 
@@ -1163,6 +1167,7 @@ int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t 
     if (p.BM == 64 && p.BN == 64)
       return p.ks == 2 ? launch_gconv<64, 64, 32, 32, 2, 0, 1>(a, p, st) : launch_gconv<64, 64, 32, 32, 1, 0, 1>(a, p, st);
     if (p.BM == 128 && p.BN == 32) return launch_gconv<128, 32, 32, 32, 1, 0, 1>(a, p, st);
+    if (p.BM == 64 && p.BN == 32) return launch_gconv<64, 32, 32, 32, 4, 0, 1>(a, p, st);
     SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: no bf16 kernel for tile %dx%d", p.BM, p.BN);
   }
   if (p.BM == 144 && p.BN == 128) return launch_gconv<128, 128, 64, 32, 1, 16>(a, p, st);
@@ -1171,6 +1176,7 @@ int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t 
   if (p.BM == 128 && p.BN == 64) return launch_gconv<128, 64, 32, 32, 1, 0>(a, p, st);
   if (p.BM == 64 && p.BN == 64)
     return p.ks == 2 ? launch_gconv<64, 64, 32, 32, 2, 0>(a, p, st) : launch_gconv<64, 64, 32, 32, 1, 0>(a, p, st);
+  if (p.BM == 64 && p.BN == 32) return launch_gconv<64, 32, 32, 32, 2, 0>(a, p, st);
   return launch_gconv<128, 32, 32, 32, 1, 0>(a, p, st);
 }
 
