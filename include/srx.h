@@ -128,10 +128,11 @@ int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float* wpk_fwd, 
 int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
                         int accumulate, float* ws, size_t ws_floats, void* stream);
 /* dw (OIHW) = autograd of nn.Conv2d wrt its weight; accumulate != 0 adds into dw (a .grad buffer)
- * instead of overwriting it.  The same flag exists on srx_colsum, srx_linear_bwd_weight,
+ * instead of overwriting it.  db (may be NULL; not for shuffle layers) receives the bias gradient
+ * sum_m dy[m][co] under the same flag: the kernel stages every dy row anyway.  The same flag exists on srx_colsum, srx_linear_bwd_weight,
  * srx_prelu_bwd; srx_bn_act_bwd_reduce takes optional accumulation targets. */
 int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, const float* dy, float* dw_oihw,
-                          int accumulate, float* ws, size_t ws_floats, void* stream);
+                          int accumulate, float* db, float* ws, size_t ws_floats, void* stream);
 
 /* ------------------------------------------------- elementwise / reductions */
 /* out[c] = sum_m x[m][c]  (bias gradient of Conv2d / Linear); ws >= 2*rows*C floats */

@@ -56,7 +56,7 @@ if 'pretrain' in which:
 if 'esrgan' in which:
     from torchsr_amd.esrgan.trainer import ESRGANTrainer
     torch.manual_seed(0)
-    for amp in (False, True):
+    for amp in ((True,) if 'amp-only' in which else (False, True)):
         torch.manual_seed(0)
         t = ESRGANTrainer(dev, targs(16, amp), [], [], 16, 16)
         lr, hr = batch(16, 128)

@@ -71,7 +71,7 @@ _SIGS = {
     'srx_conv2d_pack': (_I, [_D, _P, _P, _P, _P]),
     'srx_conv2d_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_data': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
-    'srx_conv2d_bwd_weight': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
+    'srx_conv2d_bwd_weight': (_I, [_D, _P, _P, _P, _I, _P, _P, _Z, _P]),
     'srx_colsum_ws_floats': (_Z, [_L, _I]),
     'srx_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     'srx_crop_flip_u8': (_I, [_P, _P, _P, _I, _I, _P]),

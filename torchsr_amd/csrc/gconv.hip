@@ -608,6 +608,10 @@ struct WArgs {
   //   s_c = 32 % Wm, s_rm = (32 / Wm) % Hm; dX0/dD0 plain step, dX1/dD1 extra on a column wrap
   //   (mw -= Wm, mh += 1), dX2 extra on a row wrap (mh -= Hm, next image)
   int s_c, s_rm, dX0, dX1, dX2, dD0, dD1;
+  // bias gradient db[n] = sum_m dy[m][n]: the k-tile-0 workgroups already stage every dy row of their
+  // row split, so they add the column sums up on the way and write one [Cnw] row per split here
+  // (null: not wanted); wgrad_reduce_kernel sums the rows.  Replaces two column-sum launches per layer.
+  float* bslab;
 };
 
 // PR = 1: bf16 products (the autocast mode).  The contraction runs over pixels, so an MFMA operand is eight
@@ -685,7 +689,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
       rox[p] += wr ? (unsigned)a.dX2 : 0u;
     }
   };
+  const bool want_bias = a.bslab != nullptr && kt == 0;  // workgroup-uniform
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   auto swrite = [&](int buf, const f32x4 (&rd)[2], const f32x4 (&rx)[2]) {
+    if (want_bias) bsum += rd[0] + rd[1];  // (fp32 values, whatever the product precision)
     if (PR) {  // word (pair row r0, column 4q + e) = (bf16 of row 2 r0, bf16 of row 2 r0 + 1)
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -766,13 +773,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
     const int row = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
     slab[(size_t)row * a.Kw + k0 + wk * 32 + l31] = acc[r];
   }
+  if (want_bias) {  // 16 row lanes x 16 column quads -> 64 column sums of this row split
+    f32x4* red = reinterpret_cast<f32x4*>(&sD[0][0]);  // (the loop ended on a barrier: the buffers are free)
+    red[r0 * 16 + q] = bsum;
+    __syncthreads();
+    if (tid < 16) {
+      f32x4 t = red[tid];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) t += red[r * 16 + tid];
+      *reinterpret_cast<f32x4*>(a.bslab + (size_t)blockIdx.z * a.Cnw + n0 + 4 * tid) = t;
+    }
+  }
 }
 
 // slab sums -> OIHW gradient
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int Cnw, int Kw, int K, int Ck,
                                     int Cout, int Cin, int KH, int KW, int shuffle_cps, float* __restrict__ dw,
-                                    int accumulate) {
+                                    int accumulate, const float* __restrict__ bslab, float* __restrict__ db) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (db && idx < Cout) {  // bias gradient: the row splits' column sums (the grid has >= Cout threads)
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += bslab[(size_t)z * Cnw + idx];
+    db[idx] = accumulate ? db[idx] + s : s;
+  }
   if (idx >= (int64_t)Cout * K) return;
   const int np = (int)(idx / K), k = (int)(idx - (int64_t)np * K);
   const int tap = k / Ck, ci = k - tap * Ck;
@@ -1235,10 +1258,11 @@ extern "C" size_t srx_conv2d_bwd_data_ws_floats(const srx_conv2d_t* d) {
 
 extern "C" size_t srx_conv2d_bwd_weight_ws_floats(const srx_conv2d_t* d) {
   if (check_desc(d)) return 0;
-  if (srx_thin_wgrad_applicable(d)) return srx_thin_wgrad_ws_floats(d);
+  if (srx_thin_wgrad_applicable(d))  // + the column-sum scratch of an optional bias gradient
+    return srx_thin_wgrad_ws_floats(d) + srx_colsum_ws_floats((int64_t)d->N * d->H * d->W, d->Cout);
   const Geo g = fwd_geo(d);
   const size_t Cnw = (size_t)srx_roundup(d->Cout, 64), Kw = (size_t)srx_roundup(g.K, 64);
-  return Cnw * Kw * 64;  // up to 64 row splits
+  return Cnw * (Kw + 1) * 64;  // up to 64 row splits (+ one bias row each)
 }
 
 extern "C" int srx_conv2d_stat_rows(const srx_conv2d_t* d) {
@@ -1417,12 +1441,24 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
   return SRX_OK;
 }
 
+extern "C" int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, int accumulate, float* ws,
+                          size_t ws_floats, void* stream);
+extern "C" size_t srx_colsum_ws_floats(int64_t M, int C);
+
 extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, const float* dy, float* dw, int accumulate,
-                                     float* ws, size_t ws_floats, void* stream) {
+                                     float* db, float* ws, size_t ws_floats, void* stream) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(x && dy && dw && ws, "conv2d_bwd_weight: null pointer");
+  if (db && d->shuffle) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_weight: bias gradient of a PixelShuffle layer is not fused");
   hipStream_t st = srx_stream(stream);
-  if (srx_thin_wgrad_applicable(d)) return srx_thin_wgrad(d, x, dy, dw, accumulate, ws, ws_floats, st);
+  if (srx_thin_wgrad_applicable(d)) {
+    const size_t thin_ws = srx_thin_wgrad_ws_floats(d);
+    if (int rc = srx_thin_wgrad(d, x, dy, dw, accumulate, ws, ws_floats, st)) return rc;
+    if (!db) return SRX_OK;
+    const int64_t m = (int64_t)d->N * d->H * d->W;  // thin layers are stride 1, same size
+    SRX_REQUIRE(ws_floats >= thin_ws + srx_colsum_ws_floats(m, d->Cout), "conv2d_bwd_weight: workspace too small");
+    return srx_colsum(dy, db, m, d->Cout, d->Cout_s, accumulate, ws + thin_ws, ws_floats - thin_ws, stream);
+  }
   const Geo g = fwd_geo(d);
   WArgs a{};
   a.in = x; a.dy = dy; a.slab = ws;
@@ -1477,8 +1513,9 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
   if (const char* e = getenv("SRX_WGRAD_NSPLIT")) { const int v = atoi(e); if (v > 0 && v <= 64) nsplit = v; }
   a.rows_per_split = (int)srx_roundup(srx_cdiv(a.M, nsplit), 32);
   nsplit = (int)srx_cdiv(a.M, a.rows_per_split);
-  const size_t need = (size_t)nsplit * a.Cnw * a.Kw;
+  const size_t need = (size_t)nsplit * a.Cnw * a.Kw + (db ? (size_t)nsplit * a.Cnw : 0);
   if (need > ws_floats) SRX_FAIL(SRX_E_WORKSPACE, "conv2d_bwd_weight: workspace %zu < %zu floats", ws_floats, need);
+  a.bslab = db ? ws + (size_t)nsplit * a.Cnw * a.Kw : nullptr;
   dim3 grid((unsigned)tiles, 1, nsplit);
   if (srx_prof_on()) srx_prof_begin_launch(d->precision ? "wgrad_kernel<1>" : "wgrad_kernel<0>", 2.0 * a.M * d->Cout * a.K, st);
   if (d->precision) hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, st, a);
@@ -1487,7 +1524,7 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
   SRX_CHECK_LAUNCH("wgrad_kernel");
   const int64_t n = (int64_t)d->Cout * g.K;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, st, ws, nsplit, a.Cnw, a.Kw,
-                     g.K, g.Ck, d->Cout, d->Cin, d->KH, d->KW, g.cps, dw, accumulate);
+                     g.K, g.Ck, d->Cout, d->Cin, d->KH, d->KW, g.cps, dw, accumulate, a.bslab, db);
   SRX_CHECK_LAUNCH("wgrad_reduce_kernel");
   return SRX_OK;
 }

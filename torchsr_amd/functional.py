@@ -249,25 +249,36 @@ class _Conv2d(Function):
             ws = _ws(nws, x) if nws else None
             call('srx_conv2d_bwd_data', dref, _p(dy), _p(ctx.wpk_bwd), _p(dx), 0, _p(ws), nws, s)
         wparam, bparam = ctx.params
+        bias_done = False
         if ctx.needs_input_grad[1]:
             sink = _sink(wparam)
             dw = None if sink is not None else torch.empty((st.cout, st.cin, st.k, st.k), dtype=torch.float32,
                                                              device=x.device)
+            # the bias gradient rides along in the weight-gradient kernel (it stages every dy row anyway)
+            # when both results go the same way: both accumulated into .grad, or both returned
+            bptr = None
+            if ctx.has_bias and ctx.needs_input_grad[2] and not st.shuffle:
+                bsink = _sink(bparam)
+                if (bsink is None) == (sink is None):
+                    if bsink is None:
+                        db = torch.empty(st.cout, dtype=torch.float32, device=x.device)
+                    bptr = _p(db if bsink is None else bsink)
+                    bias_done = True
             nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
             if sink is not None and side_stream_enabled[0]:
                 main, side = torch.cuda.current_stream(), side_stream(x.device.index)
                 side.wait_stream(main)          # dy (and x) are complete on the main stream
                 with torch.cuda.stream(side):
                     ws = _ws(nws, x)
-                    call('srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(sink), 1, _p(ws), nws,
+                    call('srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(sink), 1, bptr, _p(ws), nws,
                                side.cuda_stream)
                 x.record_stream(side)
                 dy.record_stream(side)
             else:
                 ws = _ws(nws, x)
                 call('srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw if sink is None else sink),
-                           0 if sink is None else 1, _p(ws), nws, s)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+                           0 if sink is None else 1, bptr, _p(ws), nws, s)
+        if ctx.has_bias and ctx.needs_input_grad[2] and not bias_done:
             sink = None if st.shuffle else _sink(bparam)
             if sink is not None:
                 m = dy.numel() // st.cout_s
@@ -778,15 +789,24 @@ class _DenseBlock(Function):
                 call('srx_act_bwd_from_out_strided', gk, total, buf.data_ptr() + 4 * cin, total, gk, total, m, g,
                      st.act, st.slope, s)
             wparam, bparam = ctx.params[2 * k], ctx.params[2 * k + 1]
+            bias_done = False
             if ctx.needs_input_grad[4 + 2 * k]:
                 sink = _sink(wparam)
                 dw = None if sink is not None else torch.empty((st.cout, st.cin, st.k, st.k), dtype=torch.float32,
                                                                  device=dev)
+                bptr = None
+                if bparam is not None and ctx.needs_input_grad[5 + 2 * k]:  # bias gradient in the same kernel
+                    bsink = _sink(bparam)
+                    if (bsink is None) == (sink is None):
+                        if bsink is None:
+                            grads[2 * k + 1] = torch.empty(st.cout, dtype=torch.float32, device=dev)
+                        bptr = _p(grads[2 * k + 1] if bsink is None else bsink)
+                        bias_done = True
                 nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
                 call('srx_conv2d_bwd_weight', dref, _p(buf), gk, _p(dw if sink is None else sink),
-                     0 if sink is None else 1, _p(_ws(nws, dy)), nws, s)
+                     0 if sink is None else 1, bptr, _p(_ws(nws, dy)), nws, s)
                 grads[2 * k] = dw
-            if bparam is not None and ctx.needs_input_grad[5 + 2 * k]:
+            if bparam is not None and ctx.needs_input_grad[5 + 2 * k] and not bias_done:
                 sink = _sink(bparam)
                 db = None if sink is not None else torch.empty(st.cout, dtype=torch.float32, device=dev)
                 nws = L.srx_colsum_ws_floats(m, st.cout)
