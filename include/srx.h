@@ -116,6 +116,15 @@ int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out);
  * taps flipped, [Cin_p][K'_p], K'=(tap,co)). */
 int srx_conv2d_pack(const srx_conv2d_t* d, const float* w_oihw, float* wpk_fwd, float* wpk_bwd, void* stream);
 
+/* The same for every conv of a model in ONE launch (after an optimiser step): build fills a host buffer of
+ * srx_pack_table_bytes(n) bytes with one record per packed operand; the caller keeps a copy of it in
+ * device memory (all pointers and sizes in it are fixed) and replays it with srx_pack_table_run.
+ * wpk_bwd[i] may be NULL (layer whose input needs no gradient). */
+size_t srx_pack_table_bytes(int n_layers);
+int srx_pack_table_build(const srx_conv2d_t* descs, int n, const float* const* w_oihw, float* const* wpk_fwd,
+                         float* const* wpk_bwd, void* host_table, int* n_records, long long* max_elems);
+int srx_pack_table_run(const void* dev_table, int n_records, long long max_elems, void* stream);
+
 /* y = act(conv(x, W) + bias).  bias may be NULL.  bn_partials may be NULL; when
  * given it receives per-row-block sums for the training-mode BatchNorm that
  * follows (srgan/residual.py:65,68; srgan/discriminator.py:36-60). */

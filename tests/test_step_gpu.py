@@ -120,6 +120,23 @@ def test_graph_replay_equals_eager(dev):
         assert torch.allclose(tg.generator(lr), te.generator(lr), rtol=1e-4, atol=1e-5)
 
 
+def test_pack_tables_take_over_after_the_first_step(dev):
+    """After the first optimiser step every conv of G / D is repacked by one table launch per model
+    (functional.PackTable) and the lazy per-layer pack finds its key current."""
+    gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
+    lr, hr = torch.from_numpy(gold['low_res']).to(dev), torch.from_numpy(gold['high_res']).to(dev)
+    t = make_trainer(dev, use_graphs=False)
+    t.gan_step(lr, hr)
+    from torchsr_amd import functional as F
+    from torchsr_amd.layers import Conv2d
+    for opt, model in ((t.gen_optimizer, t.generator), (t.disc_optimizer, t.discriminator)):
+        assert opt.pack_table.table is not None and opt.pack_table.nrec >= len(opt.pack_table.items)
+        for m in model.modules():
+            if isinstance(m, Conv2d):
+                assert m._st._key == m._st.pack_key(m.weight)
+    assert t.psnr_optimizer.pack_table is t.gen_optimizer.pack_table
+
+
 def test_segmented_step_equals_fused(dev):
     """The 4-segment step used under data parallelism (all-reduce between segments) computes the same
     thing as the single-graph step (world size 1: the all-reduces are no-ops)."""

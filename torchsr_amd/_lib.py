@@ -68,6 +68,9 @@ _SIGS = {
     'srx_conv2d_bwd_weight_ws_floats': (_Z, [_D]),
     'srx_conv2d_stat_rows': (_I, [_D]),
     'srx_conv2d_plan': (_I, [_D, _I, C.POINTER(C.c_int)]),
+    'srx_pack_table_bytes': (_Z, [_I]),
+    'srx_pack_table_build': (_I, [_P, _I, _P, _P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    'srx_pack_table_run': (_I, [_P, _I, C.c_longlong, _P]),
     'srx_conv2d_pack': (_I, [_D, _P, _P, _P, _P]),
     'srx_conv2d_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_data': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
@@ -116,7 +119,7 @@ _SIGS = {
     'srx_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
 }
 # functions whose int return value is data, not a status
-_UNCHECKED = {'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows'}
+_UNCHECKED = {'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows'}
 
 EXPORTS = tuple(_SIGS.keys())
 

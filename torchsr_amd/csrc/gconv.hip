@@ -1348,6 +1348,119 @@ extern "C" int srx_conv2d_pack(const srx_conv2d_t* d, const float* w, float* wpk
   return SRX_OK;
 }
 
+// ---------------------------------------------------------------------------
+// All layers of a model repacked by ONE launch.  The record table is built once on the host (every
+// pointer and size in it is fixed for the life of the model), kept in device memory by the caller and
+// replayed after each optimiser step: 37 + 8 pack launches per SRGAN step, ~370 per ESRGAN step, become 2.
+// ---------------------------------------------------------------------------
+struct PackRec {
+  float* dst; const float* w;
+  long long n_elems;
+  int kind;  // 0 forward, 1 data-gradient class, 2 thin forward, 3 thin data gradient
+  int rows, K, Kp, Ck, ph, pw, dminh, dminw, ntw;
+  int Cout, Cin, KH, KW, stride, pad, cps, pad_;
+};
+
+__global__ void pack_table_kernel(const PackRec* __restrict__ table) {
+  const PackRec r = table[blockIdx.y];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= r.n_elems) return;
+  float v = 0.f;
+  if (r.kind >= 2) {  // thin.hip layout: p[c][tap][ch]
+    const int taps = r.KH * r.KW;
+    const int ch = (int)(idx & 63), tap = (int)((idx >> 6) % taps), c = (int)(idx / (64 * taps));
+    const int Cthin = r.kind == 2 ? r.Cout : r.Cin;
+    if (c < Cthin) {
+      const int kh = tap / r.KW, kw = tap - kh * r.KW;
+      v = r.kind == 2 ? r.w[(((size_t)c * 64 + ch) * r.KH + kh) * r.KW + kw]
+                      : r.w[(((size_t)ch * Cthin + c) * r.KH + (r.KH - 1 - kh)) * r.KW + (r.KW - 1 - kw)];
+    }
+    r.dst[idx] = v;
+    return;
+  }
+  const int row = (int)(idx / r.Kp), k = (int)(idx - (int64_t)row * r.Kp);
+  if (k < r.K) {
+    const int tap = k / r.Ck, c = k - tap * r.Ck;
+    if (r.kind == 0) {
+      if (row < r.Cout && c < r.Cin) {
+        int co = row;
+        if (r.cps) { const int ij = row / r.cps, cc = row - ij * r.cps; co = cc * 4 + ij; }
+        const int kh = tap / r.KW, kw = tap - kh * r.KW;
+        v = r.w[(((size_t)co * r.Cin + c) * r.KH + kh) * r.KW + kw];
+      }
+    } else {
+      if (row < r.Cin && c < r.Cout) {
+        const int th = tap / r.ntw, tw = tap - th * r.ntw;
+        const int kh = r.ph + r.pad - r.stride * (r.dminh + th), kw = r.pw + r.pad - r.stride * (r.dminw + tw);
+        int co = c;
+        if (r.cps) { const int ij = c / r.cps, cc = c - ij * r.cps; co = cc * 4 + ij; }
+        v = r.w[(((size_t)co * r.Cin + row) * r.KH + kh) * r.KW + kw];
+      }
+    }
+  }
+  r.dst[idx] = v;
+}
+
+extern "C" size_t srx_pack_table_bytes(int n_layers) { return (size_t)n_layers * 17 * sizeof(PackRec); }
+
+extern "C" int srx_pack_table_build(const srx_conv2d_t* descs, int n, const float* const* w, float* const* wpk_fwd,
+                                    float* const* wpk_bwd, void* host_table, int* nrec_out, long long* max_elems_out) {
+  SRX_REQUIRE(descs && w && wpk_fwd && wpk_bwd && host_table && nrec_out && max_elems_out && n > 0,
+              "pack_table_build: bad argument");
+  PackRec* out = static_cast<PackRec*>(host_table);
+  int nrec = 0;
+  long long maxn = 0;
+  for (int i = 0; i < n; ++i) {
+    const srx_conv2d_t* d = descs + i;
+    if (int rc = check_desc(d)) return rc;
+    SRX_REQUIRE(w[i] && wpk_fwd[i], "pack_table_build: null pointer in layer %d", i);
+    const Geo g = fwd_geo(d);
+    PackRec base{};
+    base.w = w[i];
+    base.Cout = d->Cout; base.Cin = d->Cin; base.KH = d->KH; base.KW = d->KW; base.stride = d->stride; base.pad = d->pad;
+    base.cps = g.cps;
+    auto emit = [&](PackRec r) {
+      if (r.n_elems > maxn) maxn = r.n_elems;
+      out[nrec++] = r;
+    };
+    if (srx_thin_fwd_applicable(d)) {
+      PackRec r = base; r.kind = 2; r.dst = wpk_fwd[i]; r.n_elems = 4LL * d->KH * d->KW * 64; emit(r);
+    } else {
+      PackRec r = base; r.kind = 0; r.dst = wpk_fwd[i]; r.rows = g.Cnp; r.K = g.K; r.Kp = g.Kp; r.Ck = g.Ck; r.ntw = 1;
+      r.n_elems = (long long)g.Cnp * g.Kp; emit(r);
+    }
+    if (!wpk_bwd[i]) continue;
+    if (srx_thin_dgrad_applicable(d)) {
+      PackRec r = base; r.kind = 3; r.dst = wpk_bwd[i]; r.n_elems = 4LL * d->KH * d->KW * 64; emit(r);
+      continue;
+    }
+    SRX_REQUIRE(d->stride <= 4, "pack_table_build: stride > 4 unsupported for the data gradient");
+    BwdClass cls[16];
+    size_t total;
+    const int nc = bwd_classes(d, cls, total);
+    const int Cnp = pad_rows(d->Cin);
+    for (int c = 0; c < nc; ++c) {
+      PackRec r = base; r.kind = 1; r.dst = wpk_bwd[i] + cls[c].woff;
+      r.rows = Cnp; r.K = cls[c].K; r.Kp = cls[c].Kp; r.Ck = bwd_ck(d);
+      r.ph = cls[c].ph; r.pw = cls[c].pw; r.dminh = cls[c].dminh; r.dminw = cls[c].dminw;
+      r.ntw = cls[c].ntw > 0 ? cls[c].ntw : 1;
+      r.n_elems = (long long)Cnp * cls[c].Kp;
+      emit(r);
+    }
+  }
+  *nrec_out = nrec;
+  *max_elems_out = maxn;
+  return SRX_OK;
+}
+
+extern "C" int srx_pack_table_run(const void* dev_table, int nrec, long long max_elems, void* stream) {
+  SRX_REQUIRE(dev_table && nrec > 0 && nrec <= 65535 && max_elems > 0, "pack_table_run: bad argument");
+  hipLaunchKernelGGL(pack_table_kernel, dim3((unsigned)srx_cdiv(max_elems, 256), (unsigned)nrec), dim3(256), 0,
+                     srx_stream(stream), static_cast<const PackRec*>(dev_table));
+  SRX_CHECK_LAUNCH("pack_table_kernel");
+  return SRX_OK;
+}
+
 extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float* wpk, const float* bias, float* y,
                               float* bn_partials, float* ws, size_t ws_floats, void* stream) {
   if (int rc = check_desc(d)) return rc;

@@ -149,6 +149,7 @@ class ConvState:
         self.cin_s = round4(cin)
         self.cout_s = round4(cout // 4) if shuffle else round4(cout)
         self._descs = {}
+        self.model_epoch = [0]  # replaced by the owning FlatParams' counter
         self.precision = 0  # 1: bf16 products in the forward / stride-1 data gradient (srx_conv2d_t::precision)
         self.wpk_fwd = None
         self.wpk_bwd = None
@@ -169,13 +170,21 @@ class ConvState:
             return (n, 2 * ho, 2 * wo, self.cout_s)
         return (n, ho, wo, self.cout_s)
 
+    def pack_key(self, weight: Tensor):
+        """What the packed copies were made from: the tensor, its in-place version, the global epoch (bumped
+        when raw-pointer code may have changed any parameter) and the model's own epoch (bumped by its
+        optimiser, ``optim.FlatParams.pack_epoch``).  Frozen parameters (VGG19) never repack."""
+        if not weight.requires_grad:
+            return (weight.data_ptr(), weight._version, -1, -1)
+        return (weight.data_ptr(), weight._version, _pack_epoch[0], self.model_epoch[0])
+
     def pack(self, weight: Tensor, d: Conv2dDesc, force: bool = False) -> None:
         """(Re)build the packed copies when the master OIHW weight changed.
 
         ``weight`` is the module's Parameter: its ``_version`` catches in-place torch updates,
         the optimiser epoch catches raw-pointer updates by ``srx_adam_step`` (frozen parameters
         such as VGG19's never repack)."""
-        key = (weight.data_ptr(), weight._version, _pack_epoch[0] if weight.requires_grad else -1)
+        key = self.pack_key(weight)
         if not force and key == self._key and self.wpk_fwd is not None:
             return
         dref = C.byref(d)
@@ -187,6 +196,47 @@ class ConvState:
         w = _chk(weight.detach(), 'conv2d.weight')
         call('srx_conv2d_pack', dref, _p(w), _p(self.wpk_fwd), _p(self.wpk_bwd), _stream())
         self._key = key
+        self.last_desc = d
+
+
+class PackTable:
+    """Every conv of a model repacked by ONE launch after an optimiser step (``srx_pack_table_*``).
+
+    Built once all layers have seen an input (their packed buffers and descriptors exist); the record
+    table lives in device memory.  ``run()`` also stamps each layer's pack key, so the lazy per-layer
+    ``ConvState.pack`` in the next forward finds nothing to do.
+    """
+
+    def __init__(self, convs):
+        self.convs = list(convs)
+        self.table = None
+        self.nrec, self.maxn = 0, 0
+
+    def _build(self) -> bool:
+        items = [(c._st, c.weight) for c in self.convs if c.weight.requires_grad]
+        if not items or any(st.wpk_fwd is None or getattr(st, 'last_desc', None) is None for st, _ in items):
+            return False
+        n = len(items)
+        descs = (Conv2dDesc * n)(*[st.last_desc for st, _ in items])
+        arr = lambda ptrs: (C.c_void_p * n)(*ptrs)  # noqa: E731
+        w, f, b = (arr([wt.data_ptr() for _, wt in items]), arr([st.wpk_fwd.data_ptr() for st, _ in items]),
+                   arr([st.wpk_bwd.data_ptr() for st, _ in items]))
+        nbytes = _lib.lib().srx_pack_table_bytes(n)
+        host = torch.empty(nbytes, dtype=torch.uint8)
+        nrec, maxn = C.c_int(0), C.c_longlong(0)
+        call('srx_pack_table_build', descs, n, w, f, b, host.data_ptr(), C.byref(nrec), C.byref(maxn))
+        self.table = host.to(items[0][1].device)
+        self.items, self.nrec, self.maxn = items, nrec.value, maxn.value
+        return True
+
+    def run(self) -> bool:
+        """False (and nothing done) until every layer is ready: the lazy per-layer path still covers that."""
+        if self.table is None and (torch.cuda.is_current_stream_capturing() or not self._build()):
+            return False
+        call('srx_pack_table_run', self.table.data_ptr(), self.nrec, self.maxn, _stream())
+        for st, wt in self.items:
+            st._key = st.pack_key(wt)
+        return True
 
 
 # bumped by the optimiser (optim.FlatAdam.step) because a raw-pointer update does not

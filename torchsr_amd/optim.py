@@ -41,6 +41,12 @@ class FlatParams:
         self.grad = torch.zeros(total, dtype=dt, device=dev)
         self.params: List[nn.Parameter] = params
         self.numel = total
+        # bumped by every optimiser step on this buffer: the convs of THIS model repack, other models' do not
+        self.pack_epoch = [0]
+        for m in module.modules():
+            st = getattr(m, '_st', None)
+            if isinstance(st, F.ConvState):
+                st.model_epoch = self.pack_epoch
         with torch.no_grad():
             for p, o in zip(params, offs):
                 n = p.numel()
@@ -77,6 +83,7 @@ class FlatAdam:
         self.lr_dev = torch.tensor(float(lr), dtype=torch.float32, device=dev)
         self._lr = float(lr)
         self.grad_scale = 1.0
+        self.pack_table = None  # functional.PackTable of the model's convs (set by the trainer)
         self.param_groups = [{'lr': float(lr), 'initial_lr': float(lr)}]  # StepLR-style access
 
     @property
@@ -97,7 +104,9 @@ class FlatAdam:
         call('srx_adam_step', f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
              self.exp_avg_sq.data_ptr(), f.numel, self.lr_dev.data_ptr(), self.betas[0], self.betas[1], self.eps,
              self.grad_scale, self.step_count.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        F.bump_pack_epoch()
+        self.flat.pack_epoch[0] += 1
+        if self.pack_table is not None:  # every conv of the model repacked by one launch
+            self.pack_table.run()
 
     def state_dict(self):
         return {'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'step': self.step_count, 'lr': self._lr}

@@ -146,6 +146,11 @@ class SRGANTrainer:
             for opt in (self.psnr_optimizer, self.gen_optimizer):
                 opt.grad_scale = self.gen_sync.scale
             self.disc_optimizer.grad_scale = self.disc_sync.scale
+        from ..layers import Conv2d
+        gen_table = F.PackTable(m for m in self.generator.modules() if isinstance(m, Conv2d))
+        disc_table = F.PackTable(m for m in self.discriminator.modules() if isinstance(m, Conv2d))
+        self.psnr_optimizer.pack_table = self.gen_optimizer.pack_table = gen_table
+        self.disc_optimizer.pack_table = disc_table
         self.disc_scheduler = StepLR(self.disc_optimizer, step_size=self.epochs // 8, gamma=0.6)
         self.gen_scheduler = StepLR(self.gen_optimizer, step_size=self.epochs // 8, gamma=0.6)
 
