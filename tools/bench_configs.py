@@ -4,6 +4,7 @@ quoted in DESIGN.md).
     python tools/bench_configs.py [pretrain] [esrgan] [infer]
 
   pretrain : SRGAN SRResNet pre-training step, 96x96 crops, batch 16 and batch 2 (config 1 on the GPU)
+  srgan-amp: SRGAN full GAN step, batch 16, with bf16 conv products (the reference's default autocast mode)
   esrgan   : ESRGAN full GAN step, 128x128 crops, batch 16 (config 4), fp32 and with bf16 conv products (amp)
   infer    : SRGAN generator 1080p -> 8K, batch 1, eval mode, tiled (config 5)
 """
@@ -53,6 +54,15 @@ if 'pretrain' in which:
         gf = 7.648 * b
         print(f'SRGAN pretrain step  batch {b:2d}: {dt * 1e3:7.3f} ms/step  {b / dt:8.1f} crops/s  {gf / dt / 1e3:6.1f} TFLOP/s', flush=True)
         del t
+if 'srgan-amp' in which:
+    from torchsr_amd.srgan.trainer import SRGANTrainer
+    torch.manual_seed(0)
+    t = SRGANTrainer(dev, targs(16, True), [], [], 16, 16)
+    lr, hr = batch(16, 96)
+    dt = timed(lambda: t.gan_step(lr, hr), 30)
+    print(f'SRGAN GAN step       batch 16: {dt * 1e3:7.3f} ms/step  {16 / dt:8.1f} crops/s  {691.67 / dt / 1e3:6.1f} TFLOP/s '
+          f'(bf16 products (amp))', flush=True)
+    del t
 if 'esrgan' in which:
     from torchsr_amd.esrgan.trainer import ESRGANTrainer
     torch.manual_seed(0)

@@ -1073,8 +1073,7 @@ int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
   dim3 grid(p.full + p.tail * p.split);
   if (srx_prof_on()) {
     char nm[64];
-    snprintf(nm, sizeof(nm), PR ? "gconv_kernel<%d, %d, %d, %d, %d, %d, 1>" : "gconv_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, WM,
-             WN, KS, XR);
+    snprintf(nm, sizeof(nm), "gconv_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, KS, XR, PR);
     srx_prof_begin_launch(nm, 2.0 * a.M * a.Cn * a.K, st);
   }
   hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN, KS, XR, PR>), grid, dim3((BM / WM) * (BN / WN) * 64 * KS), lds, st, a);
