@@ -135,3 +135,33 @@ def test_psnr_parity(dev):
         sr = gen(lr.to(dev))
         psnr = 10 * log10(1 / F.mse_loss(sr, hr.to(dev)).item())
     assert abs(psnr - O.psnr(sr_o, hr)) < 0.01
+
+
+def test_eval_folding_equals_unfolded_eval(dev):
+    """Inference form of the SRGAN generator (BatchNorm folded into the convs, PReLU and the skip connections
+    in the conv epilogues: functional.FoldedConv) against the layer-by-layer eval forward of the same module."""
+    from torchsr_amd.srgan.generator import Generator
+    torch.manual_seed(5)
+    gen = Generator().to(dev).eval()
+    with torch.no_grad():
+        for m in gen.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.3, 0.3)
+                m.running_var.uniform_(0.4, 1.6)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+            if isinstance(m, torch.nn.PReLU):
+                m.weight.uniform_(0.1, 0.4)
+    for shape in ((2, 3, 24, 24), (1, 3, 20, 28)):       # row-tile kernel / generic kernel
+        x = torch.rand(shape, device=dev)
+        y_layers = gen(x)                                 # grad mode on: BatchNorm / PReLU as separate passes
+        with torch.no_grad():
+            y_folded = gen(x)
+        assert '_folded' in gen.__dict__
+        assert rel(y_folded, y_layers.detach().cpu().numpy()) < 2e-5
+    with torch.no_grad():                                 # a parameter update invalidates the folded copies
+        gen.blocks[3].bn1.weight.mul_(1.5)
+        x = torch.rand(1, 3, 24, 24, device=dev)
+        y1 = gen(x)
+    y2 = gen(x)
+    assert rel(y1, y2.detach().cpu().numpy()) < 2e-5

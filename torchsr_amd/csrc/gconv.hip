@@ -45,7 +45,10 @@ struct GArgs {
   // sizes of the `in` and `w` buffers: both are read through raw buffer descriptors, whose range
   // check returns 0 for the padding taps (no branch, no select, statically countable loads)
   unsigned in_bytes, w_bytes;
-  int accum;  // epilogue adds to what `out` already holds (data gradients summed into a shared dense-block buffer)
+  // epilogue addend, laid out like `out` (null: none): `out` itself when a data gradient is summed into a
+  // shared dense-block buffer, or the skip input of a residual block in eval mode (BatchNorm folded into the
+  // conv, `x + conv(...)` in one kernel).  Linear outputs only.
+  const float* add;
 };
 
 
@@ -390,6 +393,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   const unsigned tb_lo = (unsigned)srx_uniform((int)(unsigned)(tile_base & 0xffffffffu));
   const unsigned tb_hi = (unsigned)srx_uniform((int)(unsigned)(tile_base >> 32));
   const __amdgpu_buffer_rsrc_t rout = srx_rsrc(a.out + (((size_t)tb_hi << 32) | tb_lo), 0xfffffff0u);
+  const __amdgpu_buffer_rsrc_t radd = srx_rsrc((a.add ? a.add : a.out) + (((size_t)tb_hi << 32) | tb_lo), 0xfffffff0u);
 
   float bv[TN];
   unsigned ocol[TN];  // byte offset of the column inside its output row
@@ -429,13 +433,13 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
           v = v > 0.f ? v : v * a.slope;
           const unsigned off = (mok && cok[j]) ? rowoff + ocol[j] : 0xffffffffu;
           if (decltype(accum)::value)
-            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rout, (int)off, 0, 0));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
         }
       }
     }
   };
-  if (a.accum) {
+  if (a.add) {
     if (a.linear_out) store_tile(std::true_type{}, std::true_type{});
     else store_tile(std::false_type{}, std::true_type{});
   } else {
@@ -466,7 +470,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       xs2 += vs * vs;
       v = v > 0.f ? v : v * a.slope;
       const unsigned off = (mok && xok) ? rowoff + 4u * (unsigned)oc : 0xffffffffu;
-      if (a.accum) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rout, (int)off, 0, 0));
+      if (a.add) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
     }
   }
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const GArgs a) {
       }
       if (col < a.Cs) {  // Cs is a multiple of 4
         f32x4* o = reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col);
-        if (a.accum) v += *o;
+        if (a.add) v += *reinterpret_cast<const f32x4*>(a.add + (size_t)m * a.Co + col);
         *o = v;
       }
     }
@@ -1460,13 +1464,14 @@ extern "C" int srx_pack_table_run(const void* dev_table, int nrec, long long max
   return SRX_OK;
 }
 
-extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float* wpk, const float* bias, float* y,
-                              float* bn_partials, float* ws, size_t ws_floats, void* stream) {
+static int conv_fwd_impl(const srx_conv2d_t* d, const float* x, const float* wpk, const float* bias, const float* residual,
+                         float* y, float* bn_partials, float* ws, size_t ws_floats, void* stream) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(x && wpk && y, "conv2d_fwd: null pointer");
+  if (residual && d->shuffle) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_fwd: residual with PixelShuffle is not implemented");
   hipStream_t st = srx_stream(stream);
-  if (srx_thin_fwd_applicable(d) && !bn_partials) return srx_thin_fwd(d, x, wpk, bias, y, d->Cout, st);
-  if (srx_rt36_applicable(d)) return srx_rt36_run(d, x, wpk, bias, y, bn_partials, d->act, d->slope, st);
+  if (srx_thin_fwd_applicable(d) && !bn_partials && !residual) return srx_thin_fwd(d, x, wpk, bias, y, d->Cout, st);
+  if (srx_rt36_applicable(d)) return srx_rt36_run(d, x, wpk, bias, residual, y, bn_partials, d->act, d->slope, st);
   const Geo g = fwd_geo(d);
   GArgs a{};
   a.in = x; a.w = wpk; a.bias = bias; a.part = nullptr;
@@ -1487,9 +1492,21 @@ extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float
   }
   a.part = bn_partials;
   a.out = y;
+  a.add = residual;
   a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin_s * sizeof(float));
   a.w_bytes = (unsigned)((size_t)g.Cnp * g.Kp * sizeof(float));
   return run_gconv(a, fwd_plan(d, g), ws, ws_floats, st, d->precision);
+}
+
+extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float* wpk, const float* bias, float* y,
+                              float* bn_partials, float* ws, size_t ws_floats, void* stream) {
+  return conv_fwd_impl(d, x, wpk, bias, nullptr, y, bn_partials, ws, ws_floats, stream);
+}
+
+extern "C" int srx_conv2d_fwd_residual(const srx_conv2d_t* d, const float* x, const float* wpk, const float* bias,
+                                       const float* residual, float* y, float* ws, size_t ws_floats, void* stream) {
+  SRX_REQUIRE(residual, "conv2d_fwd_residual: null residual");
+  return conv_fwd_impl(d, x, wpk, bias, residual, y, nullptr, ws, ws_floats, stream);
 }
 
 extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
@@ -1506,7 +1523,7 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
   size_t total;
   const int nc = bwd_classes(d, cls, total);
   if (srx_rt36_applicable(d))  // 3x3 / stride 1 / pad 1: one class, same geometry as the forward, flipped taps
-    return srx_rt36_run(d, dy, wpk_bwd + cls[0].woff, nullptr, dx, nullptr, SRX_ACT_NONE, 0.f, st);
+    return srx_rt36_run(d, dy, wpk_bwd + cls[0].woff, nullptr, nullptr, dx, nullptr, SRX_ACT_NONE, 0.f, st);
   bool any_empty = false;
   for (int i = 0; i < nc; ++i) any_empty |= (cls[i].K == 0);
   if (any_empty) {
@@ -1536,7 +1553,7 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     a.out = dx;
     a.in_bytes = (unsigned)dy_bytes;
     a.w_bytes = (unsigned)((size_t)pad_rows(d->Cin) * c.Kp * sizeof(float));
-    a.accum = accumulate;
+    a.add = accumulate ? dx : nullptr;
     if (d->stride == 1) {
       if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st, d->precision)) return rc;
     } else if (nc <= 4) {

@@ -31,7 +31,7 @@ constexpr int PF = 8;      // weight fragments in flight per wave
 constexpr int PB = 8;      // patch b128 loads per thread and batch
 
 struct RtArgs {
-  const float* in; const float* w; const float* bias; float* out; float* part;
+  const float* in; const float* w; const float* bias; const float* res; float* out; float* part;
   int H, W, HW, M;
   float slope;       // branch-free activation: v > 0 ? v : v * slope  (none: 1, ReLU: 0, LeakyReLU: its slope)
   unsigned in_bytes, out_bytes;
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   const int col = 32 * j + i31;
   const float bv = a.bias ? a.bias[col] : 0.f;
   const __amdgpu_buffer_rsrc_t rout = srx_rsrc(a.out, a.out_bytes);
+  const __amdgpu_buffer_rsrc_t rres = srx_rsrc(a.res ? a.res : a.out, a.out_bytes);  // eval-mode skip input
   const unsigned obase = ((unsigned)m0 * 64u + (unsigned)col + 256u * h2) * 4u;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -162,14 +163,19 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     const float v = acc[r] + bv;
     s1 += v;
     s2 += v * v;
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v > 0.f ? v : v * a.slope), rout, obase, ((r & 3) + 8 * (r >> 2)) * 256, 0);
+    float o = v > 0.f ? v : v * a.slope;
+    if (a.res)
+      o += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)obase, ((r & 3) + 8 * (r >> 2)) * 256, 0));
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rout, obase, ((r & 3) + 8 * (r >> 2)) * 256, 0);
   }
   const unsigned obase4 = h2 == 0 ? ((unsigned)m0 * 64u + (unsigned)col) * 4u : 0xffffffffu;  // half 0 stores
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float v = acc4[i] + bv;
     if (h2 == 0) { s1 += v; s2 += v * v; }
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v > 0.f ? v : v * a.slope), rout, obase4, (32 + i) * 256, 0);
+    float o = v > 0.f ? v : v * a.slope;
+    if (a.res) o += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)obase4, (32 + i) * 256, 0));
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rout, obase4, (32 + i) * 256, 0);
   }
   if (a.part) {  // per-channel (sum, sum of squares) of this workgroup's 36 rows
     s1 += __shfl_xor(s1, 32, 64);
@@ -217,10 +223,10 @@ bool srx_rt36_applicable(const srx_conv2d_t* d) {
 
 int srx_rt36_rows(const srx_conv2d_t* d) { return (int)((int64_t)d->N * d->H * d->W / RT); }
 
-int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, float* out, float* part,
-                 int act, float slope, hipStream_t st) {
+int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, const float* residual,
+                 float* out, float* part, int act, float slope, hipStream_t st) {
   RtArgs a{};
-  a.in = in; a.w = wpk; a.bias = bias; a.out = out; a.part = part;
+  a.in = in; a.w = wpk; a.bias = bias; a.res = residual; a.out = out; a.part = part;
   a.H = d->H; a.W = d->W; a.HW = d->H * d->W; a.M = d->N * a.HW;
   a.slope = act == SRX_ACT_RELU ? 0.f : (act == SRX_ACT_LRELU ? slope : 1.f);
   a.in_bytes = (unsigned)((size_t)a.M * 64 * sizeof(float));

@@ -47,8 +47,8 @@ int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const
 // rowtile.hip: 3x3 / 64 -> 64 convolutions with few pixels (the SRGAN residual tower), 36 pixels per CU
 bool srx_rt36_applicable(const srx_conv2d_t* d);
 int srx_rt36_rows(const srx_conv2d_t* d);  // workgroups = rows of the BatchNorm partial table
-int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, float* out, float* part,
-                 int act, float slope, hipStream_t st);
+int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, const float* residual,
+                 float* out, float* part, int act, float slope, hipStream_t st);
 
 static inline hipStream_t srx_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t srx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -760,6 +760,83 @@ class _ConcatChannels(Function):
         return tuple(grads)
 
 
+class FoldedConv:
+    """Inference form of ``conv [-> BatchNorm2d (running statistics)] [-> PReLU] [+ residual]``: ONE kernel.
+
+    The eval-mode BatchNorm is an affine map per output channel, so it folds into the conv's weights and
+    bias (``w' = w * g / sqrt(var + eps)``, ``b' = (b - mean) * g / sqrt(var + eps) + beta``); a
+    single-parameter PReLU is the conv epilogue's LeakyReLU with the learnt slope (it commutes with the
+    fused PixelShuffle); the skip connection is the epilogue's addend (``srx_conv2d_fwd_residual``).
+    Replaces an elementwise pass over the activation per BatchNorm / PReLU of the generator at inference
+    (SURVEY.md section 8f row 1).  Folded tensors are cached and rebuilt when any source tensor changes.
+    """
+
+    def __init__(self, conv, bn=None, prelu=None):
+        self.conv, self.bn, self.prelu = conv, bn, prelu
+        self._key = None
+        self.st = None
+
+    def _sources(self):
+        ts = [self.conv.weight, self.conv.bias]
+        if self.bn is not None:
+            ts += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+        if self.prelu is not None:
+            ts.append(self.prelu.weight)
+        return [t for t in ts if t is not None]
+
+    def _refresh(self) -> None:
+        key = tuple((t.data_ptr(), t._version) for t in self._sources()) + (_pack_epoch[0], self.conv._st.model_epoch[0])
+        if key == self._key:
+            return
+        conv, bn = self.conv, self.bn
+        with torch.no_grad():
+            w = conv.weight.detach()
+            b = conv.bias.detach() if conv.bias is not None else None
+            if bn is not None:
+                scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+                w = w * scale.view(-1, 1, 1, 1)
+                b = ((b if b is not None else 0.0) - bn.running_mean) * scale + bn.bias.detach()
+            self.w = w.contiguous()
+            self.b = None if b is None else b.contiguous()
+            src = conv._st
+            act, slope = src.act, src.slope
+            if self.prelu is not None:
+                if self.prelu.weight.numel() != 1 or src.act != ACT_NONE:
+                    raise RuntimeError('FoldedConv: PReLU must have one parameter and follow a linear conv')
+                act, slope = ACT_LRELU, float(self.prelu.weight.detach().reshape(()).item())
+            self.st = ConvState(src.cin, src.cout, src.k, src.stride, src.pad, shuffle=src.shuffle, act=act, slope=slope)
+            self.st.precision = src.precision
+        self._key = key
+
+    def __call__(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+        self._refresh()
+        st = self.st
+        x = _chk(x, 'folded_conv.input')
+        n, h, w, cs = x.shape
+        if cs != st.cin_s:
+            raise RuntimeError(f'folded_conv: input has {cs} channels (stride), layer expects {st.cin_s}')
+        d = st.desc(n, h, w)
+        dref = C.byref(d)
+        st.pack(self.w, d)
+        L = _lib.lib()
+        y = torch.empty(st.out_shape(n, h, w), dtype=torch.float32, device=x.device)
+        nws = L.srx_conv2d_fwd_ws_floats(dref)
+        ws = _ws(nws, x) if nws else None
+        if residual is None:
+            call('srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(self.b), _p(y), None, _p(ws), nws, _stream())
+        else:
+            r = _chk(residual, 'folded_conv.residual')
+            if r.shape != y.shape:
+                raise RuntimeError('folded_conv: residual must have the output shape')
+            call('srx_conv2d_fwd_residual', dref, _p(x), _p(st.wpk_fwd), _p(self.b), _p(r), _p(y), _p(ws), nws, _stream())
+        return y
+
+
+def inference_mode(module) -> bool:
+    """The folded single-kernel forms apply when nothing will be differentiated and BatchNorm is in eval mode."""
+    return not module.training and not torch.is_grad_enabled()
+
+
 def concat_channels(xs) -> Tensor:
     return _ConcatChannels.apply(*xs)
 

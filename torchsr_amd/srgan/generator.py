@@ -28,6 +28,14 @@ class Generator(nn.Module):
 
     def forward_nhwc(self, x4: Tensor) -> Tensor:
         """NHWC ``[N,h,w,4]`` -> NHWC ``[N,s*h,s*w,4]`` (4th channel zero)."""
+        if F.inference_mode(self):
+            f = self.__dict__.get('_folded')
+            if f is None:
+                f = self.__dict__.setdefault('_folded', (F.FoldedConv(self.conv1[0], None, self.conv1[1]),
+                                                         F.FoldedConv(self.conv2[0], self.conv2[1], None)))
+            conv1 = f[0](x4)
+            out = f[1](self.blocks(conv1), residual=conv1)
+            return self.conv3(self.conv_layers(out))
         conv1 = self.conv1[1](self.conv1[0](x4))
         block = self.blocks(conv1)
         bn = self.conv2[1]

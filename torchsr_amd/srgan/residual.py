@@ -22,6 +22,9 @@ class SubpixelConvolutionLayer(nn.Module):
         self.prelu = PReLU()
 
     def forward(self, x: Tensor) -> Tensor:
+        if F.inference_mode(self):  # conv + PixelShuffle + PReLU in one kernel
+            f = self.__dict__.get('_folded') or self.__dict__.setdefault('_folded', F.FoldedConv(self.conv, None, self.prelu))
+            return f(x)
         out = self.conv(x)
         return self.prelu(out)
 
@@ -42,6 +45,12 @@ class ResidualBlock(nn.Module):
         self.bn2 = BatchNorm2d(channels)
 
     def forward(self, x: Tensor) -> Tensor:
+        if F.inference_mode(self):  # two kernels: BatchNorm folded, PReLU / skip connection in the epilogues
+            f = self.__dict__.get('_folded')
+            if f is None:
+                f = self.__dict__.setdefault('_folded', (F.FoldedConv(self.conv1, self.bn1, self.prelu),
+                                                         F.FoldedConv(self.conv2, self.bn2, None)))
+            return f[1](f[0](x), residual=x)
         y, part = self.conv1(x, want_stats=True) if self.bn1.training else (self.conv1(x), None)
         out = self.bn1(y, part, act=ACT_PRELU, prelu=self.prelu.weight)
         y, part = self.conv2(out, want_stats=True) if self.bn2.training else (self.conv2(out), None)
