@@ -187,3 +187,38 @@ def test_steplr_and_registry():
     with pytest.raises(RuntimeError, match='not supported'):
         models.select_trainer_model(Namespace(model='nope'))
     assert set(models.MODELS) == {'esrgan', 'srgan'} and models.CROP_SIZE == {'esrgan': 128, 'srgan': 96}
+
+
+def test_descriptor_validation_without_a_gpu():
+    """Host-side argument checking of the C ABI needs no device: limits and unsupported configurations are
+    reported through the status code + srx_last_error, never by aborting."""
+    import ctypes as C
+    from torchsr_amd import _lib
+    lib = _lib.lib()
+    out = (C.c_int * 6)()
+
+    def plan_error(*fields):
+        d = _lib.Conv2dDesc(*fields)
+        rc = lib.srx_conv2d_plan(C.byref(d), 0, out)
+        buf = C.create_string_buffer(256)
+        lib.srx_last_error(buf, 256)
+        return rc, buf.value.decode()
+
+    ok = (16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
+    assert plan_error(*ok)[0] == 0 and list(out)[:2] == [36, 64]
+    rc, msg = plan_error(1, 5000, 5000, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)          # > 2^24 pixels
+    assert rc != 0 and 'tile the image' in msg
+    rc, msg = plan_error(16, 24, 24, 64, 62, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)              # stride < channels
+    assert rc != 0 and 'Cin_s' in msg
+    rc, msg = plan_error(16, 24, 24, 64, 64, 60, 60, 3, 3, 1, 1, 2, 0, 0.0, 0, 0)              # shuffle needs Cout % 16
+    assert rc != 0 and 'shuffle' in msg
+    rc, msg = plan_error(16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 2, 0)              # fused upsample
+    assert rc == 2 and 'not implemented' in msg                                                 # SRX_E_UNSUPPORTED
+    rc, msg = plan_error(16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 7)              # precision
+    assert rc != 0 and 'precision' in msg
+    rc, msg = plan_error(16, 2, 2, 64, 64, 64, 64, 5, 5, 1, 0, 0, 0, 0.0, 0, 0)                # empty output
+    assert rc != 0 and 'empty output' in msg
+    d = _lib.Conv2dDesc(*ok)
+    assert lib.srx_conv2d_packed_fwd_floats(C.byref(d)) == 64 * 576
+    assert lib.srx_conv2d_packed_bwd_floats(C.byref(d)) == 64 * 576
+    assert lib.srx_conv2d_stat_rows(C.byref(d)) == 256

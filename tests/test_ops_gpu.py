@@ -410,3 +410,46 @@ def test_device_augmentation_kernels(dev):
         q = (want.clamp(0, 1) * 255).round() / 255
         assert float((out.cpu() - q).abs().max()) <= 1.0 / 255 + 1e-6       # ties may round either way
         assert float(((out.cpu() - q).abs() > 1e-6).float().mean()) < 1e-3
+
+
+FULL_SIZE_LAYERS = [
+    # every distinct conv shape of the batch-16 SRGAN GAN step (BASELINE configs[1]): N, H, W, Cin, Cout, k, s, p, shuffle
+    (16, 24, 24, 64, 64, 3, 1, 1, 0), (16, 24, 24, 3, 64, 9, 1, 4, 0), (16, 24, 24, 64, 256, 3, 1, 1, 2),
+    (16, 48, 48, 64, 256, 3, 1, 1, 2), (16, 96, 96, 64, 3, 9, 1, 4, 0), (16, 96, 96, 3, 64, 3, 1, 1, 0),
+    (16, 96, 96, 64, 64, 3, 2, 1, 0), (16, 48, 48, 64, 128, 3, 1, 1, 0), (16, 48, 48, 128, 128, 3, 2, 1, 0),
+    (16, 24, 24, 128, 256, 3, 1, 1, 0), (16, 24, 24, 256, 256, 3, 2, 1, 0), (16, 12, 12, 256, 512, 3, 1, 1, 0),
+    (16, 12, 12, 512, 512, 3, 2, 1, 0), (32, 96, 96, 64, 64, 3, 1, 1, 0), (32, 48, 48, 128, 128, 3, 1, 1, 0),
+    (32, 24, 24, 256, 256, 3, 1, 1, 0), (32, 12, 12, 512, 512, 3, 1, 1, 0), (32, 6, 6, 512, 512, 3, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize('case', FULL_SIZE_LAYERS, ids=lambda c: 'x'.join(map(str, c)))
+def test_full_size_adjoint_identities(dev, case):
+    """At the benchmark's own sizes a CPU oracle is too slow, so the three conv kernels are tied together by
+    properties that hold at any size:  <dy, conv(x; W)> = <x, dgrad(dy; W)> = <W, wgrad(x, dy)>  (the
+    forward is linear in x and in W, and the two gradients are its adjoints), and conv is additive in x."""
+    from torchsr_amd.layers import Conv2d
+    n, h, w, cin, cout, k, s, p, shuffle = case
+    torch.manual_seed(hash(case) % 997)
+    conv = Conv2d(cin, cout, k, s, p, bias=False, shuffle=shuffle).to(dev)
+    cs = (cin + 3) // 4 * 4
+    x = torch.zeros(n, h, w, cs, device=dev)
+    x[..., :cin] = torch.rand(n, h, w, cin, device=dev) - 0.5
+    x.requires_grad_(True)
+    y = conv(x)
+    cl = cout // 4 if shuffle else cout
+    dy = torch.zeros_like(y)
+    dy[..., :cl] = torch.rand(y.shape[:-1] + (cl,), device=dev) - 0.5
+    dx, dw = torch.autograd.grad(y, (x, conv.weight), dy)
+    lhs = (dy.double() * y.detach().double()).sum().item()
+    via_x = (x.detach().double() * dx.double()).sum().item()
+    via_w = (conv.weight.detach().double() * dw.double()).sum().item()
+    scale = (dy.double().norm() * y.detach().double().norm()).item()
+    assert abs(lhs - via_x) <= 2e-5 * scale, (lhs, via_x)
+    assert abs(lhs - via_w) <= 2e-5 * scale, (lhs, via_w)
+    with torch.no_grad():
+        x2 = torch.zeros_like(x)
+        x2[..., :cin] = torch.rand(n, h, w, cin, device=dev) - 0.5
+        y12 = conv(0.5 * x.detach() - 2.0 * x2)
+        y2 = conv(x2)
+    assert rel_err(y12, 0.5 * y.detach() - 2.0 * y2) < 2e-5
