@@ -49,4 +49,25 @@ for name, n, h, w, c in (('G 64ch @24', 16, 24, 24, 64), ('D 128ch @48', 16, 48,
             for _ in range(reps):
                 fn()
         res[tag] = timeit(g.replay) / reps
-    print(f'{name:14s} conv {res["conv"]:6.2f} us   BN forward (finalize + normalise/PReLU) {res["conv+bn"] - res["conv"]:6.2f} us', flush=True)
+    xg = x.clone().requires_grad_(True)
+
+    def fwd_bwd():
+        y, part = conv(xg, want_stats=True)
+        out = bn(y, part, act=ACT_PRELU, prelu=prelu)
+        torch.autograd.grad(out, y, gout)
+
+    def fwd_grad():
+        y, part = conv(xg, want_stats=True)
+        return bn(y, part, act=ACT_PRELU, prelu=prelu)
+
+    gout = torch.rand(n, h, w, c, device=dev)
+    for tag, fn in (('fwd(grad)', fwd_grad), ('fwd+bnbwd', fwd_bwd)):
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        res[tag] = timeit(g.replay) / reps
+    print(f'{name:14s} conv {res["conv"]:6.2f} us   BN forward {res["conv+bn"] - res["conv"]:6.2f} us   '
+          f'BN backward {res["fwd+bnbwd"] - res["fwd(grad)"]:6.2f} us', flush=True)

@@ -5,6 +5,7 @@
 // 16-byte accesses; reductions are two-stage (per row block, then a tiny finalize)
 // so results are bitwise reproducible -- no float atomics.
 #include "srx_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -121,15 +122,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ ws,
                                                             int64_t M, int C, int act, float slope,
-                                                            const float* __restrict__ prelu) {
+                                                            const float* __restrict__ prelu, int rpb) {
   __shared__ f32x4 red[2][256];
   __shared__ float redp[256];
   if (act == SRX_ACT_PRELU) slope = prelu[0];
   const int cq = C / 4, nrl = 256 / cq;
   const int tid = threadIdx.x;
   const int q = tid % cq, rl = tid / cq;
-  const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block(M);
-  const int64_t rend = min(M, rbeg + rows_per_block(M));
+  const int64_t rbeg = (int64_t)blockIdx.x * rpb;
+  const int64_t rend = min(M, rbeg + rpb);
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   float sp = 0.f;
   if (rl < nrl) {
@@ -237,26 +238,31 @@ __global__ __launch_bounds__(256) void bn_train_fwd_fused_kernel(
   float* s_scale = sm;
   float* s_shift = sm + C;
   if (act == SRX_ACT_PRELU) slope = prelu[0];
-  // 256 threads = C channels x (256/C) row lanes when C <= 256, else loop channels
-  const int nrl = C <= 256 ? 256 / C : 1;
-  __shared__ double red[2][256];
-  for (int cbase = 0; cbase < C; cbase += 256) {
-    const int c = cbase + (threadIdx.x % (C <= 256 ? C : 256));
-    const int rl = C <= 256 ? threadIdx.x / C : 0;
-    double s = 0.0, s2 = 0.0;
-    if (c < C && rl < nrl)
-      for (int r = rl; r < rows; r += nrl) {
-        const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)r * C + c) * 2);
-        s += (double)v.x;
-        s2 += (double)v.y;
-      }
-    red[0][threadIdx.x] = s;
-    red[1][threadIdx.x] = s2;
-    __syncthreads();
-    if (c < C && rl == 0) {
-      for (int k = 1; k < nrl; ++k) { s += red[0][threadIdx.x + k * C]; s2 += red[1][threadIdx.x + k * C]; }
-      const double mu = s / (double)M;
-      double var = s2 / (double)M - mu * mu;
+  // Table [rows][C][2] read as float4 = (sum, sumsq) of two channels: thread t owns channel pair t % (C/2)
+  // and the rows t / (C/2) + k * RL (C/2 divides 256): independent, fully coalesced loads, fp64 sums.
+  __shared__ double red[256][4];
+  const int cp2 = C / 2, RL = 256 / cp2;
+  const int cp = threadIdx.x % cp2, rl = threadIdx.x / cp2;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const f32x4* tab = reinterpret_cast<const f32x4*>(part);
+#pragma unroll 8
+  for (int r = rl; r < rows; r += RL) {
+    const f32x4 v = tab[(size_t)r * cp2 + cp];
+    a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+  }
+  red[threadIdx.x][0] = a0; red[threadIdx.x][1] = a1; red[threadIdx.x][2] = a2; red[threadIdx.x][3] = a3;
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < RL; ++k) {
+      a0 += red[threadIdx.x + k * cp2][0]; a1 += red[threadIdx.x + k * cp2][1];
+      a2 += red[threadIdx.x + k * cp2][2]; a3 += red[threadIdx.x + k * cp2][3];
+    }
+    const double ss[2] = {a0, a2}, s2s[2] = {a1, a3};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = 2 * cp + e;
+      const double mu = ss[e] / (double)M;
+      double var = s2s[e] / (double)M - mu * mu;
       if (var < 0.0) var = 0.0;
       const float is = (float)(1.0 / sqrt(var + (double)eps));
       const float sc = is * gamma[c];
@@ -272,8 +278,8 @@ __global__ __launch_bounds__(256) void bn_train_fwd_fused_kernel(
         }
       }
     }
-    __syncthreads();
   }
+  __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   const int cq = C / 4;
   const int64_t n4 = M * cq;
@@ -294,30 +300,43 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(
     const float* __restrict__ ws, int rows, float* __restrict__ sums, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ dprelu, float* __restrict__ dy, int64_t M, int C, int act,
     float slope, const float* __restrict__ prelu, int want_dy) {
-  extern __shared__ float sm[];  // [2C+1] reduced sums
-  __shared__ double red[256];
+  extern __shared__ float sm[];  // [2C+4] reduced sums
+  __shared__ double red[256][4];
   if (act == SRX_ACT_PRELU) slope = prelu[0];
-  const int ncol = 2 * C + 1, stride = 2 * C + 4;
-  // columns are contiguous in ws: 64 columns x 4 row lanes per pass
-  for (int cbase = 0; cbase < ncol; cbase += 64) {
-    const int c = cbase + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-    double s = 0.0;
-    if (c < ncol)
-      for (int r = rl; r < rows; r += 4) s += (double)ws[(size_t)r * stride + c];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (rl == 0 && c < ncol) {
-      const float t = (float)(red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+  // Table [rows][2C+4] read as float4 quads: thread t owns quad t % QN and the rows t / QN + k * RL.
+  const int QN = (2 * C + 4) / 4, RL = 256 / QN;
+  const int q = threadIdx.x % QN, rl = threadIdx.x / QN;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const f32x4* tab = reinterpret_cast<const f32x4*>(ws);
+  if (rl < RL) {
+#pragma unroll 8
+    for (int r = rl; r < rows; r += RL) {
+      const f32x4 v = tab[(size_t)r * QN + q];
+      a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+    }
+  }
+  red[threadIdx.x][0] = a0; red[threadIdx.x][1] = a1; red[threadIdx.x][2] = a2; red[threadIdx.x][3] = a3;
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < RL; ++k) {
+      a0 += red[threadIdx.x + k * QN][0]; a1 += red[threadIdx.x + k * QN][1];
+      a2 += red[threadIdx.x + k * QN][2]; a3 += red[threadIdx.x + k * QN][3];
+    }
+    const double t4[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * q + e;
+      const float t = (float)t4[e];
       sm[c] = t;
-      if (blockIdx.x == 0) {
+      if (blockIdx.x == 0 && c <= 2 * C) {
         sums[c] = t;
         if (c < C) { if (dbeta) dbeta[c] += t; }
         else if (c < 2 * C) { if (dgamma) dgamma[c - C] += t; }
         else if (dprelu) dprelu[0] += t;
       }
     }
-    __syncthreads();
   }
+  __syncthreads();
   if (!want_dy) return;
   const int cq = C / 4;
   const int64_t n4 = M * cq;
@@ -342,10 +361,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(
   }
 }
 
-// Measured on MI355X (16x24x24x64 layers): the fused forms are SLOWER (16.5 / 45 us vs 5+5 / 5+5 us for the
-// separate finalize + apply kernels) because every workgroup serialises on the table re-reduction, so the
-// fused path is disabled; the one-call entry points below always take the two-kernel route.
-constexpr int64_t FUSE_MAX_TABLE = 0;
+// Measured on MI355X, in a hipGraph (tools/bench_bn.py), fused vs finalize + apply as two kernels:
+//   16x24x24x64 (generator):     forward 8.3 vs 7.2 us, backward 14.7 vs 12.1 us  -> slower
+//   16x48x48x128 (discriminator): forward 4.1 vs 7.0 us, backward 57 vs 32 us     -> mixed
+// Every workgroup of the apply pass re-reducing the partial table (wide independent loads, fp64 sums) costs
+// more than the kernel boundary + one-workgroup finalize kernel it saves, and fewer / fatter reduction
+// workgroups starve the backward reduce.  The fused forms stay off; SRX_BN_FUSE_MAX=<floats> enables them
+// for tables up to that size (experiments).
+static int64_t fuse_max_table() {
+  static const char* e = getenv("SRX_BN_FUSE_MAX");
+  return e ? atoll(e) : 0;
+}
+#define FUSE_MAX_TABLE fuse_max_table()
+
+// rows per workgroup of the backward reduction when its table is re-reduced by the fused apply kernel:
+// about 64 partial rows whatever the tensor size (64 workgroups stream a 16x24x24x64 pair in ~1 us)
+__host__ inline int fused_bwd_rows_per_block(int64_t M) {
+  int64_t r = srx_roundup(srx_cdiv(M, 64), 4);
+  return (int)(r < 32 ? 32 : r);
+}
 
 int check_c(int C, const char* who) {
   SRX_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024, "%s: C must be a multiple of 4 in [4,1024]", who);
@@ -418,7 +452,7 @@ extern "C" int srx_bn_act_bwd_reduce(const float* dout, const float* y, const fl
   const int rows = srx_bn_stat_rows(M);
   hipStream_t st = srx_stream(stream);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, dout, y, mean, invstd, gamma, beta,
-                     ws, M, C, act, slope, prelu);
+                     ws, M, C, act, slope, prelu, rows_per_block(M));
   SRX_CHECK_LAUNCH("bn_bwd_reduce_kernel");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)srx_cdiv(2 * C + 1, 4)), dim3(256), 0, st, ws, rows, C,
                      sums, dgamma_acc, dbeta_acc, dprelu_acc);
@@ -453,7 +487,7 @@ extern "C" int srx_bn_train_fwd(const float* y, const float* partials, int rows,
               "bn_train_fwd: bad argument");
   SRX_REQUIRE(act != SRX_ACT_PRELU || prelu, "bn_train_fwd: PReLU needs its slope pointer");
   SRX_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running stats must come in pairs");
-  if ((int64_t)rows * C * 2 > FUSE_MAX_TABLE || (C > 256 && C % 256 != 0) || (C <= 256 && 256 % C != 0)) {
+  if ((int64_t)rows * C * 2 > FUSE_MAX_TABLE || C < 8 || C > 512 || 256 % (C / 2) != 0) {
     if (int rc = srx_bn_finalize(partials, rows, M, C, eps, momentum, save_mean, save_invstd, running_mean,
                                  running_var, nbt, stream))
       return rc;
@@ -479,8 +513,9 @@ extern "C" int srx_bn_act_bwd(const float* dout, const float* y, const float* me
   if (int rc = check_c(C, "bn_act_bwd")) return rc;
   SRX_REQUIRE(dout && y && mean && invstd && gamma && beta && sums && ws && M > 0, "bn_act_bwd: bad argument");
   SRX_REQUIRE(act != SRX_ACT_PRELU || prelu, "bn_act_bwd: PReLU needs its slope pointer");
-  const int rows = srx_bn_stat_rows(M);
-  if (!training || (int64_t)rows * (2 * C + 4) > FUSE_MAX_TABLE) {
+  const int rpb = fused_bwd_rows_per_block(M);
+  const int rows = (int)srx_cdiv(M, rpb);  // (never more than srx_bn_stat_rows(M): the workspace bound holds)
+  if (!training || (int64_t)rows * (2 * C + 4) > FUSE_MAX_TABLE || (2 * C + 4) / 4 > 256 || rows > srx_bn_stat_rows(M)) {
     if (int rc = srx_bn_act_bwd_reduce(dout, y, mean, invstd, gamma, beta, sums, M, C, act, slope, prelu, dgamma_acc,
                                        dbeta_acc, dprelu_acc, ws, ws_floats, stream))
       return rc;
@@ -491,7 +526,7 @@ extern "C" int srx_bn_act_bwd(const float* dout, const float* y, const float* me
   if (ws_floats < srx_bn_bwd_ws_floats(M, C)) SRX_FAIL(SRX_E_WORKSPACE, "bn_act_bwd: workspace too small");
   hipStream_t st = srx_stream(stream);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, dout, y, mean, invstd, gamma, beta,
-                     ws, M, C, act, slope, prelu);
+                     ws, M, C, act, slope, prelu, rpb);
   SRX_CHECK_LAUNCH("bn_bwd_reduce_kernel");
   const int64_t n4 = M * C / 4;
   int64_t blocks = srx_cdiv(n4, 256 * 4);
