@@ -52,9 +52,9 @@ int srx_last_error(char* buf, size_t n);
 /* number of compute units of the current device (used by the host for launch heuristics) */
 int srx_device_cus(void);
 /* Per-launch timing of the convolution kernels (measurement aid for bench.py's roofline leg; no
- * reference counterpart).  Between start and stop every conv kernel launch is bracketed by two HIP
- * events on its own stream -- the main kernel only, not its fix-up / reduce companion.  Not to be
- * used inside a hipGraph capture.  srx_prof_stop returns the number of records; srx_prof_get
+ * reference counterpart).  Between start and stop every conv kernel is dispatched with its own start /
+ * stop HIP events on its stream (hipExtLaunchKernelGGL) -- the main kernel only, not its fix-up / reduce
+ * companion.  Not to be used inside a hipGraph capture.  srx_prof_stop returns the number of records; srx_prof_get
  * (after stop) synchronises on record i and returns its kernel name, duration and FLOPs. */
 int srx_prof_start(int max_launches);
 int srx_prof_stop(void);

@@ -33,9 +33,11 @@ extern "C" int srx_device_cus(void) {
 }
 
 // ---------------------------------------------------------------------------
-// Per-launch timing of the convolution kernels: a pair of HIP events recorded on the launch stream
-// right around the ONE kernel named in the record (not its fix-up / reduce companions).  bench.py's
-// roofline leg reads these; off by default and never on inside a hipGraph capture.
+// Per-launch timing of the convolution kernels: the ONE kernel named in the record (not its fix-up /
+// reduce companions) is dispatched with hipExtLaunchKernelGGL and its own start / stop HIP events, i.e.
+// the timestamps of that dispatch on its stream -- events recorded as separate packets around a launch
+// add ~7 us of command-processor time to a 50 us kernel.  bench.py's roofline leg reads these; off by
+// default and never on inside a hipGraph capture.
 // ---------------------------------------------------------------------------
 namespace {
 struct ProfRec { hipEvent_t e0, e1; char name[64]; double flops; };
@@ -47,21 +49,16 @@ bool g_prof_on = false;
 
 bool srx_prof_on() { return g_prof_on; }
 
-void srx_prof_begin_launch(const char* name, double flops, hipStream_t st) {
+bool srx_prof_take(const char* name, double flops, hipEvent_t* e0, hipEvent_t* e1) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (!g_prof_on || g_prof_n >= (int)g_prof.size()) return;
-  ProfRec& r = g_prof[g_prof_n];
+  if (!g_prof_on || g_prof_n >= (int)g_prof.size()) return false;
+  ProfRec& r = g_prof[g_prof_n++];
   strncpy(r.name, name, sizeof(r.name) - 1);
   r.name[sizeof(r.name) - 1] = 0;
   r.flops = flops;
-  (void)hipEventRecord(r.e0, st);
-}
-
-void srx_prof_end_launch(hipStream_t st) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (!g_prof_on || g_prof_n >= (int)g_prof.size()) return;
-  (void)hipEventRecord(g_prof[g_prof_n].e1, st);
-  ++g_prof_n;
+  *e0 = r.e0;
+  *e1 = r.e1;
+  return true;
 }
 
 extern "C" int srx_prof_start(int max_launches) {
@@ -69,9 +66,7 @@ extern "C" int srx_prof_start(int max_launches) {
   SRX_REQUIRE(max_launches > 0 && max_launches <= (1 << 20), "prof_start: bad capacity");
   while ((int)g_prof.size() < max_launches) {
     ProfRec r{};
-    // device-scope release only: a system-scope fence per event would add microseconds to every bracket
-    if (hipEventCreateWithFlags(&r.e0, hipEventReleaseToDevice) != hipSuccess ||
-        hipEventCreateWithFlags(&r.e1, hipEventReleaseToDevice) != hipSuccess)
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess)
       SRX_FAIL(SRX_E_HIP, "prof_start: hipEventCreate failed");
     g_prof.push_back(r);
   }

@@ -1075,13 +1075,10 @@ int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(p.full + p.tail * p.split);
-  if (srx_prof_on()) {
-    char nm[64];
-    snprintf(nm, sizeof(nm), "gconv_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, KS, XR, PR);
-    srx_prof_begin_launch(nm, 2.0 * a.M * a.Cn * a.K, st);
-  }
-  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN, KS, XR, PR>), grid, dim3((BM / WM) * (BN / WN) * 64 * KS), lds, st, a);
-  if (srx_prof_on()) srx_prof_end_launch(st);
+  char nm[64];
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "gconv_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, KS, XR, PR);
+  SRX_LAUNCH_PROF(nm, 2.0 * a.M * a.Cn * a.K, (gconv_kernel<BM, BN, WM, WN, KS, XR, PR>), grid,
+                  dim3((BM / WM) * (BN / WN) * 64 * KS), lds, st, a);
   SRX_CHECK_LAUNCH("gconv_kernel");
   if (p.split > 1) {
     hipLaunchKernelGGL((tail_fixup_kernel<BM + XR, BN>), dim3(p.tail * (BN / 16)), dim3(256), 0, st, a);
@@ -1097,16 +1094,14 @@ int launch_gconv_multi(const GMulti& m, size_t lds, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_multi_kernel<BM, BN, WM, WN, XR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
+  char nm[64];
+  double fl = 0.0;
   if (srx_prof_on()) {
-    char nm[64];
     snprintf(nm, sizeof(nm), "gconv_multi_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, XR);
-    double fl = 0.0;
     for (int i = 0; i < m.n; ++i) fl += 2.0 * m.g[i].M * m.g[i].Cn * m.g[i].K;
-    srx_prof_begin_launch(nm, fl, st);
   }
-  hipLaunchKernelGGL((gconv_multi_kernel<BM, BN, WM, WN, XR>), dim3(m.first[m.n]), dim3((BM / WM) * (BN / WN) * 64), lds, st,
-                     m);
-  if (srx_prof_on()) srx_prof_end_launch(st);
+  SRX_LAUNCH_PROF(nm, fl, (gconv_multi_kernel<BM, BN, WM, WN, XR>), dim3(m.first[m.n]), dim3((BM / WM) * (BN / WN) * 64),
+                  lds, st, m);
   SRX_CHECK_LAUNCH("gconv_multi_kernel");
   return SRX_OK;
 }
@@ -1646,10 +1641,9 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
   if (need > ws_floats) SRX_FAIL(SRX_E_WORKSPACE, "conv2d_bwd_weight: workspace %zu < %zu floats", ws_floats, need);
   a.bslab = db ? ws + (size_t)nsplit * a.Cnw * a.Kw : nullptr;
   dim3 grid((unsigned)tiles, 1, nsplit);
-  if (srx_prof_on()) srx_prof_begin_launch(d->precision ? "wgrad_kernel<1>" : "wgrad_kernel<0>", 2.0 * a.M * d->Cout * a.K, st);
-  if (d->precision) hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(wgrad_kernel<0>, grid, dim3(256), 0, st, a);
-  if (srx_prof_on()) srx_prof_end_launch(st);
+  const double wfl = 2.0 * a.M * d->Cout * a.K;
+  if (d->precision) SRX_LAUNCH_PROF("wgrad_kernel<1>", wfl, wgrad_kernel<1>, grid, dim3(256), 0, st, a);
+  else SRX_LAUNCH_PROF("wgrad_kernel<0>", wfl, wgrad_kernel<0>, grid, dim3(256), 0, st, a);
   SRX_CHECK_LAUNCH("wgrad_kernel");
   const int64_t n = (int64_t)d->Cout * g.K;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, st, ws, nsplit, a.Cnw, a.Kw,

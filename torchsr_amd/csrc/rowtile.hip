@@ -241,13 +241,10 @@ int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   });
   const int nb = patch_batches(d->W);
-  if (srx_prof_on())
-    srx_prof_begin_launch(nb == 1 ? "rt36_conv3x3_c64_kernel<1>" : "rt36_conv3x3_c64_kernel<2>", 2.0 * a.M * 64 * KTOT, st);
-  if (nb == 1)
-    hipLaunchKernelGGL(rt36_conv3x3_c64_kernel<1>, dim3((unsigned)(a.M / RT)), dim3(256), lds, st, a);
-  else
-    hipLaunchKernelGGL(rt36_conv3x3_c64_kernel<2>, dim3((unsigned)(a.M / RT)), dim3(256), lds, st, a);
-  if (srx_prof_on()) srx_prof_end_launch(st);
+  const double fl = 2.0 * a.M * 64 * KTOT;
+  const dim3 grid((unsigned)(a.M / RT));
+  if (nb == 1) SRX_LAUNCH_PROF("rt36_conv3x3_c64_kernel<1>", fl, rt36_conv3x3_c64_kernel<1>, grid, dim3(256), lds, st, a);
+  else SRX_LAUNCH_PROF("rt36_conv3x3_c64_kernel<2>", fl, rt36_conv3x3_c64_kernel<2>, grid, dim3(256), lds, st, a);
   SRX_CHECK_LAUNCH("rt36_conv3x3_c64_kernel");
   return SRX_OK;
 }

@@ -1,6 +1,7 @@
 // Internal helpers shared by the HIP translation units of libsrx_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/srx.h"
@@ -30,8 +31,16 @@ void srx_set_error(const char* fmt, ...);
 
 // api.cpp: optional per-launch event timing (srx_prof_start / srx_prof_stop / srx_prof_get)
 bool srx_prof_on();
-void srx_prof_begin_launch(const char* name, double flops, hipStream_t st);
-void srx_prof_end_launch(hipStream_t st);
+bool srx_prof_take(const char* name, double flops, hipEvent_t* e0, hipEvent_t* e1);
+// launch `kernel`; with the profiler on, as a dispatch that carries its own start / stop events
+#define SRX_LAUNCH_PROF(name, flops, kernel, grid, block, lds, st, ...)                              \
+  do {                                                                                               \
+    hipEvent_t e0__ = nullptr, e1__ = nullptr;                                                       \
+    if (srx_prof_on() && srx_prof_take(name, flops, &e0__, &e1__))                                   \
+      hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), st, e0__, e1__, 0, __VA_ARGS__); \
+    else                                                                                             \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                 \
+  } while (0)
 
 // thin.hip: 3-channel-side convolutions on v_mfma_f32_4x4x1 (internal, called from gconv.hip)
 bool srx_thin_wgrad_applicable(const srx_conv2d_t* d);

@@ -319,19 +319,16 @@ int srx_thin_wgrad(const srx_conv2d_t* d, const float* x, const float* dy, float
     SRX_FAIL(SRX_E_WORKSPACE, "conv2d_bwd_weight(thin): workspace too small");
   a.nranges = nranges;
   const unsigned blocks = (unsigned)(nslabs * groups);
-  if (srx_prof_on()) {
-    char nm[64];
-    snprintf(nm, sizeof(nm), "thin_wgrad_kernel<%d, %d, %d, %d>", d->KH, d->KW, groups, thin_out ? -1 : 1);
-    srx_prof_begin_launch(nm, 2.0 * d->N * d->H * d->W * d->KH * d->KW * 64 * (thin_out ? d->Cout : d->Cin), st);
-  }
+  char nm[64];
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "thin_wgrad_kernel<%d, %d, %d, %d>", d->KH, d->KW, groups, thin_out ? -1 : 1);
+  const double fl = 2.0 * d->N * d->H * d->W * d->KH * d->KW * 64 * (thin_out ? d->Cout : d->Cin);
   if (d->KH == 9) {
-    if (thin_out) hipLaunchKernelGGL((thin_wgrad_kernel<9, 9, 3, -1>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((thin_wgrad_kernel<9, 9, 3, +1>), dim3(blocks), dim3(256), 0, st, a);
+    if (thin_out) SRX_LAUNCH_PROF(nm, fl, (thin_wgrad_kernel<9, 9, 3, -1>), dim3(blocks), dim3(256), 0, st, a);
+    else SRX_LAUNCH_PROF(nm, fl, (thin_wgrad_kernel<9, 9, 3, +1>), dim3(blocks), dim3(256), 0, st, a);
   } else {
-    if (thin_out) hipLaunchKernelGGL((thin_wgrad_kernel<3, 3, 1, -1>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((thin_wgrad_kernel<3, 3, 1, +1>), dim3(blocks), dim3(256), 0, st, a);
+    if (thin_out) SRX_LAUNCH_PROF(nm, fl, (thin_wgrad_kernel<3, 3, 1, -1>), dim3(blocks), dim3(256), 0, st, a);
+    else SRX_LAUNCH_PROF(nm, fl, (thin_wgrad_kernel<3, 3, 1, +1>), dim3(blocks), dim3(256), 0, st, a);
   }
-  if (srx_prof_on()) srx_prof_end_launch(st);
   SRX_CHECK_LAUNCH("thin_wgrad_kernel");
   const int taps = d->KH * d->KW;
   const int cthin = thin_out ? d->Cout : d->Cin;
@@ -364,13 +361,10 @@ template <int K, int R>
 static int launch_thin_fwd2(const ThinF& a, hipStream_t st) {
   constexpr int PH = 4 * R + K - 1, PW = 32 + K - 1;
   const size_t lds = (size_t)(PH * PW * 8 + 4 * K * K * 8) * sizeof(float);
-  if (srx_prof_on()) {
-    char nm[64];
-    snprintf(nm, sizeof(nm), "thin_fwd2_kernel<%d, %d>", K, R);
-    srx_prof_begin_launch(nm, 2.0 * a.N * a.H * a.W * K * K * 64 * a.Cout, st);
-  }
-  hipLaunchKernelGGL((thin_fwd2_kernel<K, R>), dim3((unsigned)(a.N * a.tiles_h * a.tiles_w)), dim3(256), lds, st, a);
-  if (srx_prof_on()) srx_prof_end_launch(st);
+  char nm[64];
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "thin_fwd2_kernel<%d, %d>", K, R);
+  SRX_LAUNCH_PROF(nm, 2.0 * a.N * a.H * a.W * K * K * 64 * a.Cout, (thin_fwd2_kernel<K, R>),
+                  dim3((unsigned)(a.N * a.tiles_h * a.tiles_w)), dim3(256), lds, st, a);
   SRX_CHECK_LAUNCH("thin_fwd2_kernel");
   return SRX_OK;
 }
