@@ -130,11 +130,12 @@ int srx_pack_table_run(const void* dev_table, int n_records, long long max_elems
  * follows (srgan/residual.py:65,68; srgan/discriminator.py:36-60). */
 int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float* wpk_fwd, const float* bias,
                    float* y, float* bn_partials, float* ws, size_t ws_floats, void* stream);
-/* y = act(conv(x, W) + bias) + residual, residual laid out like y (not for shuffle layers).  With the
- * eval-mode BatchNorm folded into W and bias by the host this is a whole `x + BN(conv(.))` of the
- * residual block (srgan/residual.py:86-91, srgan/generator.py:77-78) in one kernel. */
+/* y = act(conv(x, W) + bias) * out_scale + residual, residual laid out like y (not for shuffle layers).
+ * With the eval-mode BatchNorm folded into W and bias by the host this is a whole `x + BN(conv(.))` of the
+ * residual block (srgan/residual.py:86-91, srgan/generator.py:77-78) in one kernel; with out_scale = 0.2 it
+ * is `conv5 * scale_ratio + x` of the dense block (esrgan/residual.py:86). */
 int srx_conv2d_fwd_residual(const srx_conv2d_t* d, const float* x, const float* wpk_fwd, const float* bias,
-                            const float* residual, float* y, float* ws, size_t ws_floats, void* stream);
+                            const float* residual, float out_scale, float* y, float* ws, size_t ws_floats, void* stream);
 /* dx = conv_transpose(dy, W)  (autograd of nn.Conv2d wrt its input).  accumulate != 0 adds into dx
  * (stride-1 layers on the generic kernel): the dense block's convs share one 192-channel input buffer
  * (channel stride Cin_s, the first Cin channels are this layer's input), so their input gradients sum in

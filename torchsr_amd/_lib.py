@@ -73,7 +73,7 @@ _SIGS = {
     'srx_pack_table_run': (_I, [_P, _I, C.c_longlong, _P]),
     'srx_conv2d_pack': (_I, [_D, _P, _P, _P, _P]),
     'srx_conv2d_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
-    'srx_conv2d_fwd_residual': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    'srx_conv2d_fwd_residual': (_I, [_D, _P, _P, _P, _P, _F, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_data': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
     'srx_conv2d_bwd_weight': (_I, [_D, _P, _P, _P, _I, _P, _P, _Z, _P]),
     'srx_colsum_ws_floats': (_Z, [_L, _I]),

@@ -49,6 +49,7 @@ struct GArgs {
   // shared dense-block buffer, or the skip input of a residual block in eval mode (BatchNorm folded into the
   // conv, `x + conv(...)` in one kernel).  Linear outputs only.
   const float* add;
+  float oscale;  // applied to act(acc + bias) before the addend (conv5 * 0.2 + x of the dense block); 1 otherwise
 };
 
 
@@ -433,7 +434,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
           v = v > 0.f ? v : v * a.slope;
           const unsigned off = (mok && cok[j]) ? rowoff + ocol[j] : 0xffffffffu;
           if (decltype(accum)::value)
-            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
+            v = v * a.oscale + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
         }
       }
@@ -470,7 +471,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       xs2 += vs * vs;
       v = v > 0.f ? v : v * a.slope;
       const unsigned off = (mok && xok) ? rowoff + 4u * (unsigned)oc : 0xffffffffu;
-      if (a.add) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
+      if (a.add) v = v * a.oscale + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
     }
   }
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const GArgs a) {
       }
       if (col < a.Cs) {  // Cs is a multiple of 4
         f32x4* o = reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col);
-        if (a.add) v += *reinterpret_cast<const f32x4*>(a.add + (size_t)m * a.Co + col);
+        if (a.add) v = v * a.oscale + *reinterpret_cast<const f32x4*>(a.add + (size_t)m * a.Co + col);
         *o = v;
       }
     }
@@ -1460,13 +1461,15 @@ extern "C" int srx_pack_table_run(const void* dev_table, int nrec, long long max
 }
 
 static int conv_fwd_impl(const srx_conv2d_t* d, const float* x, const float* wpk, const float* bias, const float* residual,
-                         float* y, float* bn_partials, float* ws, size_t ws_floats, void* stream) {
+                         float out_scale, float* y, float* bn_partials, float* ws, size_t ws_floats, void* stream) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(x && wpk && y, "conv2d_fwd: null pointer");
   if (residual && d->shuffle) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_fwd: residual with PixelShuffle is not implemented");
   hipStream_t st = srx_stream(stream);
   if (srx_thin_fwd_applicable(d) && !bn_partials && !residual) return srx_thin_fwd(d, x, wpk, bias, y, d->Cout, st);
-  if (srx_rt36_applicable(d)) return srx_rt36_run(d, x, wpk, bias, residual, y, bn_partials, d->act, d->slope, st);
+  if (srx_rt36_applicable(d) && out_scale == 1.f)
+    return srx_rt36_run(d, x, wpk, bias, residual, y, bn_partials, d->act, d->slope, st);
+  if (srx_rt36_applicable(d)) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_fwd_residual: out_scale != 1 on the 36-pixel row tile");
   const Geo g = fwd_geo(d);
   GArgs a{};
   a.in = x; a.w = wpk; a.bias = bias; a.part = nullptr;
@@ -1488,6 +1491,7 @@ static int conv_fwd_impl(const srx_conv2d_t* d, const float* x, const float* wpk
   a.part = bn_partials;
   a.out = y;
   a.add = residual;
+  a.oscale = out_scale;
   a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin_s * sizeof(float));
   a.w_bytes = (unsigned)((size_t)g.Cnp * g.Kp * sizeof(float));
   return run_gconv(a, fwd_plan(d, g), ws, ws_floats, st, d->precision);
@@ -1495,13 +1499,14 @@ static int conv_fwd_impl(const srx_conv2d_t* d, const float* x, const float* wpk
 
 extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float* wpk, const float* bias, float* y,
                               float* bn_partials, float* ws, size_t ws_floats, void* stream) {
-  return conv_fwd_impl(d, x, wpk, bias, nullptr, y, bn_partials, ws, ws_floats, stream);
+  return conv_fwd_impl(d, x, wpk, bias, nullptr, 1.f, y, bn_partials, ws, ws_floats, stream);
 }
 
 extern "C" int srx_conv2d_fwd_residual(const srx_conv2d_t* d, const float* x, const float* wpk, const float* bias,
-                                       const float* residual, float* y, float* ws, size_t ws_floats, void* stream) {
+                                       const float* residual, float out_scale, float* y, float* ws, size_t ws_floats,
+                                       void* stream) {
   SRX_REQUIRE(residual, "conv2d_fwd_residual: null residual");
-  return conv_fwd_impl(d, x, wpk, bias, residual, y, nullptr, ws, ws_floats, stream);
+  return conv_fwd_impl(d, x, wpk, bias, residual, out_scale, y, nullptr, ws, ws_floats, stream);
 }
 
 extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
@@ -1549,6 +1554,7 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     a.in_bytes = (unsigned)dy_bytes;
     a.w_bytes = (unsigned)((size_t)pad_rows(d->Cin) * c.Kp * sizeof(float));
     a.add = accumulate ? dx : nullptr;
+    a.oscale = 1.f;
     if (d->stride == 1) {
       if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st, d->precision)) return rc;
     } else if (nc <= 4) {

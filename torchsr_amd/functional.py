@@ -828,7 +828,7 @@ class FoldedConv:
             r = _chk(residual, 'folded_conv.residual')
             if r.shape != y.shape:
                 raise RuntimeError('folded_conv: residual must have the output shape')
-            call('srx_conv2d_fwd_residual', dref, _p(x), _p(st.wpk_fwd), _p(self.b), _p(r), _p(y), _p(ws), nws, _stream())
+            call('srx_conv2d_fwd_residual', dref, _p(x), _p(st.wpk_fwd), _p(self.b), _p(r), 1.0, _p(y), _p(ws), nws, _stream())
         return y
 
 
@@ -879,13 +879,11 @@ class _DenseBlock(Function):
             bp = None if bias is None else _p(_chk(bias.detach(), 'dense_block.bias'))
             nws = L.srx_conv2d_fwd_ws_floats(dref)
             ws = _ws(nws, x) if nws else None
-            if last:
-                out5 = torch.empty((n, h, w, st.cout), dtype=torch.float32, device=dev)
-                call('srx_conv2d_fwd', dref, _p(buf), _p(st.wpk_fwd), bp, _p(out5), None, _p(ws), nws, s)
+            if last:  # y = conv5(...) * scale + x in the conv's epilogue (esrgan/residual.py:86)
+                y = torch.empty_like(x)
+                call('srx_conv2d_fwd_residual', dref, _p(buf), _p(st.wpk_fwd), bp, _p(x), float(scale), _p(y), _p(ws), nws, s)
             else:
                 call('srx_conv2d_fwd', dref, _p(buf), _p(st.wpk_fwd), bp, buf.data_ptr() + 4 * cin, None, _p(ws), nws, s)
-        y = torch.empty_like(x)
-        call('srx_axpby', _p(out5), _p(x), _p(y), x.numel(), float(scale), 1.0, s)
         ctx.states, ctx.descs, ctx.scale = states, descs, float(scale)
         ctx.dims = (n, h, w, c0, g, total, m)
         ctx.params = wb
