@@ -12,7 +12,9 @@
 // weights [N_pad][K_pad] with K = (tap, channel) contiguous, so both MFMA
 // operands are "k-contiguous rows" and are staged into XOR-swizzled LDS rows of
 // 32 floats read back with conflict-free ds_read_b128.
-// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak).
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak), plus
+// v_mfma_f32_16x16x4_f32 for the 16 extra rows of the 144-row tiles and v_mfma_f32_32x32x16_bf16 for
+// the bf16-product mode (srx_conv2d_t::precision).
 #include "srx_common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -177,9 +179,9 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // Two register stages: while chunk k is multiplied out of LDS, chunk k+1 waits in registers and
-  // the loads of chunk k+2 are in flight.  With one workgroup per CU (most launches here have fewer
-  // tiles than 2 x CUs) a single stage leaves ~0.5 us of L2/HBM latency exposed per chunk.
+  // Three register stages: while chunk k is multiplied out of LDS, chunk k+1 is being written to the
+  // ring and the loads of chunks k+2 and k+3 are in flight (a load has two full steps to arrive).  With
+  // one workgroup per CU a single stage leaves ~0.5 us of L2/HBM latency exposed per chunk.
   f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB], ra2[RA], rb2[RB];
   // Every step issues the same RA + RB loads -- past the end of the k range they are pointed out of
   // range and cost nothing -- so that the compiler can count outstanding loads exactly (s_waitcnt
