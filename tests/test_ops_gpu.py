@@ -453,3 +453,27 @@ def test_full_size_adjoint_identities(dev, case):
         y12 = conv(0.5 * x.detach() - 2.0 * x2)
         y2 = conv(x2)
     assert rel_err(y12, 0.5 * y.detach() - 2.0 * y2) < 2e-5
+
+
+def _random_conv_cases(count, seed):
+    rng = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < count:
+        k = int(rng.choice([1, 3, 3, 3, 5]))
+        s = int(rng.choice([1, 1, 2, 3]))
+        p = int(rng.randint(0, k // 2 + 2))
+        cin = int(rng.choice([4, 8, 12, 24, 32, 40, 64, 96, 128, 160, 200]))
+        cout = int(rng.choice([4, 8, 12, 20, 32, 48, 64, 100, 128, 256]))
+        n, h, w = int(rng.randint(1, 4)), int(rng.randint(k + 1, 30)), int(rng.randint(k + 1, 30))
+        if (h + 2 * p - k) // s + 1 < 1 or (w + 2 * p - k) // s + 1 < 1:
+            continue
+        cases.append((n, h, w, cin, cout, k, s, p, bool(rng.randint(0, 2)), int(rng.randint(0, 3)), 0))
+    return cases
+
+
+@pytest.mark.parametrize('case', _random_conv_cases(36, 20260401), ids=lambda c: 'x'.join(map(str, c)))
+def test_conv2d_random_shapes(dev, case):
+    """Seeded sweep over ragged shapes, strides 1-3, paddings from 0 to beyond 'same', odd channel counts:
+    whatever tile / split plan the library picks, forward, data gradient, weight and bias gradients must agree
+    with the CPU convolution."""
+    test_conv2d_fwd_bwd(dev, case)
