@@ -8,8 +8,8 @@ updated in place, as ``nn.BatchNorm2d`` does in training mode.
 
 Pinned: ``oracle/gen_golden.py`` (run in the build container, where the reference is
 importable) asserts these functions against the reference's own modules and writes
-``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` re-checks the oracle against
-those files everywhere.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``tests/golden/*.npz``; ``tests/test_cpu.py`` re-checks the oracle against those files
+everywhere.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import this package.
 """
 import math
@@ -210,3 +210,64 @@ class SRGANStepOracle:
 
     def state(self, which: str) -> State:
         return {k: v.detach() for k, v in getattr(self, which).items()}
+
+
+class SRGANDataParallelOracle:
+    """``world`` data-parallel replicas of the two loop bodies in ONE process (config 3).
+
+    What ``DistributedDataParallel`` does to them (torchsr/srgan/trainer.py:142-157): every rank runs the loop
+    body on its own shard with identical weights, the gradients are averaged over the ranks before each
+    optimiser step, and BatchNorm is NOT synchronised -- every rank normalises with its own batch statistics
+    and keeps its own running statistics (plain ``nn.BatchNorm2d``; ``broadcast_buffers=False`` for D at :156,
+    and G's broadcast of rank 0's buffers never influences a training-mode forward).  Because the weights stay
+    identical, one set of weight leaves is shared and each rank only owns its BatchNorm buffers: the mean of
+    the per-rank losses back-propagates exactly the averaged gradient.
+    """
+
+    def __init__(self, g_sd: State, d_sd: State, vgg_sd: State, world: int):
+        self.world = world
+        self.g = {k: v.clone() for k, v in g_sd.items()}
+        self.d = {k: v.clone() for k, v in d_sd.items()}
+        self.vgg = {k: v.clone() for k, v in vgg_sd.items()}
+        g_params, d_params = _leaves(self.g), _leaves(self.d)
+        self.psnr_optimizer, self.disc_optimizer, self.gen_optimizer = Adam(g_params), Adam(d_params), Adam(g_params)
+
+        def per_rank(sd):
+            out = [sd]  # rank 0 keeps the dict itself: its buffers are the ones a checkpoint would hold
+            for _ in range(1, world):
+                out.append({k: (v if v.requires_grad else v.clone()) for k, v in sd.items()})
+            return out
+        self.g_ranks, self.d_ranks = per_rank(self.g), per_rank(self.d)
+
+    def pretrain_step(self, low_res, high_res):
+        """``low_res`` / ``high_res``: one shard per rank."""
+        self.psnr_optimizer.zero_grad()
+        losses = [F.mse_loss(generator_forward(self.g_ranks[r], low_res[r], True), high_res[r]) for r in range(self.world)]
+        (sum(losses) / self.world).backward()
+        self.psnr_optimizer.step()
+        return [float(v.detach()) for v in losses]
+
+    def gan_step(self, low_res, high_res):
+        W = self.world
+        ones = [torch.full((low_res[r].size(0), 1), 1.0) for r in range(W)]
+        zeros = [torch.full((low_res[r].size(0), 1), 0.0) for r in range(W)]
+        self.disc_optimizer.zero_grad()
+        sr = [generator_forward(self.g_ranks[r], low_res[r], True) for r in range(W)]
+        disc = []
+        for r in range(W):
+            d_real = F.binary_cross_entropy(discriminator_forward(self.d_ranks[r], high_res[r], True), ones[r])
+            d_fake = F.binary_cross_entropy(discriminator_forward(self.d_ranks[r], sr[r].detach(), True), zeros[r])
+            disc.append(d_real + d_fake)
+        (sum(disc) / W).backward()
+        self.disc_optimizer.step()
+        self.gen_optimizer.zero_grad()
+        gen, parts = [], []
+        for r in range(W):
+            content = vgg_loss(self.vgg, sr[r], high_res[r].detach())
+            adversarial = F.binary_cross_entropy(discriminator_forward(self.d_ranks[r], sr[r], True), ones[r])
+            gen.append(content + 0.001 * adversarial)
+            parts.append((float(disc[r].detach()), float(content.detach()), float(adversarial.detach()),
+                          float(gen[-1].detach())))
+        (sum(gen) / W).backward()
+        self.gen_optimizer.step()
+        return parts

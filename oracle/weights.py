@@ -60,6 +60,33 @@ def closed_form_state(template: Dict[str, torch.Tensor], prefix: str = '') -> Di
     return {k: closed_form_tensor(prefix + k, v) for k, v in template.items()}
 
 
+# Multi-step train fixtures.  With the plain closed-form fill one Adam step saturates the discriminator (every one
+# of its 23.6 M weights moves by lr = 1e-4 in the direction that helps: disc-loss 1.39 -> 4e-5 -> 1e-6) and later
+# steps then compare two fp32 evaluations of log(1e-6); ESRGAN's un-damped dense blocks blow its output up to
+# |pixel| ~ 100.  These per-key factors keep the GAN game at O(1) losses for several steps (SRGAN disc-loss
+# 1.38 -> 1.21 -> 1.05, ESRGAN 0.70 -> 0.63 -> 0.56), so steps 1.. can be held to the same tolerance as step 0:
+# the last classifier layer is scaled down (logit sensitivity to a 1e-4 move of the layers below), the dense-block
+# convs get the x0.1 the reference's own initialiser gives them (torchsr/esrgan/residual.py:58-63) and ESRGAN's
+# output conv is scaled so that the image is O(1).
+STEP_SCALES = {
+    'srgan.D': (('classifier.2.weight', 0.01),),
+    'esrgan.D': (('classifier.2.weight', 0.01),),
+    'srgan.G': (),
+    'esrgan.G': (('conv4.weight', 0.01), ('RDB', 0.1)),
+}
+
+
+def step_state(template: Dict[str, torch.Tensor], kind: str) -> Dict[str, torch.Tensor]:
+    """``closed_form_state`` with the conditioning of ``STEP_SCALES[kind]`` ('srgan.G', 'srgan.D', 'esrgan.G',
+    'esrgan.D'): the weights the train-step fixtures and tests start from."""
+    sd = closed_form_state(template)
+    for pat, factor in STEP_SCALES[kind]:
+        for k in sd:
+            if k.endswith('weight') and sd[k].dim() > 1 and pat in k:
+                sd[k] = sd[k] * factor
+    return sd
+
+
 def seeded_input(shape, seed: int) -> torch.Tensor:
     """Uniform [0,1) fp32 from a numpy PCG64 stream (stable across torch versions)."""
     rng = np.random.Generator(np.random.PCG64(seed))

@@ -16,7 +16,7 @@ def test_train_then_test_cli(dev, tmp_path, monkeypatch):
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'SLURM_NTASKS'):
         monkeypatch.delenv(k, raising=False)
     main(['train', '--model', 'srgan', '--train-dir', 'synthetic:16', '--batch-size', '4', '--epochs', '2',
-          '--pretrain-epochs', '1', '--disable-amp', '--seed', '3'])
+          '--pretrain-epochs', '1', '--disable-amp', '--seed', '3', '--vgg-weights', 'random'])
     for f in ('srgan-psnr-best.pth', 'srgan-psnr-latest.pth', 'srgan-gan-best.pth', 'srgan-gan-latest.pth',
               'output/SR_epoch1.png'):
         assert os.path.exists(f), f
@@ -59,5 +59,6 @@ def test_device_data_pipeline_cli(dev, tmp_path, monkeypatch):
                                 (100, 100), (150, 97)]):
         Image.fromarray((rng.rand(h, w, 3) * 255).astype('uint8')).save(f'imgs/{i}.png')
     main(['train', '--model', 'srgan', '--train-dir', 'imgs', '--batch-size', '4', '--epochs', '1',
-          '--pretrain-epochs', '1', '--disable-amp', '--seed', '5', '--device-data', '--skip-image-save'])
+          '--pretrain-epochs', '1', '--disable-amp', '--seed', '5', '--device-data', '--skip-image-save',
+          '--vgg-weights', 'random'])
     assert os.path.exists('srgan-gan-latest.pth')

@@ -11,7 +11,7 @@ import torch
 
 from conftest import GOLDEN, ROOT
 from oracle import srgan as O
-from oracle.weights import closed_form_state, tensor_digest
+from oracle.weights import closed_form_state, step_state, tensor_digest
 
 
 def rel(a, b):
@@ -61,22 +61,25 @@ def test_oracle_vgg_matches_reference_golden():
     assert abs(loss.item() - float(gold['loss'])) < 1e-5 * float(gold['loss'])
 
 
-def test_oracle_first_gan_step_matches_reference_trainer_golden():
+def test_oracle_gan_steps_match_reference_trainer_golden():
+    """Two consecutive steps: the fixtures start from ``step_state`` weights, which keep the discriminator out of
+    saturation, so the second step pins arithmetic as well as the first."""
     from torchsr_amd.srgan.discriminator import Discriminator
     from torchsr_amd.srgan.generator import Generator
     from torchsr_amd.srgan.loss import make_vgg19_features
     gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
     torch.set_num_threads(8)
-    orc = O.SRGANStepOracle(closed_form_state(Generator().state_dict()),
-                            closed_form_state(Discriminator().state_dict()),
+    orc = O.SRGANStepOracle(step_state(Generator().state_dict(), 'srgan.G'), step_state(Discriminator().state_dict(), 'srgan.D'),
                             closed_form_state(make_vgg19_features().state_dict(), prefix='features.'))
-    out = orc.gan_step(torch.from_numpy(gold['low_res']), torch.from_numpy(gold['high_res']))
-    assert np.allclose(out, gold['gan_losses'][0], rtol=1e-5)
-    assert abs(out[3] - gold['gan_ref_gen_losses'][0]) < 1e-5 * out[3]
     keys = [str(k) for k in gold['g_keys']]
-    for k, dg in zip(keys, gold['gan_g_digest'][0]):
-        d = tensor_digest(orc.g[k].detach())
-        assert abs(d[1] - dg[1]) <= 1e-5 * max(dg[1], 1e-9), k
+    assert 0.5 < gold['gan_losses'][2][0] < 2.0  # disc-loss is still O(1) at the third step
+    for step in range(2):
+        out = orc.gan_step(torch.from_numpy(gold['low_res']), torch.from_numpy(gold['high_res']))
+        assert np.allclose(out, gold['gan_losses'][step], rtol=1e-5)
+        assert abs(out[3] - gold['gan_ref_gen_losses'][step]) < 2e-5 * out[3]
+        for k, dg in zip(keys, gold['gan_g_digest'][step]):
+            d = tensor_digest(orc.g[k].detach())
+            assert abs(d[1] - dg[1]) <= 1e-5 * max(dg[1], 1e-9), (step, k)
 
 
 def test_oracle_esrgan_matches_reference_golden():
@@ -89,6 +92,7 @@ def test_oracle_esrgan_matches_reference_golden():
     sd = closed_form_state(Discriminator(image_size=64).state_dict())
     assert rel(OE.discriminator_forward(sd, torch.from_numpy(gold['d_x']), True), gold['d_logits']) < 1e-5
     assert len(Generator().state_dict()) == 702 and len(Discriminator().state_dict()) == 60
+    assert 0.3 < gold['gan_losses'][2][0] < 1.0 and gold['gan_losses'][0][1] < 5.0  # un-saturated D, O(1) image
 
 
 # ------------------------------------------------------------------ C ABI
@@ -176,6 +180,94 @@ def test_flat_params_views_and_zero_grad():
     assert torch.allclose(m[1].bias, before['1.bias'] + 1.0)
     m.load_state_dict(before)
     assert torch.equal(f.data[:15], before['0.weight'].flatten())
+
+
+def test_vgg19_cfg_is_torchvision_cfg_e():
+    """A literal copy of torchvision.models.vgg cfgs['E'] (public definition), written out here so that a typo
+    shared by oracle.srgan.VGG19_CFG, the golden-fixture stub and the product cannot pass unnoticed."""
+    from torchsr_amd.srgan.loss import VGG19_CFG
+    cfg_e = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
+    assert VGG19_CFG == cfg_e and O.VGG19_CFG == cfg_e
+    assert sum(1 for v in cfg_e if v != 'M') == 16 and len(cfg_e) + 16 == 37  # features[:36] drops the 5th max-pool
+
+
+def test_steplr_values_match_torch():
+    """optim.StepLR against torch.optim.lr_scheduler.StepLR for the reference's settings
+    (step_size = epochs // 8, gamma 0.6, stepped once per epoch: torchsr/srgan/trainer.py:186-195,528-529)."""
+    from torchsr_amd.optim import StepLR
+
+    class Opt:  # the slice of FlatAdam that StepLR touches; no device needed
+        def __init__(self, lr):
+            self._lr = lr
+
+        lr = property(lambda self: self._lr)
+
+        def set_lr(self, lr):
+            self._lr = float(lr)
+
+    for epochs in (8, 20, 64, 1000):
+        mine_opt = Opt(1e-4)
+        mine = StepLR(mine_opt, step_size=epochs // 8, gamma=0.6)
+        p = torch.nn.Parameter(torch.zeros(1))
+        ref_opt = torch.optim.Adam([p], lr=1e-4)
+        ref = torch.optim.lr_scheduler.StepLR(ref_opt, step_size=epochs // 8, gamma=0.6)
+        for epoch in range(min(epochs, 40)):
+            ref_opt.step()
+            ref.step()
+            mine.step()
+            assert mine.get_last_lr()[0] == pytest.approx(ref.get_last_lr()[0], rel=1e-12), (epochs, epoch)
+        sd = mine.state_dict()
+        again = StepLR(Opt(1e-4), step_size=epochs // 8, gamma=0.6)
+        again.load_state_dict(sd)
+        assert again.get_last_lr() == mine.get_last_lr()
+    assert StepLR(Opt(1e-4), step_size=0, gamma=0.6).step_size == 1  # --epochs < 8: the reference divides by zero
+
+
+def test_cli_refuses_to_train_against_random_vgg_features(monkeypatch, tmp_path):
+    """`torchsr train` without the pretrained VGG19 file must not silently optimise a meaningless perceptual
+    loss (the reference always loads vgg19(pretrained=True), torchsr/srgan/loss.py:30)."""
+    from torchsr_amd.torchsr import main
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv('TORCHSR_VGG19_WEIGHTS', raising=False)
+    monkeypatch.setenv('TORCH_HOME', str(tmp_path))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'SLURM_NTASKS'):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit, match='vgg19-dcbb9e9d.pth not found'):
+        main(['train', '--model', 'srgan', '--train-dir', 'synthetic:8', '--batch-size', '2'])
+
+
+def test_backward_cuts_pause_and_resume():
+    """ddp.BackwardCuts: a cut splits backward() into two calls whose combined effect is the plain backward."""
+    from torchsr_amd import functional as F
+    from torchsr_amd.ddp import BackwardCuts
+    torch.manual_seed(3)
+    a, b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 2)
+    x = torch.rand(5, 4)
+
+    def loss_of():  # the body runs twice per step, as the discriminator does (real and fake batch)
+        h1, h2 = F.cut_point('mid', torch.tanh(a(x))), F.cut_point('mid', torch.tanh(a(2 * x)))
+        return (b(h1) - b(h2)).square().mean()
+
+    loss_of().backward()
+    want = [p.grad.clone() for p in list(a.parameters()) + list(b.parameters())]
+    for p in list(a.parameters()) + list(b.parameters()):
+        p.grad = None
+    cuts = BackwardCuts(('mid',))
+    F.cut_hook[0] = cuts
+    try:
+        loss_of().backward()
+        assert a.weight.grad is None and b.weight.grad is not None and len(cuts.pairs['mid']) == 2
+        cuts.resume('mid')
+        with torch.no_grad():  # nothing to cut where nothing is differentiated
+            assert F.cut_point('mid', a(x)).requires_grad is False and not cuts.pending('mid')
+        cuts.names = set()     # un-armed names pass through
+        t = a(x)
+        assert F.cut_point('mid', t) is t
+    finally:
+        F.cut_hook[0] = None
+    got = [p.grad for p in list(a.parameters()) + list(b.parameters())]
+    for g, w in zip(got, want):
+        assert torch.allclose(g, w, rtol=1e-6, atol=1e-8)
 
 
 def test_steplr_and_registry():

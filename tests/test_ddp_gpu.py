@@ -1,0 +1,133 @@
+"""Data-parallel trainer step (BASELINE config 3) rehearsed on ONE MI355X: two ranks, both on ``cuda:0``, gloo
+process group (RCCL refuses two ranks on one device; the trainer code is backend agnostic).
+
+Each rank takes its own shard; after the first step every parameter must equal the data-parallel oracle
+(``oracle.srgan.SRGANDataParallelOracle``: shared weights, per-rank BatchNorm buffers, gradients averaged --
+what DistributedDataParallel does to the reference's loop bodies, torchsr/srgan/trainer.py:142-157,416-469),
+and the hipGraph-segmented run must track the eager run step for step.  Exercises the paused backward pass,
+the four gradient buckets, the 1/world factor folded into Adam and the cross-segment tensor lifetimes.
+"""
+import os
+import socket
+import warnings
+from argparse import Namespace
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+STEPS = 4  # graph trainer: 2 eager warm-ups, capture at step 2, one replay
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _shard(rank):
+    from oracle.weights import seeded_input
+    return seeded_input((2, 3, 24, 24), 170 + rank), seeded_input((2, 3, 96, 96), 180 + rank)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import srgan as O
+        from oracle.weights import closed_form_state
+        from torchsr_amd.srgan.trainer import SRGANTrainer
+        dev = torch.device('cuda', 0)
+        torch.cuda.set_device(dev)
+
+        def make(use_graphs):
+            args = Namespace(disable_amp=True, batch_size=2, epochs=8, gan_checkpoint=None, local_rank=0,
+                             pretrain_epochs=1, psnr_checkpoint=None, skip_image_save=True, world_size=world, rank=rank,
+                             use_graphs=use_graphs, vgg_weights='random')
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                t = SRGANTrainer(dev, args, [], [], 2, 2, distributed=True)
+            t.generator.load_state_dict(closed_form_state(t.generator.state_dict()))
+            t.discriminator.load_state_dict(closed_form_state(t.discriminator.state_dict()))
+            t.vgg_loss.features.load_state_dict(closed_form_state(t.vgg_loss.features.state_dict(), prefix='features.'))
+            t.generator.train()
+            t.discriminator.train()
+            return t
+
+        te, tg = make(False), make(True)
+        assert len(te.disc_sync) == 2 and len(te.gen_sync) == 2 and te.disc_sync.world_size == world
+        # the classifier bucket is the 75.5 MB + 4 KB + ... tail of the flat buffer
+        assert te.disc_sync.slices[1].numel() >= 1024 * 18432 and te.gen_sync.slices[1].numel() == 2 * (256 * 64 * 9 + 256 + 4) + 3 * 64 * 81 + 4
+        lr, hr = (t.to(dev) for t in _shard(rank))
+        report = {'loss_gap': 0.0}
+        for step in range(STEPS):
+            le, lg = te.gan_step(lr, hr), tg.gan_step(lr, hr)
+            for k in le:
+                a, b = le[k].item(), lg[k].item()
+                report['loss_gap'] = max(report['loss_gap'], abs(a - b) / max(abs(a), 1e-3))
+            if step == 0:
+                first = {'G': {k: v.detach().cpu().clone() for k, v in te.generator.state_dict().items()},
+                         'D': {k: v.detach().cpu().clone() for k, v in te.discriminator.state_dict().items()},
+                         'losses': [le[k].item() for k in ('gan/disc-loss', 'gan/content-loss', 'gan/adversarial-loss',
+                                                            'gan/train-loss')]}
+        report['graphs'] = sorted(tg._graphs)
+        pe = te.pretrain_step(lr, hr).item()   # the pre-training body's two buckets
+        pg = tg.pretrain_step(lr, hr).item()
+        report['pre_gap'] = abs(pe - pg) / max(abs(pe), 1e-3)
+        gap = 0.0
+        for (k, a), (_, b) in zip(te.generator.state_dict().items(), tg.generator.state_dict().items()):
+            if a.is_floating_point():
+                gap = max(gap, ((a - b).abs().max() / a.abs().max().clamp_min(1e-6)).item())
+        report['param_gap'] = gap
+
+        # ---- oracle for step 0: both shards in this process, gradients averaged, BatchNorm per rank
+        vgg_sd = {k: v.detach().cpu().clone() for k, v in te.vgg_loss.features.state_dict().items()}
+        orc = O.SRGANDataParallelOracle(closed_form_state(te.generator.state_dict()),
+                                        closed_form_state(te.discriminator.state_dict()), vgg_sd, world)
+        shards = [_shard(r) for r in range(world)]
+        want_losses = orc.gan_step([s[0] for s in shards], [s[1] for s in shards])[rank]
+        report['loss_err'] = max(abs(g - w) / max(abs(w), 1e-3) for g, w in zip(first['losses'], want_losses))
+        bad, worst = [], 0.0
+        for name, got, ref in (('G', first['G'], orc.g_ranks[rank]), ('D', first['D'], orc.d_ranks[rank])):
+            for k, v in got.items():
+                r = ref[k].detach()
+                if not v.is_floating_point():
+                    if int(v) != int(r):
+                        bad.append((name, k, 'counter'))
+                    continue
+                diff = (v - r).abs()
+                if 'running_' in k:
+                    if (diff.max() / r.abs().max().clamp_min(1e-6)).item() > 1e-3:
+                        bad.append((name, k, 'running'))
+                else:  # same criterion as test_first_adam_step_matches_oracle_elementwise
+                    n_bad = int((diff > 2e-6).sum())
+                    worst = max(worst, diff.max().item())
+                    if n_bad > max(1, int(2e-3 * diff.numel())) or diff.max().item() > 2.1e-4:
+                        bad.append((name, k, n_bad, diff.max().item()))
+        report['bad'], report['worst'] = bad, worst
+        out[rank] = report
+        torch.cuda.synchronize()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_trainer_step_matches_data_parallel_oracle(dev):
+    world, port = 2, _free_port()
+    mgr = mp.get_context('spawn').Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    for rank in range(world):
+        rep = out[rank]
+        assert rep['bad'] == [], (rank, rep['bad'][:5])
+        assert rep['loss_err'] < 1e-3, (rank, rep)
+        assert rep['loss_gap'] < 1e-4 and rep['pre_gap'] < 1e-4 and rep['param_gap'] < 1e-3, (rank, rep)
+        assert {'gan.disc.head', 'gan.disc.body', 'gan.content', 'gan.gen.head', 'gan.gen.body', 'gan.gopt'} <= \
+            set(rep['graphs']), rep['graphs']

@@ -1,7 +1,6 @@
 """ESRGAN generator / discriminator / GAN step on the HIP path vs golden vectors captured from the
 imported reference (tests/golden/esrgan.npz, written by oracle/gen_golden.py)."""
 import os
-import warnings
 from argparse import Namespace
 
 import numpy as np
@@ -9,7 +8,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN
-from oracle.weights import closed_form_state, tensor_digest
+from oracle.weights import closed_form_state, seeded_input, step_state, tensor_digest
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -63,53 +62,77 @@ def test_esrgan_discriminator_vs_golden(dev):
         assert digest_rel(grads[str(k)].grad, dg) < TOL, k
 
 
-def test_esrgan_gan_steps_vs_reference_trainer(dev):
+LOSS_KEYS = ('gan/disc-loss', 'gan/pixel-loss', 'gan/content-loss', 'gan/adversarial-loss', 'gan/train-loss')
+
+
+def make_trainer(dev, batch=2, disable_amp=True, use_graphs=False):
     from torchsr_amd.esrgan.trainer import ESRGANTrainer
-    gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
-    args = Namespace(disable_amp=True, batch_size=2, epochs=8, gan_checkpoint=None, local_rank=0, pretrain_epochs=1,
-                     psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1, use_graphs=False)
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        t = ESRGANTrainer(dev, args, [], [], 2, 2, distributed=False)
-    t.generator.load_state_dict(closed_form_state(t.generator.state_dict()))
-    t.discriminator.load_state_dict(closed_form_state(t.discriminator.state_dict()))
+    args = Namespace(disable_amp=disable_amp, batch_size=batch, epochs=8, gan_checkpoint=None, local_rank=0,
+                     pretrain_epochs=1, psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1,
+                     use_graphs=use_graphs, vgg_weights='random')
+    t = ESRGANTrainer(dev, args, [], [], batch, batch, distributed=False)
+    t.generator.load_state_dict(step_state(t.generator.state_dict(), 'esrgan.G'))
+    t.discriminator.load_state_dict(step_state(t.discriminator.state_dict(), 'esrgan.D'))
     t.vgg_loss.features.load_state_dict(closed_form_state(t.vgg_loss.features.state_dict(), prefix='features.'))
     t.generator.train()
     t.discriminator.train()
+    return t
+
+
+def assert_digests(keys, sd, digests, what):
+    for k, dg in zip(keys, digests):
+        d = tensor_digest(sd[str(k)].cpu())
+        assert abs(d[0] - dg[0]) <= 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6, (what, k)
+        assert abs(d[1] - dg[1]) <= 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6, (what, k)
+
+
+def test_esrgan_gan_steps_vs_reference_trainer(dev):
+    """Three steps of the UNMODIFIED ESRGANTrainer._gan_loop (23 RRDBs, 128x128 crops, batch 2): the five losses
+    at 1e-3 and the post-step parameter digests of G (702 entries) and D (60 entries) after every step."""
+    gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
+    t = make_trainer(dev)
     lr, hr = torch.from_numpy(gold['low_res']).to(dev), torch.from_numpy(gold['high_res']).to(dev)
-    for step in range(2):
+    for step in range(3):
         losses = t.gan_step(lr, hr)
-        got = [losses[k].item() for k in ('gan/disc-loss', 'gan/pixel-loss', 'gan/content-loss',
-                                           'gan/adversarial-loss', 'gan/train-loss')]
+        got = [losses[k].item() for k in LOSS_KEYS]
         want = gold['gan_losses'][step]
-        tol = 1e-3 if step == 0 else 2e-2
         for g, w in zip(got, want):
-            assert abs(g - w) <= tol * max(abs(w), 1e-3), (step, got, list(want))
-        assert abs(got[4] - gold['gan_ref_gen_losses'][step]) <= tol * gold['gan_ref_gen_losses'][step]
+            assert abs(g - w) <= TOL * max(abs(w), 1e-3), (step, got, list(want))
+        assert abs(got[4] - gold['gan_ref_gen_losses'][step]) <= TOL * gold['gan_ref_gen_losses'][step]
+        assert_digests(gold['gs_keys'], t.generator.state_dict(), gold['gan_g_digest'][step], f'G step {step}')
+        assert_digests(gold['ds_keys'], t.discriminator.state_dict(), gold['gan_d_digest'][step], f'D step {step}')
+
+
+def test_esrgan_config4_geometry_step_vs_reference_trainer(dev):
+    """BASELINE config 4's geometry -- full 23-RRDB generator, 128x128 crops -- at batch 4 in fp32 against the
+    reference trainer's losses and post-step parameter digests (seeded inputs; the fixture holds results only)."""
+    gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
+    s_lr, s_hr = (int(v) for v in gold['b4_seeds'])
+    lr, hr = seeded_input((4, 3, 32, 32), s_lr).to(dev), seeded_input((4, 3, 128, 128), s_hr).to(dev)
+    t = make_trainer(dev, batch=4)
+    losses = t.gan_step(lr, hr)
+    got = [losses[k].item() for k in LOSS_KEYS]
+    for g, w in zip(got, gold['b4_gan_losses']):
+        assert abs(g - w) <= TOL * max(abs(w), 1e-3), (got, list(gold['b4_gan_losses']))
+    assert abs(got[4] - float(gold['b4_gan_ref_gen_loss'])) <= TOL * float(gold['b4_gan_ref_gen_loss'])
+    assert_digests(gold['gs_keys'], t.generator.state_dict(), gold['b4_gan_g_digest'], 'G b4')
+    assert_digests(gold['ds_keys'], t.discriminator.state_dict(), gold['b4_gan_d_digest'], 'D b4')
 
 
 def test_esrgan_gan_step_with_bf16_products(dev):
-    """Without --disable-amp the trainers multiply bf16-rounded conv operands (fp32 accumulation, fp32
-    everything else).  The first GAN step must then land within bf16 rounding of the fp32 golden losses:
-    2e-2 relative (bf16 carries 8 bits of mantissa: 4e-3 per operand, deep networks compound it)."""
-    from torchsr_amd.esrgan.trainer import ESRGANTrainer
+    """Without --disable-amp both ESRGAN phases sit in the reference's autocast regions (esrgan/trainer.py:384,446,
+    461): every generic conv of G, D and VGG19 multiplies bf16-rounded operands (fp32 accumulation, fp32 everything
+    else).  The first GAN step must land within bf16 rounding of the fp32 golden losses: 2e-2 relative (bf16 carries
+    8 bits of mantissa: 4e-3 per operand, deep networks compound it)."""
     from torchsr_amd.layers import Conv2d
     gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
-    args = Namespace(disable_amp=False, batch_size=2, epochs=8, gan_checkpoint=None, local_rank=0, pretrain_epochs=1,
-                     psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1, use_graphs=False)
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        t = ESRGANTrainer(dev, args, [], [], 2, 2, distributed=False)
-    assert all(m._st.precision == 1 for m in t.generator.modules() if isinstance(m, Conv2d))
-    t.generator.load_state_dict(closed_form_state(t.generator.state_dict()))
-    t.discriminator.load_state_dict(closed_form_state(t.discriminator.state_dict()))
-    t.vgg_loss.features.load_state_dict(closed_form_state(t.vgg_loss.features.state_dict(), prefix='features.'))
-    t.generator.train()
-    t.discriminator.train()
+    t = make_trainer(dev, disable_amp=False)
+    assert t.amp_phases == ('psnr', 'gan')
     lr, hr = torch.from_numpy(gold['low_res']).to(dev), torch.from_numpy(gold['high_res']).to(dev)
     losses = t.gan_step(lr, hr)
-    got = [losses[k].item() for k in ('gan/disc-loss', 'gan/pixel-loss', 'gan/content-loss', 'gan/adversarial-loss',
-                                       'gan/train-loss')]
+    assert all(m._st.precision == 1 for net in (t.generator, t.discriminator, t.vgg_loss) for m in net.modules()
+               if isinstance(m, Conv2d))
+    got = [losses[k].item() for k in LOSS_KEYS]
     want = gold['gan_losses'][0]
     for g, w in zip(got, want):
         assert np.isfinite(g) and abs(g - w) <= 2e-2 * max(abs(w), 1e-3), (got, list(want))

@@ -4,6 +4,7 @@ Tolerance: north_star asks for 1e-3 relative fp32; the kernels are exact-fp32 MF
 so these tests hold them to 2e-4 of the tensor's scale (1e-5 for pure data movement).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -410,6 +411,26 @@ def test_device_augmentation_kernels(dev):
         q = (want.clamp(0, 1) * 255).round() / 255
         assert float((out.cpu() - q).abs().max()) <= 1.0 / 255 + 1e-6       # ties may round either way
         assert float(((out.cpu() - q).abs() > 1e-6).float().mean()) < 1e-3
+
+
+def test_bicubic_down_vs_pil_fixture(dev):
+    """``srx_bicubic_down`` (quantised) against what the reference's pipeline feeds the generator: PIL's
+    ``Resize(crop/4, BICUBIC)`` of the 8-bit crop (torchsr/dataset.py:88-92,121-125; fixture written by
+    oracle/gen_golden.py with the PIL of the build container).  PIL rounds its horizontal pass to 8 bits before the
+    vertical one, the kernel keeps the intermediate in fp32, so the two may differ by ONE 8-bit step and must do
+    so rarely."""
+    from conftest import GOLDEN
+    from torchsr_amd import _lib
+    gold = np.load(os.path.join(GOLDEN, 'pil_bicubic.npz'))
+    crops, lows = gold['crops'], gold['lows'].astype(np.int32)          # [4,96,96,3] u8, [4,24,24,3] u8
+    hr = (torch.from_numpy(crops).permute(0, 3, 1, 2).float() / 255.0).contiguous().to(dev)  # ToTensor
+    out = torch.empty((4, 3, 24, 24), device=dev)
+    _lib.call('srx_bicubic_down', hr.data_ptr(), out.data_ptr(), 4, 3, 96, 96, 4, 1, torch.cuda.current_stream().cuda_stream)
+    got = (out.cpu() * 255.0).round().to(torch.int32).permute(0, 2, 3, 1).numpy()
+    diff = np.abs(got - lows)
+    assert diff.max() <= 1, diff.max()
+    # torch's CPU antialiased bicubic (fp32 intermediate, like the kernel) differs from PIL on 10.9 % of these pixels
+    assert (diff != 0).mean() < 0.15, (diff != 0).mean()
 
 
 FULL_SIZE_LAYERS = [

@@ -1,12 +1,12 @@
 """The two train-step bodies (SRGANTrainer._pretrain body, ._gan_loop) on the HIP path vs the
-golden losses captured from the UNMODIFIED reference trainer and vs the CPU oracle.
+golden losses / post-step parameter digests captured from the UNMODIFIED reference trainer and vs the CPU oracle,
+at the fixture size (batch 2) and at BASELINE config 2's size (batch 16, 96x96 crops).
 
-Step 0 is held to 1e-3 relative (north_star).  Later steps run through a saturating discriminator
-(BCE on p~1e-4) that amplifies last-bit differences -- the reference's own torch-2.10 Adam and the
-oracle's torch-1.11-style Adam already differ by 2.5e-4 at step 2 -- so they are held to 2e-2.
+Every step is held to 1e-3 relative (north_star).  The fixtures start from ``oracle.weights.step_state``, whose
+discriminator does not saturate after one Adam step (disc-loss 1.38 -> 1.21 -> 1.05), so later steps compare
+arithmetic rather than two fp32 evaluations of log(1e-6).
 """
 import os
-import warnings
 from argparse import Namespace
 
 import numpy as np
@@ -15,28 +15,61 @@ import torch
 
 from conftest import GOLDEN
 from oracle import srgan as O
-from oracle.weights import closed_form_state, tensor_digest
+from oracle.weights import closed_form_state, seeded_input, step_state, tensor_digest
 
 pytestmark = pytest.mark.gpu
+LOSS_KEYS = ('gan/disc-loss', 'gan/content-loss', 'gan/adversarial-loss', 'gan/train-loss')
 
 
-def make_trainer(dev, use_graphs, batch=2):
+def make_trainer(dev, use_graphs, batch=2, disable_amp=True):
     from torchsr_amd.srgan.trainer import SRGANTrainer
-    args = Namespace(disable_amp=True, batch_size=batch, epochs=8, gan_checkpoint=None, local_rank=0,
+    args = Namespace(disable_amp=disable_amp, batch_size=batch, epochs=8, gan_checkpoint=None, local_rank=0,
                      pretrain_epochs=1, psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1,
-                     use_graphs=use_graphs)
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        t = SRGANTrainer(dev, args, [], [], batch, batch, distributed=False)
-    t.generator.load_state_dict(closed_form_state(t.generator.state_dict()))
-    t.discriminator.load_state_dict(closed_form_state(t.discriminator.state_dict()))
+                     use_graphs=use_graphs, vgg_weights='random')
+    t = SRGANTrainer(dev, args, [], [], batch, batch, distributed=False)
+    t.generator.load_state_dict(step_state(t.generator.state_dict(), 'srgan.G'))
+    t.discriminator.load_state_dict(step_state(t.discriminator.state_dict(), 'srgan.D'))
     t.vgg_loss.features.load_state_dict(closed_form_state(t.vgg_loss.features.state_dict(), prefix='features.'))
     t.generator.train()
     t.discriminator.train()
     return t
 
 
-def test_gan_steps_vs_golden_and_oracle(dev):
+def oracle_for(t):
+    vgg_sd = {k: v.detach().cpu().clone() for k, v in t.vgg_loss.features.state_dict().items()}
+    return O.SRGANStepOracle(step_state(t.generator.state_dict(), 'srgan.G'), step_state(t.discriminator.state_dict(), 'srgan.D'),
+                             vgg_sd)
+
+
+def assert_digests(keys, sd, digests, what):
+    for k, dg in zip(keys, digests):
+        d = tensor_digest(sd[k].cpu())
+        # every weight moves by ~lr = 1e-4 per Adam step; digests are sums over the tensor, so compare against
+        # the abs-sum scale
+        assert abs(d[0] - dg[0]) <= 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6, (what, k)
+        assert abs(d[1] - dg[1]) <= 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6, (what, k)
+
+
+def assert_elementwise(mod, ref, name):
+    """Every parameter within 2e-6 absolute of the oracle after ONE Adam step (updates are ~1e-4, so this pins the
+    update direction of every element that has a gradient above the noise floor)."""
+    for k, v in mod.state_dict().items():
+        if not v.is_floating_point():
+            assert int(v) == int(ref[k]), (name, k)
+            continue
+        diff = (v.cpu() - ref[k].detach()).abs()
+        if 'running_' in k:
+            assert (diff.max() / ref[k].detach().abs().max().clamp_min(1e-6)).item() < 1e-3, (name, k)
+        else:
+            # Adam's first step is lr*g/(|g|+eps): an element whose gradient sits near eps=1e-8 (or at the fp32
+            # noise floor) moves by a different fraction of lr in any two fp32 implementations; allow 0.2 % of a
+            # tensor (at least one element) to do so
+            n_bad = int((diff > 2e-6).sum())
+            assert n_bad <= max(1, int(2e-3 * diff.numel())), (name, k, n_bad, diff.max().item())
+            assert diff.max().item() <= 2.1e-4, (name, k, diff.max().item())
+
+
+def test_gan_steps_vs_golden(dev):
     gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
     lr, hr = torch.from_numpy(gold['low_res']), torch.from_numpy(gold['high_res'])
     t = make_trainer(dev, use_graphs=False)
@@ -44,61 +77,77 @@ def test_gan_steps_vs_golden_and_oracle(dev):
     d_keys = [str(k) for k in gold['d_keys']]
     for step in range(3):
         losses = t.gan_step(lr.to(dev), hr.to(dev))
-        got = [losses[k].item() for k in ('gan/disc-loss', 'gan/content-loss', 'gan/adversarial-loss',
-                                           'gan/train-loss')]
+        got = [losses[k].item() for k in LOSS_KEYS]
         want = gold['gan_losses'][step]
-        tol = 1e-3 if step == 0 else 2e-2
         for g, w in zip(got, want):
-            assert abs(g - w) <= tol * max(abs(w), 1e-3), (step, got, want)
-        assert abs(got[3] - gold['gan_ref_gen_losses'][step]) <= tol * gold['gan_ref_gen_losses'][step]
-        if step == 0:  # post-step parameters and BN running statistics of the reference trainer
-            gsd, dsd = t.generator.state_dict(), t.discriminator.state_dict()
-            for keys, sd, dig in ((g_keys, gsd, gold['gan_g_digest'][0]), (d_keys, dsd, gold['gan_d_digest'][0])):
-                for k, dg in zip(keys, dig):
-                    d = tensor_digest(sd[k].cpu())
-                    # every weight moves by ~lr=1e-4 in the first Adam step; digests are sums over the
-                    # tensor, so compare against the abs-sum scale
-                    assert abs(d[0] - dg[0]) <= 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6, k
-                    assert abs(d[1] - dg[1]) <= 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6, k
+            assert abs(g - w) <= 1e-3 * max(abs(w), 1e-3), (step, got, want)
+        assert abs(got[3] - gold['gan_ref_gen_losses'][step]) <= 1e-3 * gold['gan_ref_gen_losses'][step]
+        # post-step parameters and BN running statistics of the reference trainer, after every step
+        assert_digests(g_keys, t.generator.state_dict(), gold['gan_g_digest'][step], f'G step {step}')
+        assert_digests(d_keys, t.discriminator.state_dict(), gold['gan_d_digest'][step], f'D step {step}')
+    t.generator.eval()
+    with torch.no_grad():
+        sr = t.generator(lr.to(dev))
+    assert abs(O.psnr(sr.cpu(), hr) - float(gold['gan_psnr_after3'])) < 0.01  # PSNR parity (0.01 dB) after 3 steps
+
+
+def test_baseline_size_gan_step_vs_reference_and_oracle(dev):
+    """BASELINE config 2: ONE batch-16 96x96 SRGAN GAN step.  Losses and post-step parameter digests against the
+    unmodified reference trainer (fixture), every parameter of G and D elementwise against the oracle run here
+    (~1 s of CPU).  This is the size bench.py times: tile plans, K-splits, BatchNorm statistics and the 144-row
+    tiles are the ones the benchmark uses."""
+    gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
+    s_lr, s_hr = (int(v) for v in gold['b16_seeds'])
+    lr, hr = seeded_input((16, 3, 24, 24), s_lr), seeded_input((16, 3, 96, 96), s_hr)
+    t = make_trainer(dev, use_graphs=False, batch=16)
+    orc = oracle_for(t)
+    want = orc.gan_step(lr, hr)
+    losses = t.gan_step(lr.to(dev), hr.to(dev))
+    got = [losses[k].item() for k in LOSS_KEYS]
+    for g, w, r in zip(got, want, gold['b16_gan_losses']):
+        assert abs(g - w) <= 1e-3 * max(abs(w), 1e-3) and abs(g - r) <= 1e-3 * max(abs(r), 1e-3), (got, want)
+    assert abs(got[3] - float(gold['b16_gan_ref_gen_loss'])) <= 1e-3 * float(gold['b16_gan_ref_gen_loss'])
+    assert_digests([str(k) for k in gold['g_keys']], t.generator.state_dict(), gold['b16_gan_g_digest'], 'G b16')
+    assert_digests([str(k) for k in gold['d_keys']], t.discriminator.state_dict(), gold['b16_gan_d_digest'], 'D b16')
+    assert_elementwise(t.generator, orc.g, 'G')
+    assert_elementwise(t.discriminator, orc.d, 'D')
+
+
+def test_baseline_size_pretrain_step_vs_reference_and_oracle(dev):
+    gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
+    s_lr, s_hr = (int(v) for v in gold['b16_seeds'])
+    lr, hr = seeded_input((16, 3, 24, 24), s_lr), seeded_input((16, 3, 96, 96), s_hr)
+    t = make_trainer(dev, use_graphs=False, batch=16)
+    orc = oracle_for(t)
+    want = orc.pretrain_step(lr, hr)
+    got = t.pretrain_step(lr.to(dev), hr.to(dev)).item()
+    assert abs(got - want) <= 1e-3 * want and abs(got - float(gold['b16_pre_loss'])) <= 1e-3 * float(gold['b16_pre_loss'])
+    assert_digests([str(k) for k in gold['g_keys']], t.generator.state_dict(), gold['b16_pre_g_digest'], 'G pretrain b16')
+    assert_elementwise(t.generator, orc.g, 'G')
 
 
 def test_first_adam_step_matches_oracle_elementwise(dev):
-    """One GAN step from closed-form weights: every parameter within 2e-6 absolute of the oracle
-    (updates are ~1e-4, so this pins the update direction of every element that has a gradient
-    above the noise floor)."""
+    """One GAN step from the fixture weights: every parameter within 2e-6 absolute of the oracle."""
     gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
     lr, hr = torch.from_numpy(gold['low_res']), torch.from_numpy(gold['high_res'])
     t = make_trainer(dev, use_graphs=False)
-    vgg_sd = {k: v.detach().cpu().clone() for k, v in t.vgg_loss.features.state_dict().items()}
-    orc = O.SRGANStepOracle(closed_form_state(t.generator.state_dict()),
-                            closed_form_state(t.discriminator.state_dict()), vgg_sd)
+    orc = oracle_for(t)
     orc.gan_step(lr, hr)
     t.gan_step(lr.to(dev), hr.to(dev))
-    for name, mod, ref in (('G', t.generator, orc.g), ('D', t.discriminator, orc.d)):
-        for k, v in mod.state_dict().items():
-            if not v.is_floating_point():
-                assert int(v) == int(ref[k]), (name, k)
-                continue
-            diff = (v.cpu() - ref[k].detach()).abs()
-            if 'running_' in k:
-                assert (diff.max() / ref[k].detach().abs().max().clamp_min(1e-6)).item() < 1e-3, (name, k)
-            else:
-                # Adam's first step is lr*g/(|g|+eps): an element whose gradient sits near eps=1e-8
-                # (or at the fp32 noise floor) moves by a different fraction of lr in any two fp32
-                # implementations; allow 0.2 % of a tensor (at least one element) to do so
-                n_bad = int((diff > 2e-6).sum())
-                assert n_bad <= max(1, int(2e-3 * diff.numel())), (name, k, n_bad, diff.max().item())
-                assert diff.max().item() <= 2.1e-4, (name, k, diff.max().item())
+    assert_elementwise(t.generator, orc.g, 'G')
+    assert_elementwise(t.discriminator, orc.d, 'D')
 
 
 def test_pretrain_steps_vs_golden(dev):
     gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
     lr, hr = torch.from_numpy(gold['low_res']), torch.from_numpy(gold['high_res'])
     t = make_trainer(dev, use_graphs=False)
+    g_keys = [str(k) for k in gold['g_keys']]
     for step in range(3):
         loss = t.pretrain_step(lr.to(dev), hr.to(dev)).item()
         want = gold['pre_losses'][step]
-        assert abs(loss - want) <= (1e-3 if step == 0 else 2e-2) * want, (step, loss, want)
+        assert abs(loss - want) <= 1e-3 * want, (step, loss, want)
+        assert_digests(g_keys, t.generator.state_dict(), gold['pre_g_digest'][step], f'G pretrain step {step}')
 
 
 def test_graph_replay_equals_eager(dev):
@@ -138,19 +187,29 @@ def test_pack_tables_take_over_after_the_first_step(dev):
 
 
 def test_segmented_step_equals_fused(dev):
-    """The 4-segment step used under data parallelism (all-reduce between segments) computes the same
-    thing as the single-graph step (world size 1: the all-reduces are no-ops)."""
+    """The segmented step used under data parallelism (backward paused at the bucket boundaries, all-reduces
+    between the hipGraph segments) computes the same thing as the single-graph step (world size 1: the
+    all-reduces are no-ops).  The two-rank version is tests/test_ddp_gpu.py."""
     gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
     lr, hr = torch.from_numpy(gold['low_res']).to(dev), torch.from_numpy(gold['high_res']).to(dev)
-    from torchsr_amd.ddp import GradAllReduce
+    from torchsr_amd.ddp import BackwardCuts, GradBuckets
     ta, tb = make_trainer(dev, False), make_trainer(dev, True)
     tb.distributed = True
-    tb.gen_sync, tb.disc_sync = GradAllReduce(tb.gen_flat), GradAllReduce(tb.disc_flat)
+    tb._cuts = BackwardCuts()
+    tb.gen_sync = GradBuckets(tb.gen_flat, (tb.gen_tail_bucket,), tb.generator)
+    tb.disc_sync = GradBuckets(tb.disc_flat, (tb.disc_head_bucket,), tb.discriminator)
     for step in range(4):
         la, lb = ta.gan_step(lr, hr), tb.gan_step(lr, hr)
         for k in la:
             assert la[k].item() == pytest.approx(lb[k].item(), rel=1e-5, abs=1e-7), (step, k)
-    assert {'gan.disc', 'gan.content', 'gan.gen', 'gan.gopt'} <= set(tb._graphs)
+        assert not tb._cuts.pairs, tb._cuts.pairs.keys()  # every cut was resumed
+    assert {'gan.disc.head', 'gan.disc.body', 'gan.content', 'gan.gen.head', 'gan.gen.body', 'gan.gopt'} <= set(tb._graphs)
+    pa, pb = ta.pretrain_step(lr, hr).item(), tb.pretrain_step(lr, hr).item()
+    assert pa == pytest.approx(pb, rel=1e-5)
+    for (k, a), (_, b) in zip(ta.generator.state_dict().items(), tb.generator.state_dict().items()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6), k
+    from torchsr_amd import functional as F
+    assert F.cut_hook[0] is None
 
 
 def test_checkpoint_resume_continues_the_run(dev, tmp_path):
@@ -190,28 +249,47 @@ def test_checkpoint_resume_continues_the_run(dev, tmp_path):
         assert torch.equal(pa, pb), ka
 
 
-def test_gan_step_with_bf16_products(dev):
-    """Without --disable-amp (the reference's default: autocast) every generic conv multiplies bf16-rounded
-    operands with fp32 accumulation.  First GAN step against the fp32 golden losses of the reference trainer:
-    within bf16 rounding (8 mantissa bits, compounded through ~40 layers) -> 3e-2 relative."""
+def test_default_flags_gan_step_is_fp32_like_the_reference(dev):
+    """Without --disable-amp the reference still runs ``_gan_loop`` in fp32: its only autocast region is the
+    pre-training body (torchsr/srgan/trainer.py:382 vs :416-469).  A default-flag trainer must therefore meet the
+    fp32 golden losses of the reference's GAN step at the north-star tolerance, while its pre-training step
+    runs on bf16 products (different from the fp32 golden in the third digit, equal within bf16 rounding)."""
     gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
     lr, hr = torch.from_numpy(gold['low_res']).to(dev), torch.from_numpy(gold['high_res']).to(dev)
-    from torchsr_amd.srgan.trainer import SRGANTrainer
     from torchsr_amd.layers import Conv2d
-    args = Namespace(disable_amp=False, batch_size=2, epochs=8, gan_checkpoint=None, local_rank=0, pretrain_epochs=1,
-                     psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1, use_graphs=False)
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        t = SRGANTrainer(dev, args, [], [], 2, 2, distributed=False)
-    assert all(m._st.precision == 1 for net in (t.generator, t.discriminator, t.vgg_loss) for m in net.modules()
-               if isinstance(m, Conv2d))
-    t.generator.load_state_dict(closed_form_state(t.generator.state_dict()))
-    t.discriminator.load_state_dict(closed_form_state(t.discriminator.state_dict()))
-    t.vgg_loss.features.load_state_dict(closed_form_state(t.vgg_loss.features.state_dict(), prefix='features.'))
-    t.generator.train()
-    t.discriminator.train()
+    t = make_trainer(dev, False, disable_amp=False)
+    assert t.amp and t.amp_phases == ('psnr',)
     losses = t.gan_step(lr, hr)
-    got = [losses[k].item() for k in ('gan/disc-loss', 'gan/content-loss', 'gan/adversarial-loss', 'gan/train-loss')]
-    want = gold['gan_losses'][0]
-    for g, w in zip(got, want):
-        assert np.isfinite(g) and abs(g - w) <= 3e-2 * max(abs(w), 1e-3), (got, list(want))
+    nets = (t.generator, t.discriminator, t.vgg_loss)
+    assert all(m._st.precision == 0 for net in nets for m in net.modules() if isinstance(m, Conv2d))
+    got = [losses[k].item() for k in LOSS_KEYS]
+    for g, w in zip(got, gold['gan_losses'][0]):
+        assert abs(g - w) <= 1e-3 * max(abs(w), 1e-3), (got, list(gold['gan_losses'][0]))
+
+    t = make_trainer(dev, False, disable_amp=False)
+    loss = t.pretrain_step(lr, hr).item()
+    assert all(m._st.precision == 1 for m in t.generator.modules() if isinstance(m, Conv2d))
+    want = gold['pre_losses'][0]
+    assert abs(loss - want) <= 3e-2 * want and abs(loss - want) > 1e-7 * want, (loss, want)
+    # ... and the validation pass that follows an epoch is fp32 again (no autocast at trainer.py:286-304)
+    t._enter_phase('test')
+    assert all(m._st.precision == 0 for m in t.generator.modules() if isinstance(m, Conv2d))
+
+
+def test_precision_switch_on_a_warmed_model(dev):
+    """Switching a model's conv precision after it has run (packed weights exist, pack tables built) must not
+    leave any layer reading a stale layout: fp32 -> bf16 -> fp32 reproduces the first fp32 result exactly."""
+    from torchsr_amd.layers import set_conv_precision
+    from torchsr_amd.srgan.generator import Generator
+    gen = Generator().to(dev).train()
+    gen.load_state_dict(closed_form_state(gen.state_dict()))
+    x = torch.from_numpy(np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))['low_res']).to(dev)
+    with torch.no_grad():
+        y0 = gen(x).clone()
+        set_conv_precision(gen, 'bf16')
+        y1 = gen(x).clone()
+        set_conv_precision(gen, 'fp32')
+        y2 = gen(x).clone()
+    assert torch.equal(y0, y2)
+    rel = ((y1 - y0).abs().max() / y0.abs().max()).item()
+    assert 1e-6 < rel < 5e-2, rel  # a different precision, not a different function

@@ -338,8 +338,10 @@ int srx_thin_wgrad(const srx_conv2d_t* d, const float* x, const float* dy, float
   return SRX_OK;
 }
 
+// (the 3-channel layers are fp32 at either precision: their packed layout must not depend on srx_conv2d_t::precision,
+// which a trainer switches between its pre-training and GAN phases)
 static bool thin_geom_ok(const srx_conv2d_t* d) {
-  return d->precision == 0 && d->stride == 1 && !d->shuffle && d->KH == d->KW && (d->KH == 3 || d->KH == 9) && d->pad == (d->KH - 1) / 2 &&
+  return d->stride == 1 && !d->shuffle && d->KH == d->KW && (d->KH == 3 || d->KH == 9) && d->pad == (d->KH - 1) / 2 &&
          d->up <= 1;
 }
 bool srx_thin_fwd_applicable(const srx_conv2d_t* d) {

@@ -82,7 +82,8 @@ class DeviceLoader:
     image the reference converts back).  PIL's resampler also rounds its horizontal pass to 8 bits, so
     low-resolution pixels agree with the reference's to the last 8-bit step, not bit for bit.
     Same contract as the DataLoader it replaces: ``len()``, iteration yields ``(low_res, high_res)`` or
-    ``(low_res, bicubic, high_res)`` float NCHW in [0, 1], last partial batch dropped.
+    ``(low_res, bicubic, high_res)`` float NCHW in [0, 1]; the last partial batch is dropped when training
+    (fixed hipGraph shapes) and kept when testing.
     """
 
     def __init__(self, images, device, batch_size: int, crop_size: int, upscale_factor: int, test: bool, seed: int,
@@ -107,7 +108,10 @@ class DeviceLoader:
         return f[0].permute(1, 2, 0).clamp(0, 255).round().to(torch.uint8).contiguous()
 
     def __len__(self) -> int:
-        return len(self.order) // self.world // self.batch
+        n = len(self.order[self.rank::self.world])
+        # the reference's train loader drops nothing either (dataset.py:280-293), but a replayed hipGraph needs
+        # one batch shape, so the last partial TRAIN batch is dropped; the eager test pass keeps it (:345-360)
+        return -(-n // self.batch) if self.test else n // self.batch
 
     def __iter__(self):
         order = list(self.order)
@@ -168,8 +172,9 @@ def initialize_device_datasets(train_directory: str, device, batch_size: int = 6
         rank, world_size = 0, 1
     train = DeviceLoader(images[n_test:] or images, device, batch_size, crop_size, upscale_factor, False, seed,
                          dataset_multiplier, rank, world_size)
-    test = DeviceLoader(images[:n_test] * max(1, -(-batch_size // n_test)), device, batch_size, crop_size, upscale_factor,
-                        True, seed + 1)
+    # dataset.py:343-360: the test set is multiplied like the train set, sharded over the ranks, nothing dropped
+    test = DeviceLoader(images[:n_test], device, batch_size, crop_size, upscale_factor, True, seed + 1,
+                        dataset_multiplier, rank, world_size)
     return train, test, len(train.order), len(test.order)
 
 
@@ -179,7 +184,7 @@ def initialize_datasets(train_directory: str, batch_size: int = 64, crop_size: i
     """dataset.py:364-428."""
     if train_directory.startswith('synthetic:'):
         n = int(train_directory.split(':')[1])
-        n_test = max(batch_size, n // 10)
+        n_test = max(1, n // 10)
         train = _Synthetic(n, crop_size, upscale_factor, False, seed)
         test = _Synthetic(n_test, crop_size, upscale_factor, True, seed + 1)
         workers = 0
@@ -191,12 +196,14 @@ def initialize_datasets(train_directory: str, batch_size: int = 64, crop_size: i
         rng.shuffle(images)
         n_test = max(1, len(images) // 10)  # sklearn train_test_split(test_size=0.1), dataset.py:412
         train = _Pairs(images[n_test:] or images, crop_size, upscale_factor, dataset_multiplier, False)
-        test = _Pairs(images[:n_test], crop_size, upscale_factor, 1, True)
+        test = _Pairs(images[:n_test], crop_size, upscale_factor, dataset_multiplier, True)  # dataset.py:343-345
 
-    def loader(ds, shuffle):
+    def loader(ds, shuffle, drop_last):
         sampler = DistributedSampler(ds, seed=seed, shuffle=shuffle) if distributed else None
         return DataLoader(ds, batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
-                          num_workers=workers, drop_last=True, pin_memory=True,
+                          num_workers=workers, drop_last=drop_last, pin_memory=True,
                           persistent_workers=distributed and workers > 0)
 
-    return loader(train, True), loader(test, False), len(train), len(test)
+    # train: the replayed hipGraph needs one batch shape, so the last partial batch is dropped; test: eager, and the
+    # reference's test loader drops nothing (dataset.py:345-360) -- a shard smaller than --batch-size still gets tested
+    return loader(train, True, True), loader(test, False, False), len(train), len(test)

@@ -15,6 +15,10 @@ class Generator(nn.Module):
     conv + LeakyReLU (fused epilogue).
     """
 
+    # tiled inference (torchsr_amd/test.py): the true receptive field radius is ~350 low-resolution pixels, more than a
+    # tile can carry, so ESRGAN tiling is approximate near tile borders
+    halo = 64
+
     def __init__(self, num_rrdb_blocks: int = NUM_RESIDUAL) -> None:
         super().__init__()
         self.conv1 = Conv2d(3, 64, kernel_size=3, stride=1, padding=1)
@@ -31,6 +35,7 @@ class Generator(nn.Module):
         conv1 = self.conv1(x4)
         conv2 = self.conv2(self.blocks(conv1))
         out = F.axpby(conv1, conv2, 1.0, 1.0)                       # torch.add, generator.py:72
+        out = F.cut_point('g.tail', out)                            # data parallel: upsample* / conv3 / conv4 gradients go out first
         out = self.upsample1(F.upsample_nearest2x(out))             # :73-75
         out = self.upsample2(F.upsample_nearest2x(out))             # :76-78
         return self.conv4(self.conv3[0](out))                       # :79-80

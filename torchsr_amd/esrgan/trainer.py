@@ -1,17 +1,16 @@
 """ESRGAN trainer on MI355X -- interface of torchsr/esrgan/trainer.py:39-560.
 
 Same skeleton as the SRGAN trainer (shared host loop, checkpoints, PSNR test, hipGraph capture,
-flat Adam, RCCL gradient exchange); differences follow the reference:
+flat Adam, bucketed RCCL gradient exchange); differences follow the reference:
 
 * pre-training minimises L1 instead of MSE (esrgan/trainer.py:163,385);
 * relativistic-average GAN losses on logits, ``BCEWithLogits(real - mean(fake), 1)`` etc.
   (:451-453,468), ``disc_loss = (real + fake) / 2``;
 * the generator is run a second time for its own update (:462) and
-  ``gen_loss = 0.01 * L1 + 1 * VGG + 0.005 * adversarial`` (:469).
-
-The reference autocasts both phases to fp16 on CUDA; BASELINE config 4 asks for bf16 on MI355X.
-This round the ESRGAN path runs in exact fp32 on the same kernels as SRGAN (bf16 MFMA kernels and
-the in-place dense-block buffer are the planned next step).
+  ``gen_loss = 0.01 * L1 + 1 * VGG + 0.005 * adversarial`` (:469);
+* BOTH phases sit inside ``amp.autocast`` (:384,446,461), so without ``--disable-amp`` the generator,
+  the discriminator and VGG19 all multiply bf16-rounded operands with fp32 accumulation in both
+  phases (``amp_phases``; BASELINE config 4).  ``--disable-amp`` gives exact fp32.
 """
 import torch
 
@@ -26,6 +25,8 @@ class ESRGANTrainer(SRGANTrainer):
     phase_prefix = 'esrgan'
     generator_cls = Generator
     discriminator_cls = Discriminator
+    amp_phases = ('psnr', 'gan')          # esrgan/trainer.py:384 and :446,461
+    gen_tail_bucket = 'upsample1.weight'  # data parallel: upsample1/2, conv3, conv4 gradients complete first
 
     def _initialize_loss(self) -> None:
         """esrgan/trainer.py:159-165."""
@@ -38,14 +39,14 @@ class ESRGANTrainer(SRGANTrainer):
         """esrgan/trainer.py:444-455 (optimizer step is issued by ``_phase_gen`` after the all-reduce)."""
         low_res, high_res = self._static['low_res'], self._static['high_res']
         self.disc_optimizer.zero_grad()                                          # :444
-        super_res = self.generator(low_res)                                      # :447
+        with torch.no_grad():  # only ever used detached (:449); the generator has no BatchNorm state to update
+            super_res = self.generator(low_res)                                  # :447
         real_output = self.discriminator(high_res)                               # :448
-        fake_output = self.discriminator(super_res.detach())                     # :449
+        fake_output = self.discriminator(super_res)                              # :449 (detached)
         d_real = self.bce_loss(real_output, 1.0, shift=F.mean(fake_output))      # :451
         d_fake = self.bce_loss(fake_output, 0.0, shift=F.mean(real_output))      # :452
         disc_loss = F.axpby(d_real, d_fake, 0.5, 0.5)                            # :453
         disc_loss.backward()                                                     # :455
-        F.join_side_stream()
         self._losses['gan/disc-loss'] = disc_loss.detach()
 
     def _phase_content(self) -> None:
@@ -69,7 +70,6 @@ class ESRGANTrainer(SRGANTrainer):
         adversarial = self.bce_loss(fake_output, 1.0, shift=real_mean)           # :468
         gen_loss = F.axpby(self._content, adversarial, 1.0, 0.005)               # :469
         gen_loss.backward()                                                      # :480
-        F.join_side_stream()
         self._losses['gan/adversarial-loss'] = adversarial.detach()
         self._losses['gan/train-loss'] = gen_loss.detach()
         self._super_res = self._content = None

@@ -35,27 +35,15 @@ def _sink(param: Optional[Tensor]) -> Optional[Tensor]:
     return g
 
 
-# Weight-gradient kernels of the small layers fill only part of the chip and nothing downstream in
-# the backward pass needs their result, so (when enabled by a trainer) they are issued on a second
-# HIP stream: in the captured hipGraph they become a parallel branch next to the data-gradient chain.
-side_stream_enabled = [False]
-_side = {}
+# Pause points of the backward pass.  A data-parallel trainer installs a ``ddp.BackwardCuts`` here so that
+# ``loss.backward()`` stops where a gradient bucket is complete and the bucket's all-reduce can be launched
+# before the rest of the backward pass is issued; without a hook a cut point is the identity.
+cut_hook = [None]
 
 
-def side_stream(device) -> 'torch.cuda.Stream':
-    st = _side.get(device)
-    if st is None:
-        st = torch.cuda.Stream(device=device)
-        _side[device] = st
-    return st
-
-
-def join_side_stream() -> None:
-    """Make the current stream wait for everything issued on the side stream (call after backward)."""
-    if side_stream_enabled[0]:
-        dev = torch.cuda.current_device()
-        if dev in _side:
-            torch.cuda.current_stream().wait_stream(_side[dev])
+def cut_point(name: str, t: Tensor) -> Tensor:
+    hook = cut_hook[0]
+    return t if hook is None else hook(name, t)
 
 
 def _stream() -> int:
@@ -175,8 +163,8 @@ class ConvState:
         when raw-pointer code may have changed any parameter) and the model's own epoch (bumped by its
         optimiser, ``optim.FlatParams.pack_epoch``).  Frozen parameters (VGG19) never repack."""
         if not weight.requires_grad:
-            return (weight.data_ptr(), weight._version, -1, -1)
-        return (weight.data_ptr(), weight._version, _pack_epoch[0], self.model_epoch[0])
+            return (weight.data_ptr(), weight._version, -1, -1, self.precision)
+        return (weight.data_ptr(), weight._version, _pack_epoch[0], self.model_epoch[0], self.precision)
 
     def pack(self, weight: Tensor, d: Conv2dDesc, force: bool = False) -> None:
         """(Re)build the packed copies when the master OIHW weight changed.
@@ -315,19 +303,9 @@ class _Conv2d(Function):
                     bptr = _p(db if bsink is None else bsink)
                     bias_done = True
             nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
-            if sink is not None and side_stream_enabled[0]:
-                main, side = torch.cuda.current_stream(), side_stream(x.device.index)
-                side.wait_stream(main)          # dy (and x) are complete on the main stream
-                with torch.cuda.stream(side):
-                    ws = _ws(nws, x)
-                    call('srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(sink), 1, bptr, _p(ws), nws,
-                               side.cuda_stream)
-                x.record_stream(side)
-                dy.record_stream(side)
-            else:
-                ws = _ws(nws, x)
-                call('srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw if sink is None else sink),
-                           0 if sink is None else 1, bptr, _p(ws), nws, s)
+            ws = _ws(nws, x)
+            call('srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw if sink is None else sink),
+                 0 if sink is None else 1, bptr, _p(ws), nws, s)
         if ctx.has_bias and ctx.needs_input_grad[2] and not bias_done:
             sink = None if st.shuffle else _sink(bparam)
             if sink is not None:
@@ -785,7 +763,8 @@ class FoldedConv:
         return [t for t in ts if t is not None]
 
     def _refresh(self) -> None:
-        key = tuple((t.data_ptr(), t._version) for t in self._sources()) + (_pack_epoch[0], self.conv._st.model_epoch[0])
+        key = tuple((t.data_ptr(), t._version) for t in self._sources()) + (_pack_epoch[0], self.conv._st.model_epoch[0],
+                                                                            self.conv._st.precision)
         if key == self._key:
             return
         conv, bn = self.conv, self.bn

@@ -40,6 +40,7 @@ class FlatParams:
         self.data = torch.zeros(total, dtype=dt, device=dev)
         self.grad = torch.zeros(total, dtype=dt, device=dev)
         self.params: List[nn.Parameter] = params
+        self.offsets: List[int] = offs
         self.numel = total
         # bumped by every optimiser step on this buffer: the convs of THIS model repack, other models' do not
         self.pack_epoch = [0]
@@ -53,6 +54,11 @@ class FlatParams:
                 self.data[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.data[o:o + n].view(p.shape)
                 p.grad = self.grad[o:o + n].view(p.shape)
+
+    def offsets_by_name(self, module: nn.Module) -> dict:
+        """``{parameter name: offset (floats) in the flat buffers}`` for the module this buffer was built from."""
+        where = {id(p): o for p, o in zip(self.params, self.offsets)}
+        return {n: where[id(p)] for n, p in module.named_parameters() if id(p) in where}
 
     def zero_grad(self) -> None:
         """One memset; re-attaches the views in case something set ``.grad = None``."""

@@ -35,6 +35,7 @@ class Discriminator(nn.Module):
             y, part = conv(out, want_stats=True) if bn.training else (conv(out), None)
             out = bn(y, part, act=ACT_LRELU, slope=0.2)
             i += 3
+        out = F.cut_point('d.head', out)  # data parallel: classifier.* gradients are a bucket of their own
         out = F.flatten_nchw(out)  # torch.flatten(out, 1) in NCHW order, discriminator.py:86
         out = self.classifier[0](out, act=ACT_LRELU, slope=0.2)
         out = self.classifier[2](out)

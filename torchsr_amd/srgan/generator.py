@@ -17,6 +17,10 @@ class Generator(nn.Module):
     NHWC fp32 on hand-written gfx950 kernels.
     """
 
+    # low-resolution pixels a tile must see beyond its border for tiled inference to equal the untiled result
+    # (receptive field radius: 4 + 16 * 2 + 1 + 1 + 1/2 + 1 = 39.5)
+    halo = 48
+
     def __init__(self, scale_factor: int = 4) -> None:
         super().__init__()
         num_conv_layers = int(math.log(scale_factor, 2))
@@ -41,6 +45,7 @@ class Generator(nn.Module):
         bn = self.conv2[1]
         y, part = self.conv2[0](block, want_stats=True) if bn.training else (self.conv2[0](block), None)
         out = bn(y, part, residual=conv1)  # torch.add(conv1, conv2), generator.py:78
+        out = F.cut_point('g.tail', out)   # data parallel: conv_layers.* / conv3.* gradients go out first
         out = self.conv_layers(out)
         return self.conv3(out)
 

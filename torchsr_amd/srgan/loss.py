@@ -6,7 +6,8 @@ with this repository, so the graph is restated from the public cfg 'E' definitio
 and the weights are loaded from a user supplied state_dict (``weights=`` argument,
 ``$TORCHSR_VGG19_WEIGHTS`` or the torch hub cache).  Without a file the features are
 seeded-random (kaiming-normal, as torchvision initialises VGG) -- good for
-benchmarks and parity tests, not for training quality; a warning says so.
+benchmarks and parity tests, not for training quality: library callers get a warning,
+the ``train`` command line refuses to start unless ``--vgg-weights random`` asks for it.
 """
 import os
 import warnings
@@ -62,7 +63,7 @@ class VGGLoss(nn.Module):
     def __init__(self, feature_layer: int = 36, weights: Optional[str] = None, seed: int = 1234) -> None:
         super().__init__()
         self.features = make_vgg19_features(feature_layer).eval()
-        path = _find_weights(weights)
+        path = None if weights == 'random' else _find_weights(weights)
         if path is not None:
             state = torch.load(path, map_location='cpu')
             own = self.features.state_dict()
@@ -71,8 +72,9 @@ class VGGLoss(nn.Module):
             self.features.load_state_dict(picked, strict=True)
             self.pretrained = True
         else:
-            warnings.warn(f'{VGG19_FILE} not found (pass weights=, or set TORCHSR_VGG19_WEIGHTS): VGGLoss uses '
-                          'seeded random features', stacklevel=2)
+            if weights != 'random':  # 'random' is the explicit opt-in of benchmarks, tests and `--vgg-weights random`
+                warnings.warn(f'{VGG19_FILE} not found (pass weights=, or set TORCHSR_VGG19_WEIGHTS): VGGLoss uses '
+                              'seeded random features', stacklevel=2)
             g = torch.Generator().manual_seed(seed)
             for m in self.features:
                 if isinstance(m, Conv2d):
@@ -98,8 +100,7 @@ class VGGLoss(nn.Module):
 
     def forward(self, source: Tensor, target: Tensor = None, target_features: Tensor = None) -> Tensor:
         """``l1_loss(features(source), features(target))``.  ``target_features`` may carry the second
-        term when the caller has already computed it (the trainers do so on a second stream: the target
-        branch depends on nothing but the HR batch)."""
+        term when the caller has already computed it."""
         fs = self.features_nhwc(F.to_nhwc(source, 4))
         ft = target_features if target_features is not None else self.target_features(target)
         return F.l1_loss(fs, ft)

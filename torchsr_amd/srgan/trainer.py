@@ -5,17 +5,23 @@ optimiser settings, checkpoint files and per-epoch PSNR test as the reference.  
 different is underneath:
 
 * all device work goes through the hand-written HIP kernels (``torchsr_amd.functional``);
-* the whole train step is captured once into a hipGraph and replayed (the step is ~700 kernel
+* the whole train step is captured once into a hipGraph and replayed (the step is ~600 kernel
   launches of a few microseconds each; eager launches would be host bound);
-* data parallelism is one process per GPU with two flat-buffer all-reduces per step on RCCL
-  (``torchsr_amd.ddp``) instead of ``DistributedDataParallel``; the discriminator's 94 MB
-  gradient exchange overlaps the VGG19 forward;
+* data parallelism is one process per GPU with bucketed flat-buffer all-reduces on RCCL
+  (``torchsr_amd.ddp``) instead of ``DistributedDataParallel``: the backward pass is paused where a
+  bucket is complete, so the discriminator's 75 MB classifier gradient is on xGMI while its
+  convolutions' backward still runs, and the rest rides under the VGG19 forward;
 * the discriminator pass inside the generator update does not compute the discriminator weight
   gradients the reference computes there and never uses.
 
-AMP: the reference autocasts the pre-training phase to fp16 with loss scaling on CUDA
-(trainer.py:382-388) and runs the GAN phase in fp32.  This implementation is fp32 in both phases
-(exact-fp32 MFMA); ``--disable-amp`` is accepted and ignored.
+AMP follows the reference region by region.  SRGAN autocasts ONLY the pre-training body
+(trainer.py:382-385, fp16 + GradScaler on CUDA); ``_gan_loop`` (:416-469) has no autocast and runs in
+fp32 whatever ``--disable-amp`` says.  Here an autocast region selects bf16 products with fp32
+accumulation in the convolutions of the networks it encloses (``srx_conv2d_t::precision``; BASELINE
+config 4 asks for bf16 on MI355X, which needs no loss scaling); tensors, BatchNorm, losses, weight
+gradients and Adam stay fp32, and everything outside such a region is exact fp32.  ``amp_phases`` names
+the phases the reference autocasts: ``('psnr',)`` here, ``('psnr', 'gan')`` for ESRGAN
+(esrgan/trainer.py:384,446,461).
 """
 import os
 import time
@@ -28,8 +34,8 @@ import torch.distributed as dist
 from torch import Tensor
 
 from .. import functional as F
-from ..ddp import GradAllReduce, broadcast_module
-from ..layers import no_weight_grad
+from ..ddp import BackwardCuts, GradBuckets, broadcast_module
+from ..layers import no_weight_grad, set_conv_precision
 from ..optim import FlatAdam, FlatParams, StepLR
 from .discriminator import Discriminator
 from .generator import Generator
@@ -59,14 +65,15 @@ class SRGANTrainer:
     phase_prefix = 'srgan'
     generator_cls = Generator
     discriminator_cls = Discriminator
+    amp_phases = ('psnr',)  # phases the reference wraps in amp.autocast (trainer.py:382); the GAN loop is fp32
+    # data parallel: first parameter of the gradient bucket that autograd completes FIRST (see ddp.py)
+    gen_tail_bucket = 'conv_layers.0.conv.weight'
+    disc_head_bucket = 'classifier.0.weight'
+    wandb_log_every = 50  # steps between train-loss samples sent to wandb (each one is a device -> host sync)
 
     def __init__(self, device, args: Namespace, train_loader, test_loader, train_len: int, test_len: int,
                  distributed: bool = False) -> None:
-        # The reference wraps its forward passes in torch.cuda.amp.autocast unless --disable-amp is given
-        # (trainer.py:379-383,438-462).  Here that selects bf16 products with fp32 accumulation in every
-        # convolution (forward + stride-1 data gradient, srx_conv2d_t::precision); tensors, BatchNorm, the
-        # losses, the weight gradients and Adam stay fp32, so no GradScaler is needed.
-        self.amp = not args.disable_amp
+        self.amp = not args.disable_amp  # trainer.py:67; what it enables is decided per phase (_enter_phase)
         self.batch_size = args.batch_size
         self.best_psnr = -1.0
         self.device = torch.device(device)
@@ -85,10 +92,6 @@ class SRGANTrainer:
         self.main_process = args.rank in [-1, 0]
         self.use_graphs = bool(getattr(args, 'use_graphs', True))
         self.vgg_weights = getattr(args, 'vgg_weights', None)
-        # VGG19(high_res) on a second stream: measured 2 % slower (12.86 vs 12.60 ms/step) on MI355X, and a
-        # fork / join pair cannot straddle the data-parallel graph segments, so off by default
-        self.overlap_target_vgg = bool(getattr(args, 'overlap_target_vgg', False)) and not distributed
-        self._target_feat = None
         if self.device.type != 'cuda':
             raise RuntimeError('torchsr_amd trains on an MI355X (device "cuda"); there is no CPU path')
         if self.device.index is None:
@@ -101,10 +104,9 @@ class SRGANTrainer:
         self._graph_pool = None
         self._calls: Dict[str, int] = {}
         self._static: Dict[str, Tensor] = {}
+        self._phase = None
+        self._cuts = BackwardCuts(('g.tail', 'd.head')) if distributed else None
         F.direct_grads[0] = True  # parameter gradients accumulate straight into the flat .grad views
-        # weight gradients on a second stream (a parallel hipGraph branch): measured 8 % SLOWER on MI355X
-        # (cross-queue dependencies cost more than the overlap wins), so off unless asked for
-        F.side_stream_enabled[0] = bool(getattr(args, 'side_stream', False))
         self._initialize_trainer()
         self._create_test_image()
 
@@ -113,10 +115,19 @@ class SRGANTrainer:
         self._initialize_models()
         self._initialize_loss()
         self._initialize_optimizers()
-        if self.amp:
-            from ..layers import set_conv_precision
-            for module in (self.generator, self.discriminator, self.vgg_loss):
-                set_conv_precision(module, 'bf16')
+        self._enter_phase('gan')
+
+    def _enter_phase(self, phase: str) -> None:
+        """Select the arithmetic of ``phase`` ('psnr', 'gan' or 'test'): bf16 products inside the regions the
+        reference autocasts (``amp_phases``, unless ``--disable-amp``), exact fp32 everywhere else -- the
+        validation pass (trainer.py:286-304) has no autocast.  Packed weight layouts do not depend on the
+        precision, so switching costs nothing; each phase has its own captured hipGraphs."""
+        if phase == self._phase:
+            return
+        self._phase = phase
+        precision = 'bf16' if (self.amp and phase in self.amp_phases) else 'fp32'
+        for module in (self.generator, self.discriminator, self.vgg_loss):
+            set_conv_precision(module, precision)
 
     def _initialize_models(self) -> None:
         """trainer.py:136-157.  DDP wrapping is replaced by flat buffers + explicit all-reduce."""
@@ -127,8 +138,11 @@ class SRGANTrainer:
             broadcast_module(self.discriminator)
         self.gen_flat = FlatParams(self.generator)
         self.disc_flat = FlatParams(self.discriminator)
-        self.gen_sync = GradAllReduce(self.gen_flat) if self.distributed else None
-        self.disc_sync = GradAllReduce(self.disc_flat) if self.distributed else None
+        # gradient buckets in parameter order: [0] = the body (complete LAST in the backward pass), [1] = the slice
+        # autograd completes first (the generator's sub-pixel tail, the discriminator's classifier)
+        self.gen_sync = GradBuckets(self.gen_flat, (self.gen_tail_bucket,), self.generator) if self.distributed else None
+        self.disc_sync = GradBuckets(self.disc_flat, (self.disc_head_bucket,), self.discriminator) \
+            if self.distributed else None
 
     def _initialize_loss(self) -> None:
         """trainer.py:159-165 (MSELoss / BCELoss are kernels in torchsr_amd.functional)."""
@@ -173,11 +187,13 @@ class SRGANTrainer:
             print(statement)
 
     def _log_wandb(self, contents: dict, step: int = None) -> None:
-        if wandb and self.main_process:
-            wandb.log(contents, step=step)
+        """trainer.py:219-231.  ``wandb.init`` is the CLI's job (torchsr.py:242-243); a trainer built by other
+        code without a run simply does not log."""
+        if wandb and self.main_process and getattr(wandb, 'run', None) is not None:
+            wandb.log({k: (v.item() if torch.is_tensor(v) else v) for k, v in contents.items()}, step=step)
 
     def _cleanup(self) -> None:
-        if wandb:
+        if wandb and getattr(wandb, 'run', None) is not None:
             wandb.finish()
 
     def _model_state(self, epoch: int, phase: str) -> dict:
@@ -241,6 +257,7 @@ class SRGANTrainer:
         # with a process group alive, RCCL's watchdog thread may query events while we capture; only
         # the capturing thread's own calls should be policed then
         mode = 'thread_local' if self.distributed else 'global'
+        cut_state = {k: list(v) for k, v in self._cuts.pairs.items()} if self._cuts is not None else None
         try:
             with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=mode):
                 fn()
@@ -250,6 +267,8 @@ class SRGANTrainer:
             self._graphs.clear()
             torch.cuda.synchronize()
             F.bump_pack_epoch()  # packs "refreshed" during the failed capture never ran
+            if cut_state is not None:
+                self._cuts.pairs = cut_state  # what the failed capture cut or resumed never ran either
             fn()
             return
         self._graphs[key] = g
@@ -269,24 +288,33 @@ class SRGANTrainer:
 
     # ------------------------------------------------------------------ pre-training
     def _pretrain_body(self) -> None:
-        """Loop body of ``_pretrain``, trainer.py:380-388 (no autocast / GradScaler: fp32)."""
+        """Loop body of ``_pretrain``, trainer.py:380-386.  The autocast region is the generator forward + MSE
+        (``_enter_phase('psnr')``); bf16 needs no GradScaler, so ``scaler.scale / step / update`` reduce to
+        ``backward`` + ``step``."""
         self.psnr_optimizer.zero_grad()
         super_res = self.generator(self._static['low_res'])
         loss = self.pixel_loss(super_res, self._static['high_res'])
         loss.backward()
-        F.join_side_stream()
         self._losses['psnr/train-loss'] = loss.detach()
 
     def pretrain_step(self, low_res: Tensor, high_res: Tensor) -> Tensor:
         """One SRResNet pre-training step on device tensors; returns the (device) loss."""
+        self._enter_phase('psnr')
         self._losses = getattr(self, '_losses', {})
         self._stage('low_res', low_res)
         self._stage('high_res', high_res)
         if self.distributed:
-            self._exec('psnr.fwdbwd', self._pretrain_body)
-            self.gen_sync.launch()
-            self.gen_sync.wait()
-            self._exec('psnr.opt', self.psnr_optimizer.step)
+            F.cut_hook[0] = self._cuts
+            try:
+                self._cuts.names = {'g.tail'}
+                self._exec('psnr.head', self._pretrain_body)           # stops at the generator's 'g.tail' cut
+                self.gen_sync.launch(1)                                # conv_layers / conv3 gradients: on the wire
+                self._exec('psnr.body', lambda: self._cuts.resume('g.tail'))  # residual tower backward
+                self.gen_sync.launch(0)
+                self.gen_sync.wait()
+                self._exec('psnr.opt', self.psnr_optimizer.step)
+            finally:
+                F.cut_hook[0] = None
         else:
             self._exec('psnr.all', lambda: (self._pretrain_body(), self.psnr_optimizer.step()))
         return self._losses['psnr/train-loss']
@@ -315,7 +343,7 @@ class SRGANTrainer:
             for sub_step, (low_res, high_res) in enumerate(self.train_loader):
                 loss = self.pretrain_step(low_res, high_res)
                 step = (sub_step * self.batch_size * self.world_size) + ((epoch - 1) * self.train_len)
-                if wandb:
+                if sub_step % self.wandb_log_every == 0:  # trainer.py:393-399 logs every step (a sync each)
                     self._log_wandb({'psnr/train-loss': loss, 'psnr/epoch': epoch}, step=step)
             torch.cuda.synchronize()
             time_taken = time.time() - start_time
@@ -325,58 +353,41 @@ class SRGANTrainer:
             self._test(epoch, f'{self.phase_prefix}-psnr', step)
 
     # ------------------------------------------------------------------ GAN phase
-    def _fork_target_features(self, high_res: Tensor) -> None:
-        """VGG19(high_res) (loss.py:53, detached) depends on nothing but the HR batch: issue its 115 GFLOP on
-        a second stream at the top of the step so that the big VGG kernels fill the CUs the generator's
-        small launches leave idle (one fork / one join: a single parallel branch in the hipGraph)."""
-        self._target_feat = None
-        if not self.overlap_target_vgg:
-            return
-        main = torch.cuda.current_stream()
-        side = F.side_stream(self.device.index)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self._target_feat = self.vgg_loss.target_features(high_res)
-        self._target_feat.record_stream(main)
-
-    def _join_target_features(self) -> Optional[Tensor]:
-        if self._target_feat is None:
-            return None
-        torch.cuda.current_stream().wait_stream(F.side_stream(self.device.index))
-        feat, self._target_feat = self._target_feat, None
-        return feat
-
     def _phase_disc(self) -> None:
-        """trainer.py:442-450: G forward, D on real and fake, D backward."""
+        """trainer.py:442-450: G forward, D on real and fake, D backward (down to the 'd.head' cut when data
+        parallel: the classifier's gradients are complete then, the convolutions' follow in ``_phase_disc_body``)."""
         low_res, high_res = self._static['low_res'], self._static['high_res']
-        self._fork_target_features(high_res)
         self.disc_optimizer.zero_grad()                                      # :442
         self._super_res = self.generator(low_res)                            # :444
         d_real = self.bce_loss(self.discriminator(high_res), 1.0)            # :446
         d_fake = self.bce_loss(self.discriminator(self._super_res.detach()), 0.0)  # :447
         disc_loss = F.axpby(d_real, d_fake, 1.0, 1.0)                        # :448
         disc_loss.backward()                                                 # :450
-        F.join_side_stream()
         self._losses['gan/disc-loss'] = disc_loss.detach()
+
+    def _phase_disc_body(self) -> None:
+        self._cuts.resume('d.head')
 
     def _phase_content(self) -> None:
         """trainer.py:453-455: VGG19 perceptual loss (does not need the updated discriminator)."""
         self.gen_optimizer.zero_grad()                                       # :453
-        self._content = self.vgg_loss(self._super_res, self._static['high_res'],
-                                      target_features=self._join_target_features())  # :455
+        self._content = self.vgg_loss(self._super_res, self._static['high_res'])  # :455
 
     def _phase_gen(self) -> None:
-        """trainer.py:451,456-468: D update, adversarial term through the UPDATED D, G backward."""
+        """trainer.py:451,456-468: D update, adversarial term through the UPDATED D, G backward (down to the
+        'g.tail' cut when data parallel)."""
         self.disc_optimizer.step()                                           # :451
         with no_weight_grad():  # C5: D's weight gradients are never consumed here
             adversarial = self.bce_loss(self.discriminator(self._super_res), 1.0)  # :456
         gen_loss = F.axpby(self._content, adversarial, 1.0, 0.001)           # :457
         gen_loss.backward()                                                  # :468
-        F.join_side_stream()
         self._losses['gan/content-loss'] = self._content.detach()
         self._losses['gan/adversarial-loss'] = adversarial.detach()
         self._losses['gan/train-loss'] = gen_loss.detach()
         self._super_res = self._content = None
+
+    def _phase_gen_body(self) -> None:
+        self._cuts.resume('g.tail')
 
     def _gan_all(self) -> None:
         self._phase_disc()
@@ -386,18 +397,32 @@ class SRGANTrainer:
 
     def gan_step(self, low_res: Tensor, high_res: Tensor) -> Dict[str, Tensor]:
         """One full GAN step (``_gan_loop`` without the logging); returns device loss tensors."""
+        self._enter_phase('gan')
         self._losses = getattr(self, '_losses', {})
         self._stage('low_res', low_res)
         self._stage('high_res', high_res)
         if self.distributed:
-            self._exec('gan.disc', self._phase_disc)
-            self.disc_sync.launch()            # 94 MB all-reduce rides under the VGG forward
-            self._exec('gan.content', self._phase_content)
-            self.disc_sync.wait()
-            self._exec('gan.gen', self._phase_gen)
-            self.gen_sync.launch()
-            self.gen_sync.wait()
-            self._exec('gan.gopt', self.gen_optimizer.step)
+            # hipGraph segments between the collectives; every all-reduce is launched the moment its bucket's
+            # gradients are enqueued and awaited right before the optimiser that consumes it
+            F.cut_hook[0] = self._cuts
+            try:
+                self._cuts.names = {'g.tail', 'd.head'}
+                self._exec('gan.disc.head', self._phase_disc)
+                self.disc_sync.launch(1)           # classifier.*: 75.5 MB, under D's conv backward + the VGG forward
+                self._exec('gan.disc.body', self._phase_disc_body)
+                self.disc_sync.launch(0)           # features.*: 19 MB, under the VGG forward
+                self._cuts.names = {'g.tail'}      # (ESRGAN runs its second generator forward in this segment)
+                self._exec('gan.content', self._phase_content)
+                self.disc_sync.wait()
+                self._cuts.names = set()           # the discriminator pass below is differentiated in ONE piece
+                self._exec('gan.gen.head', self._phase_gen)
+                self.gen_sync.launch(1)            # conv_layers.* / conv3.*: under the residual tower's backward
+                self._exec('gan.gen.body', self._phase_gen_body)
+                self.gen_sync.launch(0)
+                self.gen_sync.wait()
+                self._exec('gan.gopt', self.gen_optimizer.step)
+            finally:
+                F.cut_hook[0] = None
         else:
             self._exec('gan.all', self._gan_all)
         return self._losses
@@ -405,7 +430,8 @@ class SRGANTrainer:
     def _gan_loop(self, low_res: Tensor, high_res: Tensor, step: int) -> None:
         """trainer.py:416-469."""
         losses = self.gan_step(low_res, high_res)
-        if wandb:
+        self._gan_calls = getattr(self, '_gan_calls', 0) + 1
+        if (self._gan_calls - 1) % self.wandb_log_every == 0:  # :459-466 logs every step (a sync each)
             self._log_wandb({'gan/disc-lr': self.disc_scheduler.get_last_lr()[0],
                              'gan/gen-lr': self.gen_scheduler.get_last_lr()[0],
                              'gan/train-loss': losses['gan/train-loss']}, step=step)
@@ -450,7 +476,9 @@ class SRGANTrainer:
 
     # ------------------------------------------------------------------ validation
     def _test(self, epoch: int, phase: str, step: int) -> None:
-        """trainer.py:260-343: eval-mode G, per-batch PSNR (unclamped SR), best/latest checkpoints."""
+        """trainer.py:260-343: eval-mode G (fp32: no autocast there), per-batch PSNR (unclamped SR), best/latest
+        checkpoints, monitor image."""
+        self._enter_phase('test')
         self.generator.eval()
         self._log(f'Testing results after epoch {epoch}')
         with torch.no_grad():
@@ -464,8 +492,12 @@ class SRGANTrainer:
                 psnr += 10 * log10(1 / mse)                                   # :296
                 loss += mse
                 batches += 1
+            if batches == 0:
+                # a PSNR of 0 would be written to every later checkpoint decision; the reference divides by
+                # len(test_loader) == 0 here
+                raise RuntimeError('the test loader yielded no batch on this rank: the test shard is empty '
+                                   f'(test_len {self.test_len}, world size {self.world_size})')
             time_taken = max(time.time() - start_time, 1e-9)
-            batches = max(batches, 1)
             throughput = batches * self.batch_size * self.world_size / time_taken
             psnr, loss = psnr / batches, loss / batches
             self._log(f'PSNR: {round(psnr, 3)}, Throughput: {round(throughput, 3)} images/sec')
@@ -480,6 +512,11 @@ class SRGANTrainer:
             if self.save_image and self.main_process:
                 super_res = self.generator(self.test_image)
                 save_image(super_res, f'output/SR_epoch{epoch}.png')
+                if wandb and getattr(wandb, 'run', None) is not None:        # :337-343, at 1/4 size
+                    _, _, height, width = super_res.shape
+                    small = torch.nn.functional.interpolate(super_res.clamp(0, 1).cpu(), size=(height // 4, width // 4),
+                                                            mode='bicubic', align_corners=False).clamp(0, 1)
+                    self._log_wandb({f'images/epoch{epoch}': wandb.Image(small[0].permute(1, 2, 0).numpy())})
         self.generator.train()
 
     def train(self) -> None:

@@ -9,7 +9,11 @@ without DDP's ``module.`` prefix), run the generator in eval mode without autogr
 Large images (BASELINE config 5: 1080p -> 8K) are processed in spatial tiles with a halo: the
 generator is fully convolutional and, in eval mode, BatchNorm is a per-channel affine map, so a tile
 whose halo covers the receptive field reproduces the untiled result exactly while every conv call
-stays below the kernels' 2^24-pixel / 2^31-element addressing limits.
+stays below the kernels' 2^24-pixel / 2^31-element addressing limits.  That holds for SRGAN, whose
+receptive field radius is < 40 low-resolution pixels (``Generator.halo`` = 48).  RRDBNet's is ~350 pixels
+(69 dense blocks of five 3x3 convs), more than a tile can carry: ESRGAN tiles use a 64-pixel halo and
+are an approximation near tile borders (the dense blocks' 0.2 residual scaling makes far pixels count
+little); pass ``halo=`` / ``max_tile_pixels=`` to trade time for accuracy.
 """
 import os
 from argparse import Namespace
@@ -18,7 +22,7 @@ from collections import OrderedDict
 import torch
 from torch import Tensor
 
-HALO = 48            # LR pixels; SRResNet's receptive field radius is < 44 LR pixels, RRDBNet uses more tiles
+HALO = 48            # LR pixels: default when the generator does not name its own (``Generator.halo``)
 MAX_TILE_PIXELS = 600 * 1000  # LR pixels per tile (x16 HR pixels must stay < 2^24)
 
 
@@ -29,10 +33,12 @@ def load_generator_state(path: str) -> OrderedDict:
 
 
 @torch.no_grad()
-def upscale(generator: torch.nn.Module, low_res: Tensor, halo: int = HALO,
+def upscale(generator: torch.nn.Module, low_res: Tensor, halo: int = None,
             max_tile_pixels: int = MAX_TILE_PIXELS, scale: int = 4) -> Tensor:
     """``generator(low_res)`` in eval mode, tiled when the image is large.  ``low_res``: [N,3,h,w]."""
     generator.eval()
+    if halo is None:
+        halo = int(getattr(generator, 'halo', HALO))
     n, c, h, w = low_res.shape
     if n * h * w <= max_tile_pixels:
         return generator(low_res)

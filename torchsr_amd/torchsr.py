@@ -8,6 +8,7 @@ longer divides by zero; ``--train-dir synthetic:N`` trains on N seeded random cr
 """
 import os
 import random
+import sys
 from argparse import ArgumentParser, ArgumentTypeError, Namespace
 from typing import Tuple
 
@@ -17,6 +18,11 @@ import torch.distributed as dist
 
 from torchsr_amd.constants import BATCH_SIZE, EPOCHS, MODEL, PRE_EPOCHS, TRAIN_DIR
 from torchsr_amd.models import MODELS, select_test_model, select_trainer_model
+
+try:  # optional, as in the reference (torchsr.py:26-29)
+    import wandb
+except ImportError:
+    wandb = None
 
 
 def positive_integer(value: str) -> int:
@@ -89,7 +95,9 @@ def parse_args(argv=None) -> Namespace:
     train.add_argument('--seed', type=int, default=0)
     train.add_argument('--skip-image-save', action='store_true')
     train.add_argument('--train-dir', type=str, default=TRAIN_DIR)
-    train.add_argument('--vgg-weights', type=str, default=None, help='path to vgg19-dcbb9e9d.pth')
+    train.add_argument('--vgg-weights', type=str, default=None,
+                       help='path to vgg19-dcbb9e9d.pth (default: $TORCHSR_VGG19_WEIGHTS, then the torch hub cache); '
+                            '"random" trains against seeded random VGG19 features (smoke runs only)')
     train.add_argument('--no-graphs', action='store_true', help='run the step eagerly instead of as a hipGraph')
     train.add_argument('--device-data', action='store_true',
                        help='keep the decoded images in HBM and crop / flip / bicubic-downsample on the GPU')
@@ -103,12 +111,21 @@ def main(argv=None) -> None:
     """torchsr.py:239-270."""
     args = parse_args(argv)
     args, distributed = distributed_params(args)
+    if wandb and args.rank in [-1, 0]:                      # torchsr.py:242-243
+        wandb.init(config=args, name='TorchSR', project='torchsr')
     device = get_device(args)
     if args.function == 'test':
         from torchsr_amd.test import test
         test(args, select_test_model(args), device)
         return
     model_class, crop_size = select_trainer_model(args)
+    if args.vgg_weights != 'random':
+        # the reference always trains against the pretrained VGG19 (srgan/loss.py:30); a perceptual loss on random
+        # features is not that objective, so it has to be asked for
+        from torchsr_amd.srgan.loss import VGG19_FILE, _find_weights
+        if _find_weights(args.vgg_weights) is None:
+            sys.exit(f'torchsr train: {VGG19_FILE} not found (--vgg-weights PATH, $TORCHSR_VGG19_WEIGHTS or the torch hub '
+                     'cache); pass "--vgg-weights random" to train against seeded random VGG19 features instead')
     if args.seed:
         random.seed(args.seed)
         np.random.seed(args.seed)
@@ -118,6 +135,9 @@ def main(argv=None) -> None:
         if args.master_port:
             os.environ['MASTER_PORT'] = args.master_port
         dist.init_process_group(backend='nccl' if device.type == 'cuda' else 'gloo')
+        if args.rank == 0:
+            from torchsr_amd.ddp import describe_group
+            print(f'process group: {describe_group()}')
     args.use_graphs = not args.no_graphs
     from torchsr_amd.dataset import initialize_datasets, initialize_device_datasets
     if args.device_data:
