@@ -9,15 +9,22 @@ discriminator forwards, discriminator backward + Adam, VGG19 perceptual loss (tw
 data-gradient backward), generator backward + Adam -- on a batch of 16 synthetic 96x96 HR crops
 per GPU, fp32, random-init weights (VGG19 features seeded-random: the pretrained file is not
 available offline).  Inputs are resident in HBM before the timed region.  One process per GPU;
-at N > 1 the two flat gradient buffers are all-reduced over RCCL (weak scaling).
+at N > 1 the gradient buckets are all-reduced over RCCL as the backward pass completes them
+(weak scaling); the line then carries the process group it actually ran on.
 
 Rank 0 prints ONE JSON line.  At N = 1 it also carries
-  "roofline":     the dominant kernel (by device time) measured live with HIP events on the
-                  launch stream in an instrumented pass of the same step: algorithmic FLOPs of
-                  its launches / their event-measured duration, against the 157.3 TFLOP/s fp32
-                  MFMA peak of MI355X;
-  "cpu_baseline": the CPU oracle (oracle/srgan.py, stock torch ops) running the identical step
-                  on the host cores -- a reported baseline, not the target.
+  "parity":       the four losses of the FIRST step (seeded default-init weights) on the HIP path and on the
+                  CPU oracle from the same weights and batch; ``rel`` is the generator-loss difference;
+  "roofline":     the dominant (kernel, GEMM shape) pair by device time, measured live with HIP events on the
+                  launch stream in an instrumented eager pass of the same step: algorithmic FLOPs of its
+                  launches / their event-measured duration, against the 157.3 TFLOP/s fp32 MFMA peak of
+                  MI355X; ``traffic`` = HBM bytes per launch of that pair from the committed rocprofv3 --pmc
+                  passes (profiles/r02_traffic.json), null when that pair was not profiled;
+                  ``north_star`` = the 3x3 64->64 residual conv at 16x24x24 timed the way the step runs it,
+                  as back-to-back launches inside a replayed hipGraph (HIP events on the replay stream);
+  "cpu_baseline": the CPU oracle (oracle/srgan.py, stock torch ops) running the identical step on the host
+                  cores, BASELINE.md section 5 protocol (3 warm-up + 10 timed steps, median), plus the
+                  config-1 leg (pre-training step, batch 2) -- a reported baseline, not the target.
 """
 import argparse
 import ctypes as C
@@ -38,14 +45,96 @@ BATCH = 16          # per GPU (BASELINE.json configs[1])
 CROP = 96
 GF_PER_CROP = 43.23  # necessary algorithmic GFLOP per crop of the GAN step
 PEAK_TFLOPS = 157.3  # fp32 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+NORTH_STAR_GF = 0.6795  # 3x3 64->64 conv at 16x24x24: 2 * 9216 * 64 * 576
 
 
-def synth_batch(device, rank):
+def synth_batch(device, rank, batch=BATCH):
     g = torch.Generator().manual_seed(1234 + rank)
-    hr = torch.rand(BATCH, 3, CROP, CROP, generator=g)
+    hr = torch.rand(batch, 3, CROP, CROP, generator=g)
     lr = torch.nn.functional.interpolate(hr, scale_factor=0.25, mode='bicubic', align_corners=False,
                                          antialias=True).clamp(0, 1)
     return lr.to(device), hr.to(device)
+
+
+def cpu_states(trainer):
+    cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}  # noqa: E731
+    return cpu(trainer.generator.state_dict()), cpu(trainer.discriminator.state_dict()), \
+        cpu(trainer.vgg_loss.features.state_dict())
+
+
+def host_threads():
+    """Host cores this process may use: the GPU box gives one GPU's share of the machine (cgroup / affinity),
+    ``os.cpu_count()`` reports the whole machine."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:  # cgroup v2 CPU quota, when there is one
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get('SRX_CPU_BASELINE_THREADS', '64'))))
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def parity_check(states, lr, hr, gpu_losses):
+    """First GAN step from the same weights and batch on the CPU oracle vs what the HIP path just computed."""
+    from oracle import srgan as O
+    torch.set_num_threads(host_threads())
+    orc = O.SRGANStepOracle(*states)
+    want = orc.gan_step(lr.cpu(), hr.cpu())
+    keys = ('gan/disc-loss', 'gan/content-loss', 'gan/adversarial-loss', 'gan/train-loss')
+    got = [float(gpu_losses[k]) for k in keys]
+    rels = [abs(g - w) / max(abs(w), 1e-3) for g, w in zip(got, want)]
+    return {'gen_loss_gpu': got[3], 'gen_loss_oracle': want[3], 'rel': rels[3], 'max_rel_of_4_losses': max(rels),
+            'losses_gpu': got, 'losses_oracle': list(want), 'tolerance': 1e-3, 'ok': max(rels) < 1e-3,
+            'what': 'first GAN step, batch 16, seeded default init, oracle/srgan.py on the host'}
+
+
+def north_star_in_graph(device, reps=66, replays=20):
+    """The north-star kernel the way the step runs it: `reps` back-to-back launches (the 66 per step) inside one
+    hipGraph, replayed; HIP events on the replay stream around each replay."""
+    from torchsr_amd.layers import Conv2d
+    torch.manual_seed(3)
+    conv = Conv2d(64, 64, 3, 1, 1, bias=False).to(device)
+    x = torch.rand(16, 24, 24, 64, device=device)
+    with torch.no_grad():
+        conv(x)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = x
+            for _ in range(reps):
+                y = conv(x)  # same input: every launch does identical work, launches stay dependent on the stream
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(replays):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e3 / reps)
+    times.sort()
+    us = times[len(times) // 2]
+    tf = NORTH_STAR_GF / us * 1e3
+    return {'kernel': 'rt36_conv3x3_c64_kernel<1>', 'shape': '3x3 64->64 @16x24x24 (M 9216, N 64, K 576)',
+            'launches_per_replay': reps, 'us_per_launch_in_graph': round(us, 3), 'tflops': round(tf, 2),
+            'frac': round(tf / PEAK_TFLOPS, 4), 'gflop_per_launch': NORTH_STAR_GF,
+            'note': 'includes the ~1.5 us kernel boundary between dependent launches'}
 
 
 def roofline_pass(trainer, lr, hr, reps=2):
@@ -65,76 +154,88 @@ def roofline_pass(trainer, lr, hr, reps=2):
     finally:
         n = _lib.lib().srx_prof_stop()
         trainer.use_graphs = was
-    groups = {}
-    name = C.create_string_buffer(64)
+    pairs, kernels = {}, {}
+    name = C.create_string_buffer(112)
     ms, fl = C.c_float(), C.c_double()
     for i in range(n):
-        _lib.call('srx_prof_get', i, name, 64, C.byref(ms), C.byref(fl))
-        gsum = groups.setdefault(name.value.decode(), [0.0, 0.0, 0])
-        gsum[0] += ms.value
-        gsum[1] += fl.value
-        gsum[2] += 1
-    total_ms = sum(v[0] for v in groups.values())
-    name, (ms, fl, cnt) = max(groups.items(), key=lambda kv: kv[1][0])
+        _lib.call('srx_prof_get', i, name, 112, C.byref(ms), C.byref(fl))
+        full = name.value.decode()
+        for table, key in ((pairs, full), (kernels, full.split(' MxNxK=')[0])):
+            gsum = table.setdefault(key, [0.0, 0.0, 0])
+            gsum[0] += ms.value
+            gsum[1] += fl.value
+            gsum[2] += 1
+    total_ms = sum(v[0] for v in kernels.values())
+    full, (ms, fl, cnt) = max(pairs.items(), key=lambda kv: kv[1][0])
+    kname, _, shape = full.partition(' MxNxK=')
     achieved = fl / (ms * 1e-3) / 1e12
-    table = {k: {'ms_per_step': v[0] / reps, 'gflop_per_step': v[1] / reps / 1e9, 'launches_per_step': v[2] // reps,
-                 'tflops': v[1] / (v[0] * 1e-3) / 1e12} for k, v in groups.items()}
-    # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
-    # tools/pmc_traffic.py); counters cannot be read from inside the process, so the committed summary is used
-    traffic = None
-    for f in sorted(os.listdir(os.path.join(ROOT, 'profiles'))) if os.path.isdir(os.path.join(ROOT, 'profiles')) else []:
-        if f.startswith('r01_traffic') and f.endswith('.json'):
-            t = json.load(open(os.path.join(ROOT, 'profiles', f)))
-            if t.get('kernel') == name:
-                traffic = round(t['hbm_bytes_per_launch'])
+    table = {k: {'ms_per_step': round(v[0] / reps, 4), 'gflop_per_step': round(v[1] / reps / 1e9, 3),
+                 'launches_per_step': v[2] // reps, 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 2)}
+             for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][0])}
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE: tools/pmc_traffic.py) of
+    # tools/bench_kernels.py restricted to ONE layer shape; counters cannot be read from inside the process
+    traffic, alg_bytes = None, None
+    tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+    if os.path.exists(tpath):
+        ent = json.load(open(tpath)).get(full)
+        if ent:
+            traffic, alg_bytes = round(ent['hbm_bytes_per_launch']), ent.get('algorithmic_bytes_per_launch')
     return {
-        'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / PEAK_TFLOPS, 4), 'traffic': traffic,
+        'bound': 'mfma', 'kernel': kname, 'shape_MxNxK': shape, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS,
+        'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS, 4), 'traffic': traffic,
+        'algorithmic_bytes_per_launch': alg_bytes,
         'avg_launch_us': round(ms / cnt * 1e3, 2), 'launches_per_step': cnt // reps,
         'gflop_per_launch': round(fl / cnt / 1e9, 4),
         'conv_ms_per_step': round(total_ms / reps, 3), 'by_kernel': table,
     }
 
 
-def cpu_baseline(trainer, lr, hr, steps=2):
-    """The oracle's GAN step on the host cores, same weights, same batch."""
+def cpu_baseline(states, lr, hr, warmup=3, steps=10, budget_s=60.0):
+    """The oracle's steps on the host cores, same weights, same batch (3 warm-up + 10 timed
+    steps, median).  A slow host cuts the timed steps short at ``budget_s`` seconds and says so."""
     from oracle import srgan as O
-    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get('SRX_CPU_BASELINE_THREADS', '16'))))
+    cores = host_threads()
     torch.set_num_threads(cores)
-    cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}  # noqa: E731
-    orc = O.SRGANStepOracle(cpu(trainer.generator.state_dict()), cpu(trainer.discriminator.state_dict()),
-                            cpu(trainer.vgg_loss.features.state_dict()))
     lrc, hrc = lr.cpu(), hr.cpu()
-    t0 = time.perf_counter()
-    orc.gan_step(lrc, hrc)  # warm-up
-    first = time.perf_counter() - t0
-    times = []
-    if first > 15.0:  # keep the default run within minutes on a slow host: the warm-up is the sample
-        times, steps = [first], 0
-    for _ in range(steps):
-        t0 = time.perf_counter()
-        orc.gan_step(lrc, hrc)
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+
+    def timed(fn):
+        t_begin = time.perf_counter()
+        for _ in range(warmup):
+            fn()
+            if time.perf_counter() - t_begin > budget_s / 2:
+                break
+        times = []
+        t_begin = time.perf_counter()
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            fn()
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_begin > budget_s:
+                break
+        times.sort()
+        return times[len(times) // 2], len(times)
+
+    orc = O.SRGANStepOracle(*states)
+    med, n = timed(lambda: orc.gan_step(lrc, hrc))
+    orc2 = O.SRGANStepOracle(*states)
+    med2, n2 = timed(lambda: orc2.pretrain_step(lrc[:2], hrc[:2]))
     return {'value': round(BATCH / med, 3), 'unit': 'crops/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{max(steps, 1)} GAN step(s) of batch {BATCH} (oracle/srgan.py, torch {torch.__version__} CPU ops), '
-                      f'median {med:.2f} s/step'}
+            'sample': f'{n} timed GAN steps of batch {BATCH} after {warmup} warm-up (oracle/srgan.py, torch {torch.__version__} '
+                      f'CPU ops), median {med:.3f} s/step',
+            'cpu_model': cpu_model(), 'os_cpu_count': os.cpu_count(), 'threads': torch.get_num_threads(),
+            'config1_pretrain_b2': {'value': round(2 / med2, 3), 'unit': 'crops/s',
+                                    'sample': f'{n2} timed pre-training steps of batch 2, median {med2 * 1e3:.1f} ms/step'}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-graphs', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -157,20 +258,23 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    import warnings
-    warnings.filterwarnings('ignore', message='.*seeded random features.*')
+    from torchsr_amd.ddp import describe_group
     from torchsr_amd.srgan.trainer import SRGANTrainer
 
     torch.manual_seed(0)  # identical init on every rank (and an explicit broadcast in the trainer)
     targs = Namespace(disable_amp=True, batch_size=BATCH, epochs=8, gan_checkpoint=None, local_rank=local_rank,
                       pretrain_epochs=1, psnr_checkpoint=None, skip_image_save=True, world_size=world,
-                      rank=rank if distributed else -1, use_graphs=not args.no_graphs)
+                      rank=rank if distributed else -1, use_graphs=not args.no_graphs, vgg_weights='random')
     trainer = SRGANTrainer(device, targs, [], [], BATCH, BATCH, distributed=distributed)
     trainer.generator.train()
     trainer.discriminator.train()
     lr, hr = synth_batch(device, rank)
 
-    for _ in range(3):  # set-up: two eager passes + hipGraph capture (not warm-up, not timed)
+    want_parity = world == 1 and not args.no_parity
+    states0 = cpu_states(trainer) if (world == 1 and not (args.no_parity and args.no_cpu_baseline)) else None
+    first = trainer.gan_step(lr, hr)  # set-up step 1 of 3 (eager); its losses feed the parity check
+    first = {k: float(v) for k, v in first.items()} if want_parity else None
+    for _ in range(2):  # set-up: second eager pass + hipGraph capture (not warm-up, not timed)
         trainer.gan_step(lr, hr)
     for _ in range(args.warmup):
         trainer.gan_step(lr, hr)
@@ -193,6 +297,21 @@ def main():
     if not (gen_loss == gen_loss):
         sys.exit('bench.py: generator loss is NaN')
 
+    # spread of the step time (outside the timed region): per-step HIP events on the step's stream
+    spread = None
+    if rank == 0 and not distributed:
+        evs = []
+        for _ in range(min(args.steps, 50)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            trainer.gan_step(lr, hr)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        spread = {'p10': round(ts[len(ts) // 10], 3), 'median': round(ts[len(ts) // 2], 3),
+                  'p90': round(ts[(len(ts) * 9) // 10], 3), 'samples': len(ts), 'how': 'HIP events around single steps'}
+
     if rank == 0:
         value = world * BATCH * args.steps / elapsed
         out = {
@@ -204,22 +323,33 @@ def main():
                                    '96x96 HR crops, batch 16 per GPU, fp32',
                        'per_gpu_batch': BATCH, 'global_batch': BATCH * world, 'crop': CROP,
                        'parallelism': f'dp{world}', 'hip_graph': not args.no_graphs,
-                       'vgg19_weights': 'pretrained' if trainer.vgg_loss.pretrained else 'seeded-random'},
+                       'vgg19_weights': 'pretrained' if trainer.vgg_loss.pretrained else 'seeded-random',
+                       'process_group': describe_group(),
+                       'grad_buckets': ({'generator': len(trainer.gen_sync), 'discriminator': len(trainer.disc_sync)}
+                                        if distributed else None)},
             'step_tflops': round(value * GF_PER_CROP / 1e3, 2),
             'step_frac_of_fp32_mfma_peak': round(value * GF_PER_CROP / 1e3 / (PEAK_TFLOPS * world), 4),
+            'step_ms_spread': spread,
             'final_gen_loss': round(gen_loss, 6),
         }
         if world == 1:
-            # the headline line must survive a failure of either side measurement
+            # the headline line must survive a failure of any side measurement
+            if want_parity:
+                try:
+                    out['parity'] = parity_check(states0, lr, hr, first)
+                except Exception as exc:  # noqa: BLE001
+                    print(f'bench.py: parity check failed to run: {type(exc).__name__}: {exc}', file=sys.stderr)
+                    out['parity'] = None
             if not args.no_roofline:
                 try:
                     out['roofline'] = roofline_pass(trainer, lr, hr)
+                    out['roofline']['north_star'] = north_star_in_graph(device)
                 except Exception as exc:  # noqa: BLE001
                     print(f'bench.py: roofline pass failed: {type(exc).__name__}: {exc}', file=sys.stderr)
-                    out['roofline'] = None
+                    out.setdefault('roofline', None)
             if not args.no_cpu_baseline:
                 try:
-                    out['cpu_baseline'] = cpu_baseline(trainer, lr, hr)
+                    out['cpu_baseline'] = cpu_baseline(states0, lr, hr)
                 except Exception as exc:  # noqa: BLE001
                     print(f'bench.py: cpu baseline failed: {type(exc).__name__}: {exc}', file=sys.stderr)
                     out['cpu_baseline'] = None

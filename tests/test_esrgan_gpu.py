@@ -81,6 +81,11 @@ def make_trainer(dev, batch=2, disable_amp=True, use_graphs=False):
 
 def assert_digests(keys, sd, digests, what):
     for k, dg in zip(keys, digests):
+        if str(k) == 'classifier.2.bias':
+            # the relativistic losses only see logit DIFFERENCES (real - mean(fake), fake - mean(real)), in which
+            # the last layer's bias cancels: its exact gradient is 0, what any fp32 implementation computes is
+            # rounding noise, and Adam turns noise into +-lr steps.  Nothing to pin.
+            continue
         d = tensor_digest(sd[str(k)].cpu())
         assert abs(d[0] - dg[0]) <= 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6, (what, k)
         assert abs(d[1] - dg[1]) <= 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6, (what, k)

@@ -125,7 +125,7 @@ def test_generator_vs_oracle_fresh_inputs(dev, seed):
     def oracle(dtype):
         sd = {k: (v.to(dtype).clone() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
         O._leaves(sd)
-        xo = x.to(dtype).requires_grad_(True)
+        xo = x.detach().to(dtype).clone().requires_grad_(True)
         yo = O.generator_forward(sd, xo, True)
         yo.square().mean().backward()
         return yo.detach(), xo.grad, {k: sd[k].grad for k in watch}
@@ -133,7 +133,7 @@ def test_generator_vs_oracle_fresh_inputs(dev, seed):
     y64, dx64, g64 = oracle(torch.float64)
     y32, dx32, g32 = oracle(torch.float32)
     gen = gen.to(dev).train()
-    xg = x.to(dev).requires_grad_(True)
+    xg = x.detach().to(dev).requires_grad_(True)
     y = gen(xg)
     assert y.shape == (3, 3, 52, 36)
     y.square().mean().backward()

@@ -40,7 +40,7 @@ extern "C" int srx_device_cus(void) {
 // default and never on inside a hipGraph capture.
 // ---------------------------------------------------------------------------
 namespace {
-struct ProfRec { hipEvent_t e0, e1; char name[64]; double flops; };
+struct ProfRec { hipEvent_t e0, e1; char name[112]; double flops; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 int g_prof_n = 0;

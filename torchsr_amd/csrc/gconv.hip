@@ -1078,8 +1078,10 @@ int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(p.full + p.tail * p.split);
-  char nm[64];
-  if (srx_prof_on()) snprintf(nm, sizeof(nm), "gconv_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, KS, XR, PR);
+  char nm[112];  // kernel + GEMM shape: the roofline leg of bench.py groups launches by both
+  if (srx_prof_on())
+    snprintf(nm, sizeof(nm), "gconv_kernel<%d, %d, %d, %d, %d, %d, %d> MxNxK=%dx%dx%d", BM, BN, WM, WN, KS, XR, PR, a.M, a.Cn,
+             a.K);
   SRX_LAUNCH_PROF(nm, 2.0 * a.M * a.Cn * a.K, (gconv_kernel<BM, BN, WM, WN, KS, XR, PR>), grid,
                   dim3((BM / WM) * (BN / WN) * 64 * KS), lds, st, a);
   SRX_CHECK_LAUNCH("gconv_kernel");
@@ -1650,8 +1652,10 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
   a.bslab = db ? ws + (size_t)nsplit * a.Cnw * a.Kw : nullptr;
   dim3 grid((unsigned)tiles, 1, nsplit);
   const double wfl = 2.0 * a.M * d->Cout * a.K;
-  if (d->precision) SRX_LAUNCH_PROF("wgrad_kernel<1>", wfl, wgrad_kernel<1>, grid, dim3(256), 0, st, a);
-  else SRX_LAUNCH_PROF("wgrad_kernel<0>", wfl, wgrad_kernel<0>, grid, dim3(256), 0, st, a);
+  char nm[112];
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "wgrad_kernel<%d> MxNxK=%dx%dx%d", d->precision ? 1 : 0, a.M, d->Cout, a.K);
+  if (d->precision) SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<1>, grid, dim3(256), 0, st, a);
+  else SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<0>, grid, dim3(256), 0, st, a);
   SRX_CHECK_LAUNCH("wgrad_kernel");
   const int64_t n = (int64_t)d->Cout * g.K;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, st, ws, nsplit, a.Cnw, a.Kw,

@@ -20,6 +20,7 @@
 // The two channel halves are folded through LDS; bias, activation, BatchNorm partial sums and the store
 // follow the generic epilogue (gconv.hip).
 #include "srx_common.h"
+#include <cstdio>
 #include <mutex>
 
 namespace {
@@ -243,8 +244,10 @@ int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const
   const int nb = patch_batches(d->W);
   const double fl = 2.0 * a.M * 64 * KTOT;
   const dim3 grid((unsigned)(a.M / RT));
-  if (nb == 1) SRX_LAUNCH_PROF("rt36_conv3x3_c64_kernel<1>", fl, rt36_conv3x3_c64_kernel<1>, grid, dim3(256), lds, st, a);
-  else SRX_LAUNCH_PROF("rt36_conv3x3_c64_kernel<2>", fl, rt36_conv3x3_c64_kernel<2>, grid, dim3(256), lds, st, a);
+  char nm[112];
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "rt36_conv3x3_c64_kernel<%d> MxNxK=%dx64x%d", nb, a.M, KTOT);
+  if (nb == 1) SRX_LAUNCH_PROF(nm, fl, rt36_conv3x3_c64_kernel<1>, grid, dim3(256), lds, st, a);
+  else SRX_LAUNCH_PROF(nm, fl, rt36_conv3x3_c64_kernel<2>, grid, dim3(256), lds, st, a);
   SRX_CHECK_LAUNCH("rt36_conv3x3_c64_kernel");
   return SRX_OK;
 }
