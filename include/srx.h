@@ -148,6 +148,17 @@ int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk
  * srx_prelu_bwd; srx_bn_act_bwd_reduce takes optional accumulation targets. */
 int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, const float* dy, float* dw_oihw,
                           int accumulate, float* db, float* ws, size_t ws_floats, void* stream);
+/* The same for `nprob` (<= 72) problems of ONE geometry in one launch.  Autograd produces the weight gradients of
+ * the generator's 33 identical 3x3 64->64 convs (srgan/residual.py:64,67; srgan/generator.py:48) one by one
+ * between the data gradients, each 0.68 GFLOP -- too small to fill the chip -- and nothing reads them before
+ * optimizer.step() (srgan/trainer.py:386-387,468-469), so the host may collect (x, dy) pairs during the backward
+ * pass and hand them over together.  `per_out` consecutive problems are segments of one gradient and are summed
+ * into one output (the discriminator's real and fake passes, srgan/trainer.py:446-450): xs / dys hold nprob
+ * pointers, dws / dbs hold nprob / per_out (dbs, or single entries of it, may be NULL). */
+size_t srx_conv2d_bwd_weight_multi_ws_floats(const srx_conv2d_t* d, int nprob);
+int srx_conv2d_bwd_weight_multi(const srx_conv2d_t* d, int nprob, int per_out, const float* const* xs,
+                                const float* const* dys, float* const* dws, int accumulate, float* const* dbs,
+                                float* ws, size_t ws_floats, void* stream);
 
 /* ------------------------------------------------- elementwise / reductions */
 /* out[c] = sum_m x[m][c]  (bias gradient of Conv2d / Linear); ws >= 2*rows*C floats */

@@ -182,6 +182,79 @@ def test_conv2d_bf16_products(dev, case):
     assert rel_err(conv.weight.grad, wa.grad) < 2e-5
 
 
+@pytest.mark.parametrize('case', [(2, 12, 12, 64, 64, 3, 1, 1, False), (2, 16, 16, 64, 32, 3, 2, 1, True),
+                                  (1, 10, 14, 3, 64, 3, 1, 1, True)])
+def test_grouped_weight_gradient(dev, case):
+    """srx_conv2d_bwd_weight_multi: several problems of one geometry in one launch (the generator's residual
+    convs: distinct outputs) and segments of one gradient (the discriminator's real + fake passes: per_out = 2),
+    accumulating into existing .grad buffers, with the bias gradient riding along -- against torch's
+    conv2d_weight on the CPU, problem by problem."""
+    from torchsr_amd import _lib
+    n, h, w, cin, cout, k, stride, pad, bias = case
+    cs_in, cs_out = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    d = _lib.Conv2dDesc(n, h, w, cin, cs_in, cout, cs_out, k, k, stride, pad, 0, 0, 0.0, 0, 0)
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    arr = lambda ts: (C.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])  # noqa: E731
+
+    def run(nprob, per_out):
+        xs = [rnd((n, cin, h, w), 100 + i) for i in range(nprob)]
+        dys = [rnd((n, cout, ho, wo), 200 + i) for i in range(nprob)]
+        nout = nprob // per_out
+        base_w = [rnd((cout, cin, k, k), 300 + o) for o in range(nout)]   # accumulate = 1: .grad already holds something
+        base_b = [rnd((cout,), 400 + o) for o in range(nout)]
+        want_w, want_b = [b.clone() for b in base_w], [b.clone() for b in base_b]
+        for i in range(nprob):
+            o = i // per_out
+            want_w[o] += torch.nn.grad.conv2d_weight(xs[i].double(), (cout, cin, k, k), dys[i].double(), stride=stride,
+                                                     padding=pad).float()
+            want_b[o] += dys[i].sum((0, 2, 3))
+        gx = [nhwc(x, cs_in).to(dev) for x in xs]
+        gdy = [nhwc(t, cs_out).to(dev) for t in dys]
+        gw = [b.to(dev) for b in base_w]
+        gb = [b.to(dev) for b in base_b] if bias else None
+        nws = L.srx_conv2d_bwd_weight_multi_ws_floats(C.byref(d), nprob)
+        ws = torch.empty(max(nws, 4), device=dev)
+        _lib.call('srx_conv2d_bwd_weight_multi', C.byref(d), nprob, per_out, arr(gx), arr(gdy), arr(gw), 1,
+                  arr(gb) if bias else None, ws.data_ptr(), nws, s)
+        for o in range(nout):
+            assert rel_err(gw[o], want_w[o]) < 2e-4, (nprob, per_out, o)
+            if bias:
+                assert rel_err(gb[o], want_b[o]) < 2e-4, (nprob, per_out, o)
+
+    run(1, 1)
+    run(5, 1)     # five layers, five gradients
+    run(6, 2)     # three gradients of two segments each
+    run(33, 1)    # the generator's residual tower
+    with pytest.raises(RuntimeError, match='whole number of outputs'):
+        _lib.call('srx_conv2d_bwd_weight_multi', C.byref(d), 5, 2, None, None, None, 1, None, None, 0, s)
+
+
+def test_deferred_weight_grads_equal_immediate(dev):
+    """functional.deferred_weight_grads: the same .grad buffers as the layer-by-layer backward pass."""
+    from torchsr_amd import functional as F
+    from torchsr_amd.optim import FlatParams
+    from torchsr_amd.srgan.generator import Generator
+    torch.manual_seed(11)
+    gens = [Generator().to(dev).train() for _ in range(2)]
+    gens[1].load_state_dict(gens[0].state_dict())
+    flats = [FlatParams(g) for g in gens]
+    x = rnd((2, 3, 12, 12), 5, 0.0, 1.0).to(dev)
+    old = F.direct_grads[0]
+    F.direct_grads[0] = True
+    try:
+        gens[0](x).square().mean().backward()
+        with F.deferred_weight_grads() as q:
+            gens[1](x).square().mean().backward()
+            assert sum(len(items) for _, items in q.groups.values()) == 37   # 33 residual + conv1, 2 sub-pixel, conv3
+            assert float(gens[1].blocks[3].conv1.weight.grad.abs().sum()) == 0.0  # nothing issued yet
+    finally:
+        F.direct_grads[0] = old
+    assert F.wgrad_queue[0] is None
+    assert rel_err(flats[1].grad, flats[0].grad) < 1e-5
+
+
 def test_row_tile_plan(dev):
     """The SRGAN residual conv at the reference batch runs as 256 workgroups of 36 pixels (forward and
     data gradient); a layer the row tile does not cover falls back to the generic plan."""

@@ -619,6 +619,24 @@ struct WArgs {
   // row split, so they add the column sums up on the way and write one [Cnw] row per split here
   // (null: not wanted); wgrad_reduce_kernel sums the rows.  Replaces two column-sum launches per layer.
   float* bslab;
+  int nsplit;
+};
+
+// Several weight-gradient problems of ONE geometry in one launch (blockIdx.y = problem): the 33 residual convs
+// of the SRGAN generator are 0.68 GFLOP each -- alone, such a problem is all pipeline fill and slab reduction
+// (19 + 5 us for 4.3 us of matrix work) -- and nothing downstream waits for a weight gradient before the
+// optimiser, so the host collects them during the backward pass and issues them together: long loops, every CU
+// holding several workgroups, one reduction.  Problems may also be SEGMENTS of one gradient (the discriminator's
+// real and fake passes): `per_out` consecutive problems are summed into one output.
+constexpr int WG_MAXP = 72;
+struct WMulti {
+  WArgs a;
+  const float* x[WG_MAXP];
+  const float* dy[WG_MAXP];
+};
+struct WReduce {
+  float* dw[WG_MAXP];
+  float* db[WG_MAXP];  // entries may be null
 };
 
 // PR = 1: bf16 products (the autocast mode).  The contraction runs over pixels, so an MFMA operand is eight
@@ -626,7 +644,9 @@ struct WArgs {
 // to bf16 and stores them interleaved -- one 32-bit word per (row pair, column) -- so that a lane collects
 // its eight rows as four words; two v_mfma_f32_32x32x16_bf16 per chunk replace sixteen fp32 MFMAs.
 template <int PR>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const WMulti mp) {
+  const WArgs& a = mp.a;
+  const int prob = blockIdx.y;
   constexpr int LROWS = PR ? 16 : 32;  // LDS rows per chunk (row pairs for bf16)
   __shared__ __attribute__((aligned(16))) float sD[2][LROWS * 64];
   __shared__ __attribute__((aligned(16))) float sX[2][LROWS * 64];
@@ -634,7 +654,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
   const int ntile = srx_uniform(blockIdx.x / a.ktiles), kt = blockIdx.x - ntile * a.ktiles;
   const int k0 = kt * 64, n0 = ntile * 64;
   const int q = tid & 15, r0 = tid >> 4;
-  const __amdgpu_buffer_rsrc_t rx_ = srx_rsrc(a.in, a.in_bytes), rd_ = srx_rsrc(a.dy, a.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx_ = srx_rsrc(mp.x[prob], a.in_bytes), rd_ = srx_rsrc(mp.dy[prob], a.dy_bytes);
 
   // this thread's fixed k (A gather) and fixed dy column
   const int k = k0 + 4 * q;
@@ -774,7 +794,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
     swrite(0, rd0, rx0);
     __syncthreads();
   }
-  float* slab = a.slab + (size_t)blockIdx.z * a.Cnw * a.Kw;
+  const size_t slab_id = (size_t)prob * a.nsplit + blockIdx.z;
+  float* slab = a.slab + slab_id * a.Cnw * a.Kw;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -788,19 +809,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs a) {
       f32x4 t = red[tid];
 #pragma unroll
       for (int r = 1; r < 16; ++r) t += red[r * 16 + tid];
-      *reinterpret_cast<f32x4*>(a.bslab + (size_t)blockIdx.z * a.Cnw + n0 + 4 * tid) = t;
+      *reinterpret_cast<f32x4*>(a.bslab + slab_id * a.Cnw + n0 + 4 * tid) = t;
     }
   }
 }
 
-// slab sums -> OIHW gradient
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int Cnw, int Kw, int K, int Ck,
-                                    int Cout, int Cin, int KH, int KW, int shuffle_cps, float* __restrict__ dw,
-                                    int accumulate, const float* __restrict__ bslab, float* __restrict__ db) {
+// slab sums -> OIHW gradient.  blockIdx.y = output; its `nslab` slabs (row splits x segments) are consecutive.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab_all, int nslab, int Cnw, int Kw, int K, int Ck,
+                                    int Cout, int Cin, int KH, int KW, int shuffle_cps, const WReduce outs,
+                                    int accumulate, const float* __restrict__ bslab_all) {
+  const int o = blockIdx.y;
+  float* __restrict__ dw = outs.dw[o];
+  float* __restrict__ db = outs.db[o];
+  const float* __restrict__ slab = slab_all + (size_t)o * nslab * Cnw * Kw;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (db && idx < Cout) {  // bias gradient: the row splits' column sums (the grid has >= Cout threads)
+  if (db && idx < Cout) {  // bias gradient: the slabs' column sums (the grid has >= Cout threads)
+    const float* __restrict__ bslab = bslab_all + (size_t)o * nslab * Cnw;
     float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += bslab[(size_t)z * Cnw + idx];
+    for (int z = 0; z < nslab; ++z) s += bslab[(size_t)z * Cnw + idx];
     db[idx] = accumulate ? db[idx] + s : s;
   }
   if (idx >= (int64_t)Cout * K) return;
@@ -811,19 +837,19 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, 
   const size_t zs = (size_t)Cnw * Kw;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int z = 0;
-  for (; z + 3 < nsplit; z += 4) {
+  for (; z + 3 < nslab; z += 4) {
     s0 += sp[(size_t)z * zs];
     s1 += sp[(size_t)(z + 1) * zs];
     s2 += sp[(size_t)(z + 2) * zs];
     s3 += sp[(size_t)(z + 3) * zs];
   }
-  for (; z < nsplit; ++z) s0 += sp[(size_t)z * zs];
+  for (; z < nslab; ++z) s0 += sp[(size_t)z * zs];
   const float s = (s0 + s1) + (s2 + s3);
   int co = np;
   if (shuffle_cps) { const int ij = np / shuffle_cps, cc = np - ij * shuffle_cps; co = cc * 4 + ij; }
   const int kh = tap / KW, kw = tap - kh * KW;
-  float* o = dw + (((size_t)co * Cin + ci) * KH + kh) * KW + kw;
-  *o = accumulate ? *o + s : s;
+  float* op = dw + (((size_t)co * Cin + ci) * KH + kh) * KW + kw;
+  *op = accumulate ? *op + s : s;
 }
 
 // ---------------------------------------------------------------------------
@@ -1259,14 +1285,40 @@ extern "C" size_t srx_conv2d_bwd_data_ws_floats(const srx_conv2d_t* d) {
   return plan_ws_floats(bwd_plan(d, cls[0]));
 }
 
-extern "C" size_t srx_conv2d_bwd_weight_ws_floats(const srx_conv2d_t* d) {
-  if (check_desc(d)) return 0;
-  if (srx_thin_wgrad_applicable(d))  // + the column-sum scratch of an optional bias gradient
+// Row splits of a (group of) weight-gradient problem(s): the slabs cost a write + a read each, a workgroup alone on
+// its CU runs latency-bound (~1 us per 32-row chunk, ~0.65 us with four co-resident), and workgroup counts just
+// above a multiple of the CU count leave a nearly empty last round.  Calibrated on the SRGAN layer shapes
+// (tools/bench_kernels.py --graph); SRX_WGRAD_NSPLIT overrides for experiments.
+static int wgrad_nsplit(int M, int64_t tiles, int nprob, int Cnw, int Kw) {
+  static int cus = 0;
+  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
+  const int max_by_rows = (int)srx_cdiv(M, 128);  // at least 128 rows per split
+  int nsplit = 1;
+  float best_cost = 1e30f;
+  for (int ns = 1; ns <= 64 && ns <= max_by_rows; ++ns) {
+    const int rps = (int)srx_roundup(srx_cdiv(M, ns), 32);
+    if ((int)srx_cdiv(M, rps) != ns) continue;  // not reachable after rounding to whole chunks
+    const int L = (int)srx_cdiv(tiles * nprob * ns, cus);
+    const float hide = L >= 4 ? 0.65f : (L == 3 ? 0.7f : (L == 2 ? 0.8f : 1.0f));
+    const float cost = 1.07f * L * (rps / 32 + 6) * hide + (float)nprob * ns * Cnw * Kw * 8.0f / 3.0e6f;
+    if (cost < best_cost) { best_cost = cost; nsplit = ns; }
+  }
+  if (const char* e = getenv("SRX_WGRAD_NSPLIT")) { const int v = atoi(e); if (v > 0 && v <= 64 && v <= max_by_rows) nsplit = v; }
+  const int rps = (int)srx_roundup(srx_cdiv(M, nsplit), 32);
+  return (int)srx_cdiv(M, rps);
+}
+
+extern "C" size_t srx_conv2d_bwd_weight_multi_ws_floats(const srx_conv2d_t* d, int nprob) {
+  if (check_desc(d) || nprob < 1 || nprob > WG_MAXP) return 0;
+  if (srx_thin_wgrad_applicable(d))  // (one call per problem) + the column-sum scratch of an optional bias gradient
     return srx_thin_wgrad_ws_floats(d) + srx_colsum_ws_floats((int64_t)d->N * d->H * d->W, d->Cout);
   const Geo g = fwd_geo(d);
   const size_t Cnw = (size_t)srx_roundup(d->Cout, 64), Kw = (size_t)srx_roundup(g.K, 64);
-  return Cnw * (Kw + 1) * 64;  // up to 64 row splits (+ one bias row each)
+  const int ns = wgrad_nsplit(d->N * g.Ho * g.Wo, (int64_t)(Kw / 64) * (Cnw / 64), nprob, (int)Cnw, (int)Kw);
+  return Cnw * (Kw + 1) * (size_t)ns * nprob;  // one slab (+ one bias row) per problem and row split
 }
+
+extern "C" size_t srx_conv2d_bwd_weight_ws_floats(const srx_conv2d_t* d) { return srx_conv2d_bwd_weight_multi_ws_floats(d, 1); }
 
 extern "C" int srx_conv2d_stat_rows(const srx_conv2d_t* d) {
   if (check_desc(d)) return 0;
@@ -1579,23 +1631,39 @@ extern "C" int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, 
                           size_t ws_floats, void* stream);
 extern "C" size_t srx_colsum_ws_floats(int64_t M, int C);
 
-extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, const float* dy, float* dw, int accumulate,
-                                     float* db, float* ws, size_t ws_floats, void* stream) {
+extern "C" int srx_conv2d_bwd_weight_multi(const srx_conv2d_t* d, int nprob, int per_out, const float* const* xs,
+                                           const float* const* dys, float* const* dws, int accumulate, float* const* dbs,
+                                           float* ws, size_t ws_floats, void* stream) {
   if (int rc = check_desc(d)) return rc;
-  SRX_REQUIRE(x && dy && dw && ws, "conv2d_bwd_weight: null pointer");
-  if (db && d->shuffle) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_weight: bias gradient of a PixelShuffle layer is not fused");
+  SRX_REQUIRE(nprob >= 1 && nprob <= WG_MAXP && per_out >= 1 && nprob % per_out == 0,
+              "conv2d_bwd_weight_multi: 1..%d problems, a whole number of outputs", WG_MAXP);
+  SRX_REQUIRE(xs && dys && dws && ws, "conv2d_bwd_weight: null pointer");
+  const int nout = nprob / per_out;
+  bool any_db = false;
+  for (int i = 0; i < nprob; ++i) SRX_REQUIRE(xs[i] && dys[i], "conv2d_bwd_weight: null tensor in problem %d", i);
+  for (int o = 0; o < nout; ++o) {
+    SRX_REQUIRE(dws[o], "conv2d_bwd_weight: null gradient pointer for output %d", o);
+    any_db |= dbs && dbs[o];
+  }
+  if (any_db && d->shuffle) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_weight: bias gradient of a PixelShuffle layer is not fused");
   hipStream_t st = srx_stream(stream);
-  if (srx_thin_wgrad_applicable(d)) {
+  if (srx_thin_wgrad_applicable(d)) {  // 3-channel layers: their own kernel, one problem at a time
     const size_t thin_ws = srx_thin_wgrad_ws_floats(d);
-    if (int rc = srx_thin_wgrad(d, x, dy, dw, accumulate, ws, ws_floats, st)) return rc;
-    if (!db) return SRX_OK;
     const int64_t m = (int64_t)d->N * d->H * d->W;  // thin layers are stride 1, same size
-    SRX_REQUIRE(ws_floats >= thin_ws + srx_colsum_ws_floats(m, d->Cout), "conv2d_bwd_weight: workspace too small");
-    return srx_colsum(dy, db, m, d->Cout, d->Cout_s, accumulate, ws + thin_ws, ws_floats - thin_ws, stream);
+    for (int i = 0; i < nprob; ++i) {
+      const int o = i / per_out;
+      const int acc = accumulate || (i % per_out) > 0;
+      if (int rc = srx_thin_wgrad(d, xs[i], dys[i], dws[o], acc, ws, ws_floats, st)) return rc;
+      if (!(dbs && dbs[o])) continue;
+      SRX_REQUIRE(ws_floats >= thin_ws + srx_colsum_ws_floats(m, d->Cout), "conv2d_bwd_weight: workspace too small");
+      if (int rc = srx_colsum(dys[i], dbs[o], m, d->Cout, d->Cout_s, acc, ws + thin_ws, ws_floats - thin_ws, stream)) return rc;
+    }
+    return SRX_OK;
   }
   const Geo g = fwd_geo(d);
-  WArgs a{};
-  a.in = x; a.dy = dy; a.slab = ws;
+  WMulti mp{};
+  WArgs& a = mp.a;
+  a.in = xs[0]; a.dy = dys[0]; a.slab = ws;
   a.N = d->N; a.Hi = d->H; a.Wi = d->W; a.Ci = d->Cin_s;
   a.Hm = g.Ho; a.Wm = g.Wo; a.HmWm = g.Ho * g.Wo; a.M = d->N * g.Ho * g.Wo;
   a.inv_HmWm = 1.0f / (float)a.HmWm; a.inv_Wm = 1.0f / (float)g.Wo;
@@ -1626,40 +1694,35 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
     }
   }
   const int ntiles = a.Cnw / 64;
-  static int cus = 0;
-  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
   const int64_t tiles = (int64_t)a.ktiles * ntiles;
-  // Row splits: the slabs cost a write + a read each, a workgroup alone on its CU runs latency-bound
-  // (~1 us per 32-row chunk, ~0.65 us with four co-resident), and workgroup counts just above a
-  // multiple of the CU count leave a nearly empty last round.  Calibrated on the SRGAN layer shapes
-  // (tools/bench_kernels.py --graph); SRX_WGRAD_NSPLIT overrides for experiments.
-  const int max_by_rows = (int)srx_cdiv(a.M, 128);  // at least 128 rows per split
-  int nsplit = 1;
-  float best_cost = 1e30f;
-  for (int ns = 1; ns <= 64 && ns <= max_by_rows; ++ns) {
-    const int rps = (int)srx_roundup(srx_cdiv(a.M, ns), 32);
-    if ((int)srx_cdiv(a.M, rps) != ns) continue;  // not reachable after rounding to whole chunks
-    const int L = (int)srx_cdiv(tiles * ns, cus);
-    const float hide = L >= 4 ? 0.65f : (L == 3 ? 0.7f : (L == 2 ? 0.8f : 1.0f));
-    const float cost = 1.07f * L * (rps / 32 + 6) * hide + (float)ns * a.Cnw * a.Kw * 8.0f / 3.0e6f;
-    if (cost < best_cost) { best_cost = cost; nsplit = ns; }
-  }
-  if (const char* e = getenv("SRX_WGRAD_NSPLIT")) { const int v = atoi(e); if (v > 0 && v <= 64) nsplit = v; }
+  const int nsplit = wgrad_nsplit(a.M, tiles, nprob, a.Cnw, a.Kw);
   a.rows_per_split = (int)srx_roundup(srx_cdiv(a.M, nsplit), 32);
-  nsplit = (int)srx_cdiv(a.M, a.rows_per_split);
-  const size_t need = (size_t)nsplit * a.Cnw * a.Kw + (db ? (size_t)nsplit * a.Cnw : 0);
+  a.nsplit = nsplit;
+  const size_t nslabs = (size_t)nsplit * nprob;
+  const size_t need = nslabs * a.Cnw * a.Kw + (any_db ? nslabs * a.Cnw : 0);
   if (need > ws_floats) SRX_FAIL(SRX_E_WORKSPACE, "conv2d_bwd_weight: workspace %zu < %zu floats", ws_floats, need);
-  a.bslab = db ? ws + (size_t)nsplit * a.Cnw * a.Kw : nullptr;
-  dim3 grid((unsigned)tiles, 1, nsplit);
-  const double wfl = 2.0 * a.M * d->Cout * a.K;
+  a.bslab = any_db ? ws + nslabs * a.Cnw * a.Kw : nullptr;
+  WReduce outs{};
+  for (int i = 0; i < nprob; ++i) { mp.x[i] = xs[i]; mp.dy[i] = dys[i]; }
+  for (int o = 0; o < nout; ++o) { outs.dw[o] = dws[o]; outs.db[o] = dbs ? dbs[o] : nullptr; }
+  dim3 grid((unsigned)tiles, (unsigned)nprob, nsplit);
+  const double wfl = 2.0 * a.M * d->Cout * a.K * nprob;
   char nm[112];
-  if (srx_prof_on()) snprintf(nm, sizeof(nm), "wgrad_kernel<%d> MxNxK=%dx%dx%d", d->precision ? 1 : 0, a.M, d->Cout, a.K);
-  if (d->precision) SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<1>, grid, dim3(256), 0, st, a);
-  else SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<0>, grid, dim3(256), 0, st, a);
+  if (srx_prof_on())
+    snprintf(nm, sizeof(nm), "wgrad_kernel<%d> MxNxK=%dx%dx%d x%d", d->precision ? 1 : 0, a.M, d->Cout, a.K, nprob);
+  if (d->precision) SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<1>, grid, dim3(256), 0, st, mp);
+  else SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<0>, grid, dim3(256), 0, st, mp);
   SRX_CHECK_LAUNCH("wgrad_kernel");
   const int64_t n = (int64_t)d->Cout * g.K;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, st, ws, nsplit, a.Cnw, a.Kw,
-                     g.K, g.Ck, d->Cout, d->Cin, d->KH, d->KW, g.cps, dw, accumulate, a.bslab, db);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)srx_cdiv(n, 256), (unsigned)nout), dim3(256), 0, st, ws,
+                     nsplit * per_out, a.Cnw, a.Kw, g.K, g.Ck, d->Cout, d->Cin, d->KH, d->KW, g.cps, outs, accumulate,
+                     a.bslab);
   SRX_CHECK_LAUNCH("wgrad_reduce_kernel");
   return SRX_OK;
+}
+
+extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, const float* dy, float* dw, int accumulate,
+                                     float* db, float* ws, size_t ws_floats, void* stream) {
+  SRX_REQUIRE(x && dy && dw && ws, "conv2d_bwd_weight: null pointer");
+  return srx_conv2d_bwd_weight_multi(d, 1, 1, &x, &dy, &dw, accumulate, db ? &db : nullptr, ws, ws_floats, stream);
 }

@@ -46,7 +46,7 @@ class ESRGANTrainer(SRGANTrainer):
         d_real = self.bce_loss(real_output, 1.0, shift=F.mean(fake_output))      # :451
         d_fake = self.bce_loss(fake_output, 0.0, shift=F.mean(real_output))      # :452
         disc_loss = F.axpby(d_real, d_fake, 0.5, 0.5)                            # :453
-        disc_loss.backward()                                                     # :455
+        self._backward(disc_loss)                                                # :455
         self._losses['gan/disc-loss'] = disc_loss.detach()
 
     def _phase_content(self) -> None:
@@ -69,7 +69,7 @@ class ESRGANTrainer(SRGANTrainer):
             fake_output = self.discriminator(self._super_res)                    # :464
         adversarial = self.bce_loss(fake_output, 1.0, shift=real_mean)           # :468
         gen_loss = F.axpby(self._content, adversarial, 1.0, 0.005)               # :469
-        gen_loss.backward()                                                      # :480
+        self._backward(gen_loss)                                                 # :480
         self._losses['gan/adversarial-loss'] = adversarial.detach()
         self._losses['gan/train-loss'] = gen_loss.detach()
         self._super_res = self._content = None

@@ -8,6 +8,7 @@ fp32 tensors ``[N, H, W, C_s]``; parameters keep the reference's layouts.
 Nothing in this module falls back to CPU or to ATen kernels for the hot ops:
 non-CUDA inputs raise.
 """
+import contextlib
 from typing import Optional, Tuple
 
 import torch
@@ -44,6 +45,69 @@ cut_hook = [None]
 def cut_point(name: str, t: Tensor) -> Tensor:
     hook = cut_hook[0]
     return t if hook is None else hook(name, t)
+
+
+class WeightGradQueue:
+    """Weight-gradient work of one backward pass, collected and issued together.
+
+    Autograd reaches a conv's weight gradient right after its data gradient, one layer at a time, but nothing
+    reads a weight gradient before the optimiser.  For the generator's 33 identical 3x3 64->64 convs a single
+    problem is 0.68 GFLOP -- launched alone it is mostly pipeline fill plus a slab reduction -- so, while a queue
+    is installed (``deferred_weight_grads``), the conv Functions only record ``(descriptor, x, dy, sink)`` and the
+    queue hands every group of equal-geometry problems to ``srx_conv2d_bwd_weight_multi`` when it is flushed:
+    one launch with long loops instead of 33 short ones.  Problems that share a sink (the discriminator's real
+    and fake passes) become segments of one gradient.  Only gradients that accumulate straight into the flat
+    ``.grad`` buffers are deferred; the queued tensors stay alive until the flush.
+    """
+    MAXP = 72  # WG_MAXP of gconv.hip
+
+    def __init__(self):
+        self.groups = {}
+
+    def add(self, d: Conv2dDesc, x_ptr: int, dy_ptr: int, sink_ptr: int, bias_ptr, keep) -> None:
+        key = tuple(getattr(d, f) for f, _ in Conv2dDesc._fields_)
+        self.groups.setdefault(key, [d, []])[1].append((x_ptr, dy_ptr, sink_ptr, bias_ptr or 0, keep))
+
+    def flush(self) -> None:
+        groups, self.groups = self.groups, {}
+        if not groups:
+            return
+        L, s = _lib.lib(), _stream()
+        for d, items in groups.values():
+            by_sink = {}
+            for it in items:
+                by_sink.setdefault((it[2], it[3]), []).append(it)
+            by_count = {}
+            for sink, its in by_sink.items():  # outputs with the same number of segments go into one launch
+                by_count.setdefault(len(its), []).append((sink, its))
+            dref = C.byref(d)
+            for per_out, outs in by_count.items():
+                step = max(1, self.MAXP // per_out)
+                for i in range(0, len(outs), step):
+                    part = outs[i:i + step]
+                    probs = [it for _, its in part for it in its]
+                    n = len(probs)
+                    arr = lambda vals: (C.c_void_p * len(vals))(*vals)  # noqa: E731
+                    xs, dys = arr([p[0] for p in probs]), arr([p[1] for p in probs])
+                    dws, dbs = arr([sk[0] for sk, _ in part]), arr([sk[1] or None for sk, _ in part])
+                    nws = L.srx_conv2d_bwd_weight_multi_ws_floats(dref, n)
+                    ws = torch.empty(max(int(nws), 4), dtype=torch.float32, device=probs[0][4][0].device)
+                    call('srx_conv2d_bwd_weight_multi', dref, n, per_out, xs, dys, dws, 1, dbs, _p(ws), nws, s)
+
+
+wgrad_queue = [None]
+
+
+@contextlib.contextmanager
+def deferred_weight_grads():
+    """Collect the conv weight gradients of the backward passes run inside and issue them on exit."""
+    q, old = WeightGradQueue(), wgrad_queue[0]
+    wgrad_queue[0] = q
+    try:
+        yield q
+    finally:
+        wgrad_queue[0] = old
+    q.flush()
 
 
 def _stream() -> int:
@@ -302,10 +366,14 @@ class _Conv2d(Function):
                         db = torch.empty(st.cout, dtype=torch.float32, device=x.device)
                     bptr = _p(db if bsink is None else bsink)
                     bias_done = True
-            nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
-            ws = _ws(nws, x)
-            call('srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw if sink is None else sink),
-                 0 if sink is None else 1, bptr, _p(ws), nws, s)
+            queue = wgrad_queue[0]
+            if queue is not None and sink is not None:
+                queue.add(d, _p(x), _p(dy), _p(sink), bptr, (x, dy))
+            else:
+                nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
+                ws = _ws(nws, x)
+                call('srx_conv2d_bwd_weight', dref, _p(x), _p(dy), _p(dw if sink is None else sink),
+                     0 if sink is None else 1, bptr, _p(ws), nws, s)
         if ctx.has_bias and ctx.needs_input_grad[2] and not bias_done:
             sink = None if st.shuffle else _sink(bparam)
             if sink is not None:
@@ -906,9 +974,13 @@ class _DenseBlock(Function):
                             grads[2 * k + 1] = torch.empty(st.cout, dtype=torch.float32, device=dev)
                         bptr = _p(grads[2 * k + 1] if bsink is None else bsink)
                         bias_done = True
-                nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
-                call('srx_conv2d_bwd_weight', dref, _p(buf), gk, _p(dw if sink is None else sink),
-                     0 if sink is None else 1, bptr, _p(_ws(nws, dy)), nws, s)
+                queue = wgrad_queue[0]
+                if queue is not None and sink is not None:
+                    queue.add(d, _p(buf), gk, _p(sink), bptr, (buf, gbuf, g5))
+                else:
+                    nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
+                    call('srx_conv2d_bwd_weight', dref, _p(buf), gk, _p(dw if sink is None else sink),
+                         0 if sink is None else 1, bptr, _p(_ws(nws, dy)), nws, s)
                 grads[2 * k] = dw
             if bparam is not None and ctx.needs_input_grad[5 + 2 * k] and not bias_done:
                 sink = _sink(bparam)

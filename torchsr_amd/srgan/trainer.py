@@ -286,6 +286,16 @@ class SRGANTrainer:
         buf.copy_(value, non_blocking=True)
         return buf
 
+    def _backward(self, loss: Tensor) -> None:
+        """``loss.backward()`` with the conv weight gradients of the pass collected and issued together at its end
+        (``functional.WeightGradQueue``): they are off the critical path until the optimiser step."""
+        with F.deferred_weight_grads():
+            loss.backward()
+
+    def _resume(self, cut: str) -> None:
+        with F.deferred_weight_grads():
+            self._cuts.resume(cut)
+
     # ------------------------------------------------------------------ pre-training
     def _pretrain_body(self) -> None:
         """Loop body of ``_pretrain``, trainer.py:380-386.  The autocast region is the generator forward + MSE
@@ -294,7 +304,7 @@ class SRGANTrainer:
         self.psnr_optimizer.zero_grad()
         super_res = self.generator(self._static['low_res'])
         loss = self.pixel_loss(super_res, self._static['high_res'])
-        loss.backward()
+        self._backward(loss)
         self._losses['psnr/train-loss'] = loss.detach()
 
     def pretrain_step(self, low_res: Tensor, high_res: Tensor) -> Tensor:
@@ -309,7 +319,7 @@ class SRGANTrainer:
                 self._cuts.names = {'g.tail'}
                 self._exec('psnr.head', self._pretrain_body)           # stops at the generator's 'g.tail' cut
                 self.gen_sync.launch(1)                                # conv_layers / conv3 gradients: on the wire
-                self._exec('psnr.body', lambda: self._cuts.resume('g.tail'))  # residual tower backward
+                self._exec('psnr.body', lambda: self._resume('g.tail'))       # residual tower backward
                 self.gen_sync.launch(0)
                 self.gen_sync.wait()
                 self._exec('psnr.opt', self.psnr_optimizer.step)
@@ -362,11 +372,11 @@ class SRGANTrainer:
         d_real = self.bce_loss(self.discriminator(high_res), 1.0)            # :446
         d_fake = self.bce_loss(self.discriminator(self._super_res.detach()), 0.0)  # :447
         disc_loss = F.axpby(d_real, d_fake, 1.0, 1.0)                        # :448
-        disc_loss.backward()                                                 # :450
+        self._backward(disc_loss)                                            # :450
         self._losses['gan/disc-loss'] = disc_loss.detach()
 
     def _phase_disc_body(self) -> None:
-        self._cuts.resume('d.head')
+        self._resume('d.head')
 
     def _phase_content(self) -> None:
         """trainer.py:453-455: VGG19 perceptual loss (does not need the updated discriminator)."""
@@ -380,14 +390,14 @@ class SRGANTrainer:
         with no_weight_grad():  # C5: D's weight gradients are never consumed here
             adversarial = self.bce_loss(self.discriminator(self._super_res), 1.0)  # :456
         gen_loss = F.axpby(self._content, adversarial, 1.0, 0.001)           # :457
-        gen_loss.backward()                                                  # :468
+        self._backward(gen_loss)                                             # :468
         self._losses['gan/content-loss'] = self._content.detach()
         self._losses['gan/adversarial-loss'] = adversarial.detach()
         self._losses['gan/train-loss'] = gen_loss.detach()
         self._super_res = self._content = None
 
     def _phase_gen_body(self) -> None:
-        self._cuts.resume('g.tail')
+        self._resume('g.tail')
 
     def _gan_all(self) -> None:
         self._phase_disc()
