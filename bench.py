@@ -166,6 +166,11 @@ def roofline_pass(trainer, lr, hr, reps=2):
             gsum[1] += fl.value
             gsum[2] += 1
     total_ms = sum(v[0] for v in kernels.values())
+    if os.environ.get('SRX_BENCH_SHAPES'):  # developer aid: the full (kernel, shape) table
+        with open(os.environ['SRX_BENCH_SHAPES'], 'w') as f:
+            for k, v in sorted(pairs.items(), key=lambda kv: -kv[1][0]):
+                f.write(f'{v[0] / reps * 1e3:9.1f} us/step {v[2] // reps:3d} launches {v[0] / v[2] * 1e3:8.1f} us each '
+                        f'{v[1] / (v[0] * 1e-3) / 1e12:6.1f} TF/s  {k}\n')
     full, (ms, fl, cnt) = max(pairs.items(), key=lambda kv: kv[1][0])
     kname, _, shape = full.partition(' MxNxK=')
     achieved = fl / (ms * 1e-3) / 1e12

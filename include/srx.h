@@ -142,6 +142,12 @@ int srx_conv2d_fwd_residual(const srx_conv2d_t* d, const float* x, const float* 
  * place of the torch.cat adjoint (esrgan/residual.py:81-85). */
 int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
                         int accumulate, float* ws, size_t ws_floats, void* stream);
+/* The same followed by the backward of the activation that PRODUCED this conv's input: dx = conv_transpose(dy, W) *
+ * (x > 0 ? 1 : slope), x = that activation's output = the conv's saved input (laid out like dx).  In the VGG19
+ * feature stack (srgan/loss.py:30-31,52: conv, ReLU, conv, ReLU, ...) every ReLU backward then rides in the
+ * epilogue of the data gradient above it instead of being a pass of its own.  Stride-1 layers, generic kernel. */
+int srx_conv2d_bwd_data_act(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, const float* x, float slope,
+                            float* dx, float* ws, size_t ws_floats, void* stream);
 /* dw (OIHW) = autograd of nn.Conv2d wrt its weight; accumulate != 0 adds into dw (a .grad buffer)
  * instead of overwriting it.  db (may be NULL; not for shuffle layers) receives the bias gradient
  * sum_m dy[m][co] under the same flag: the kernel stages every dy row anyway.  The same flag exists on srx_colsum, srx_linear_bwd_weight,
@@ -250,6 +256,8 @@ int srx_bn_act_bwd(const float* dout, const float* y, const float* mean, const f
 /* nn.MaxPool2d(2,2) of VGG19 (torchvision cfg 'E', srgan/loss.py:30-31); H, W even */
 int srx_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int srx_maxpool2x2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, void* stream);
+/* max-pool backward followed by the backward of the ReLU that produced x (conv, ReLU, MaxPool in cfg 'E') */
+int srx_maxpool2x2_relu_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, void* stream);
 
 /* ------------------------------------------------------------------ linear */
 /* nn.Linear (srgan/discriminator.py:65,67; esrgan/discriminator.py:73,75).

@@ -87,8 +87,11 @@ def assert_digests(keys, sd, digests, what):
             # rounding noise, and Adam turns noise into +-lr steps.  Nothing to pin.
             continue
         d = tensor_digest(sd[str(k)].cpu())
-        assert abs(d[0] - dg[0]) <= 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6, (what, k)
-        assert abs(d[1] - dg[1]) <= 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6, (what, k)
+        # digests are sums over the tensor.  Every element moves by ~lr = 1e-4 per Adam step, and the few whose
+        # gradient sits at the fp32 noise floor move in a direction that differs between any two fp32
+        # implementations (the elementwise test below allows 0.2 % of a tensor to do so): each costs 2e-4 of a sum
+        slack = 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6 + max(2, 2e-3 * sd[str(k)].numel()) * 2.1e-4
+        assert abs(d[0] - dg[0]) <= slack and abs(d[1] - dg[1]) <= slack, (what, k, d[:2], dg[:2])
 
 
 def test_esrgan_gan_steps_vs_reference_trainer(dev):
@@ -106,6 +109,35 @@ def test_esrgan_gan_steps_vs_reference_trainer(dev):
         assert abs(got[4] - gold['gan_ref_gen_losses'][step]) <= TOL * gold['gan_ref_gen_losses'][step]
         assert_digests(gold['gs_keys'], t.generator.state_dict(), gold['gan_g_digest'][step], f'G step {step}')
         assert_digests(gold['ds_keys'], t.discriminator.state_dict(), gold['gan_d_digest'][step], f'D step {step}')
+
+
+def test_esrgan_first_step_matches_oracle_elementwise(dev):
+    """One ESRGAN GAN step (23 RRDBs, 128x128 crops, batch 2): every parameter of G and D within 2e-6 absolute of
+    the CPU oracle's (updates are ~1e-4: this pins the update direction of every element whose gradient is above
+    the noise floor; up to 0.2 % of a tensor may sit below it)."""
+    from oracle import esrgan as OE
+    gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
+    t = make_trainer(dev)
+    vgg_sd = {k: v.detach().cpu().clone() for k, v in t.vgg_loss.features.state_dict().items()}
+    orc = OE.ESRGANStepOracle(step_state(t.generator.state_dict(), 'esrgan.G'), step_state(t.discriminator.state_dict(), 'esrgan.D'),
+                              vgg_sd)
+    lr, hr = torch.from_numpy(gold['low_res']), torch.from_numpy(gold['high_res'])
+    orc.gan_step(lr, hr)
+    t.gan_step(lr.to(dev), hr.to(dev))
+    for name, mod, ref in (('G', t.generator, orc.g), ('D', t.discriminator, orc.d)):
+        for k, v in mod.state_dict().items():
+            if not v.is_floating_point():
+                assert int(v) == int(ref[k]), (name, k)
+                continue
+            if (name, k) == ('D', 'classifier.2.bias'):
+                continue  # exact gradient 0 (see assert_digests): Adam steps on rounding noise
+            diff = (v.cpu() - ref[k].detach()).abs()
+            if 'running_' in k:
+                assert (diff.max() / ref[k].detach().abs().max().clamp_min(1e-6)).item() < 1e-3, (name, k)
+            else:
+                n_bad = int((diff > 2e-6).sum())
+                assert n_bad <= max(2, int(2e-3 * diff.numel())), (name, k, n_bad, diff.max().item())
+                assert diff.max().item() <= 2.1e-4, (name, k, diff.max().item())
 
 
 def test_esrgan_config4_geometry_step_vs_reference_trainer(dev):

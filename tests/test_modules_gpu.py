@@ -106,6 +106,31 @@ def test_vgg_loss_vs_golden(dev):
     assert rel(src.grad, gold['dsrc']) < TOL
 
 
+def test_vgg_fused_stack_equals_layer_by_layer(dev):
+    """VGGLoss.forward (one autograd node: source + target as one batch, ReLU backwards folded into the data
+    gradients and the pool backwards) against the same layers run one by one through their own autograd nodes,
+    at the bench's batch-16 96x96 geometry (tile plans with and without K-split tails) and at an odd small one."""
+    from torchsr_amd import functional as F
+    from torchsr_amd.srgan.loss import VGGLoss
+    vgg = VGGLoss(weights='random').to(dev)
+    for shape, seed in (((16, 3, 96, 96), 1), ((3, 3, 32, 48), 2)):
+        g = torch.Generator().manual_seed(seed)
+        src, tgt = torch.rand(shape, generator=g).to(dev), torch.rand(shape, generator=g).to(dev)
+        a = src.clone().requires_grad_(True)
+        loss_a = vgg(a, tgt)
+        loss_a.backward()
+        b = src.clone().requires_grad_(True)
+        loss_b = F.l1_loss(vgg.features_nhwc(F.to_nhwc(b, 4)), vgg.target_features(tgt))
+        loss_b.backward()
+        assert abs(loss_a.item() - loss_b.item()) <= 1e-6 * abs(loss_b.item()), shape
+        assert rel(a.grad, b.grad) < 1e-5, shape
+        # a precomputed target term takes the source-only path
+        c = src.clone().requires_grad_(True)
+        loss_c = vgg(c, target_features=vgg.target_features(tgt))
+        loss_c.backward()
+        assert abs(loss_c.item() - loss_b.item()) <= 1e-6 * abs(loss_b.item()) and rel(c.grad, b.grad) < 1e-5
+
+
 @pytest.mark.parametrize('seed', [5, 6, 7])
 def test_generator_vs_oracle_fresh_inputs(dev, seed):
     """Default (seeded) init + fresh random input, batch 3, non-square 13x9: output AND gradients.

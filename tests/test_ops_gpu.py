@@ -255,6 +255,48 @@ def test_deferred_weight_grads_equal_immediate(dev):
     assert rel_err(flats[1].grad, flats[0].grad) < 1e-5
 
 
+@pytest.mark.parametrize('case', [(2, 24, 24, 64, 64), (16, 6, 6, 512, 512), (2, 12, 12, 128, 256), (1, 10, 14, 64, 128)])
+def test_dgrad_with_folded_activation_backward(dev, case):
+    """srx_conv2d_bwd_data_act: dx = conv_transpose(dy, W) * (x > 0 ? 1 : slope) in one kernel, against the two-step
+    form on the CPU (whole tiles, K-split tail tiles with their fix-up pass, the 144-row tiles' extra rows)."""
+    from torchsr_amd import _lib
+    from torchsr_amd.layers import Conv2d
+    n, h, w, cin, cout = case
+    torch.manual_seed(cin + h)
+    conv = Conv2d(cin, cout, 3, 1, 1, bias=False).to(dev)
+    x = rnd((n, cin, h, w), 1)                 # "activation output": about half of it <= 0
+    dy = rnd((n, cout, h, w), 2)
+    xg = nhwc(x).to(dev)
+    y = conv(xg)                               # packs the weights
+    st = conv._st
+    d = st.desc(n, h, w)
+    L = _lib.lib()
+    for slope in (0.0, 0.2):
+        want = torch.nn.grad.conv2d_input((n, cin, h, w), conv.weight.detach().cpu().double(), dy.double(), padding=1)
+        want = want * torch.where(x > 0, 1.0, slope).double()
+        dx = torch.empty_like(xg)
+        nws = L.srx_conv2d_bwd_data_ws_floats(C.byref(d))
+        ws = torch.empty(max(nws, 4), device=dev)
+        _lib.call('srx_conv2d_bwd_data_act', C.byref(d), nhwc(dy).to(dev).data_ptr(), st.wpk_bwd.data_ptr(), xg.data_ptr(),
+                  slope, dx.data_ptr(), ws.data_ptr(), nws, torch.cuda.current_stream().cuda_stream)
+        assert rel_err(nchw(dx.cpu(), cin), want.float()) < 2e-4, slope
+    del y
+
+
+def test_maxpool_relu_backward(dev):
+    from torchsr_amd import _lib
+    x = torch.relu(rnd((2, 8, 8, 8), 3)).to(dev)    # NHWC, a ReLU output: many exact zeros
+    dy = rnd((2, 4, 4, 8), 4).to(dev)
+    dx = torch.empty_like(x)
+    _lib.call('srx_maxpool2x2_relu_bwd', dy.data_ptr(), x.data_ptr(), dx.data_ptr(), 2, 8, 8, 8,
+              torch.cuda.current_stream().cuda_stream)
+    xc = x.cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    TF.max_pool2d(torch.relu(xc), 2).backward(dy.cpu().permute(0, 3, 1, 2))
+    # where a whole window is 0 ATen sends the gradient to its first element and ReLU's backward then drops it
+    want = (xc.grad * (xc.detach() > 0)).permute(0, 2, 3, 1)
+    assert torch.equal(dx.cpu(), want)
+
+
 def test_row_tile_plan(dev):
     """The SRGAN residual conv at the reference batch runs as 256 workgroups of 36 pixels (forward and
     data gradient); a layer the row tile does not cover falls back to the generic plan."""

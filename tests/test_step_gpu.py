@@ -44,10 +44,11 @@ def oracle_for(t):
 def assert_digests(keys, sd, digests, what):
     for k, dg in zip(keys, digests):
         d = tensor_digest(sd[k].cpu())
-        # every weight moves by ~lr = 1e-4 per Adam step; digests are sums over the tensor, so compare against
-        # the abs-sum scale
-        assert abs(d[0] - dg[0]) <= 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6, (what, k)
-        assert abs(d[1] - dg[1]) <= 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6, (what, k)
+        # digests are sums over the tensor.  Every element moves by ~lr = 1e-4 per Adam step, and the few whose
+        # gradient sits at the fp32 noise floor move in a direction that differs between any two fp32
+        # implementations (assert_elementwise allows 0.2 % of a tensor to do so): each costs 2e-4 of a sum
+        slack = 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6 + max(2, 2e-3 * sd[k].numel()) * 2.1e-4
+        assert abs(d[0] - dg[0]) <= slack and abs(d[1] - dg[1]) <= slack, (what, k, d[:2], dg[:2])
 
 
 def assert_elementwise(mod, ref, name):

@@ -239,7 +239,9 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
   }
 }
 
-// gradient goes to the first maximum in scan order, as ATen's max_pool2d does
+// gradient goes to the first maximum in scan order, as ATen's max_pool2d does.  RELU: x is the output of a ReLU,
+// whose backward (grad * (x > 0)) is applied on the way: a window whose maximum is 0 passes nothing.
+template <bool RELU>
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
                                    int N, int H, int W, int C) {
   const int Ho = H / 2, Wo = W / 2, cq = C / 4;
@@ -265,6 +267,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const float* __
       if (b[e] > m) { m = b[e]; idx = 1; }
       if (c[e] > m) { m = c[e]; idx = 2; }
       if (d[e] > m) { m = d[e]; idx = 3; }
+      if (RELU && !(m > 0.f)) idx = -1;
       ga[e] = idx == 0 ? g[e] : 0.f;
       gb[e] = idx == 1 ? g[e] : 0.f;
       gc[e] = idx == 2 ? g[e] : 0.f;
@@ -486,7 +489,17 @@ extern "C" int srx_maxpool2x2_bwd(const float* dy, const float* x, float* dx, in
                                   void* stream) {
   SRX_REQUIRE(dy && x && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool2x2_bwd: bad argument");
   SRX_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2x2_bwd: H, W must be even and C a multiple of 4");
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid((int64_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+  hipLaunchKernelGGL(maxpool_bwd_kernel<false>, dim3(stream_grid((int64_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                     srx_stream(stream), dy, x, dx, N, H, W, C);
+  SRX_CHECK_LAUNCH("maxpool_bwd_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_maxpool2x2_relu_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C,
+                                       void* stream) {
+  SRX_REQUIRE(dy && x && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool2x2_relu_bwd: bad argument");
+  SRX_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2x2_relu_bwd: H, W must be even and C a multiple of 4");
+  hipLaunchKernelGGL(maxpool_bwd_kernel<true>, dim3(stream_grid((int64_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
                      srx_stream(stream), dy, x, dx, N, H, W, C);
   SRX_CHECK_LAUNCH("maxpool_bwd_kernel");
   return SRX_OK;

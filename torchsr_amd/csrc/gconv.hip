@@ -52,6 +52,10 @@ struct GArgs {
   // conv, `x + conv(...)` in one kernel).  Linear outputs only.
   const float* add;
   float oscale;  // applied to act(acc + bias) before the addend (conv5 * 0.2 + x of the dense block); 1 otherwise
+  // add_is_mask != 0: `add` is not an addend but the OUTPUT of the activation that produced this conv's input
+  // (laid out like `out`): the data gradient is multiplied by that activation's derivative on its way out,
+  // v * (add[i] > 0 ? 1 : oscale) -- ReLU / LeakyReLU backward of the layer below without a pass of its own.
+  int add_is_mask;
 };
 
 
@@ -418,7 +422,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
 
-  auto store_tile = [&](auto linear, auto accum) {  // one copy per addressing / accumulate mode, chosen by ONE branch
+  auto store_tile = [&](auto linear, auto accum) {  // one copy per addressing / epilogue mode (0 plain, 1 add, 2 mask), chosen by ONE branch
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -435,19 +439,25 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
           csq[j] += vs * vs;
           v = v > 0.f ? v : v * a.slope;
           const unsigned off = (mok && cok[j]) ? rowoff + ocol[j] : 0xffffffffu;
-          if (decltype(accum)::value)
+          if (decltype(accum)::value == 1)
             v = v * a.oscale + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
+          if (decltype(accum)::value == 2)
+            v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0)) > 0.f ? v : v * a.oscale;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
         }
       }
     }
   };
-  if (a.add) {
-    if (a.linear_out) store_tile(std::true_type{}, std::true_type{});
-    else store_tile(std::false_type{}, std::true_type{});
+  using M0 = std::integral_constant<int, 0>; using M1 = std::integral_constant<int, 1>; using M2 = std::integral_constant<int, 2>;
+  if (a.add && a.add_is_mask) {
+    if (a.linear_out) store_tile(std::true_type{}, M2{});
+    else store_tile(std::false_type{}, M2{});
+  } else if (a.add) {
+    if (a.linear_out) store_tile(std::true_type{}, M1{});
+    else store_tile(std::false_type{}, M1{});
   } else {
-    if (a.linear_out) store_tile(std::true_type{}, std::false_type{});
-    else store_tile(std::false_type{}, std::false_type{});
+    if (a.linear_out) store_tile(std::true_type{}, M0{});
+    else store_tile(std::false_type{}, M0{});
   }
 
   float xs1 = 0.f, xs2 = 0.f;
@@ -473,7 +483,10 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       xs2 += vs * vs;
       v = v > 0.f ? v : v * a.slope;
       const unsigned off = (mok && xok) ? rowoff + 4u * (unsigned)oc : 0xffffffffu;
-      if (a.add) v = v * a.oscale + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
+      if (a.add) {
+        const float ld = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
+        v = a.add_is_mask ? (ld > 0.f ? v : v * a.oscale) : v * a.oscale + ld;
+      }
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
     }
   }
@@ -573,7 +586,15 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const GArgs a) {
       }
       if (col < a.Cs) {  // Cs is a multiple of 4
         f32x4* o = reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col);
-        if (a.add) v = v * a.oscale + *reinterpret_cast<const f32x4*>(a.add + (size_t)m * a.Co + col);
+        if (a.add) {
+          const f32x4 ld = *reinterpret_cast<const f32x4*>(a.add + (size_t)m * a.Co + col);
+          if (a.add_is_mask) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ld[e] > 0.f ? v[e] : v[e] * a.oscale;
+          } else {
+            v = v * a.oscale + ld;
+          }
+        }
         *o = v;
       }
     }
@@ -1278,11 +1299,11 @@ extern "C" size_t srx_conv2d_fwd_ws_floats(const srx_conv2d_t* d) {
 
 extern "C" size_t srx_conv2d_bwd_data_ws_floats(const srx_conv2d_t* d) {
   if (check_desc(d)) return 0;
-  if (d->stride != 1 || srx_rt36_applicable(d)) return 0;
+  if (d->stride != 1) return 0;
   BwdClass cls[16];
   size_t total;
   bwd_classes(d, cls, total);
-  return plan_ws_floats(bwd_plan(d, cls[0]));
+  return plan_ws_floats(bwd_plan(d, cls[0]));  // (also covers srx_conv2d_bwd_data_act, which never takes the row-tile path)
 }
 
 // Row splits of a (group of) weight-gradient problem(s): the slabs cost a write + a read each, a workgroup alone on
@@ -1565,20 +1586,23 @@ extern "C" int srx_conv2d_fwd_residual(const srx_conv2d_t* d, const float* x, co
   return conv_fwd_impl(d, x, wpk, bias, residual, out_scale, y, nullptr, ws, ws_floats, stream);
 }
 
-extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
-                                   int accumulate, float* ws, size_t ws_floats, void* stream) {
+static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx, int accumulate,
+                              const float* act_out, float act_slope, float* ws, size_t ws_floats, void* stream) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(dy && wpk_bwd && dx, "conv2d_bwd_data: null pointer");
   SRX_REQUIRE(d->stride <= 4, "conv2d_bwd_data: stride > 4 unsupported");
-  if (accumulate && (d->stride != 1 || srx_thin_dgrad_applicable(d) || srx_rt36_applicable(d)))
+  const bool rt36 = srx_rt36_applicable(d) && !act_out;  // (the row-tile kernel has no masked epilogue)
+  if (accumulate && (d->stride != 1 || srx_thin_dgrad_applicable(d) || rt36))
     SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: accumulate is implemented for stride-1 layers on the generic kernel only");
+  if (act_out && (accumulate || d->stride != 1 || srx_thin_dgrad_applicable(d)))
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data_act: stride-1 layers on the generic kernel only, without accumulate");
   hipStream_t st = srx_stream(stream);
   if (srx_thin_dgrad_applicable(d)) return srx_thin_fwd(d, dy, wpk_bwd, nullptr, dx, d->Cin, st);
   const Geo g = fwd_geo(d);
   BwdClass cls[16];
   size_t total;
   const int nc = bwd_classes(d, cls, total);
-  if (srx_rt36_applicable(d))  // 3x3 / stride 1 / pad 1: one class, same geometry as the forward, flipped taps
+  if (rt36)  // 3x3 / stride 1 / pad 1: one class, same geometry as the forward, flipped taps
     return srx_rt36_run(d, dy, wpk_bwd + cls[0].woff, nullptr, nullptr, dx, nullptr, SRX_ACT_NONE, 0.f, st);
   bool any_empty = false;
   for (int i = 0; i < nc; ++i) any_empty |= (cls[i].K == 0);
@@ -1611,6 +1635,7 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     a.w_bytes = (unsigned)((size_t)pad_rows(d->Cin) * c.Kp * sizeof(float));
     a.add = accumulate ? dx : nullptr;
     a.oscale = 1.f;
+    if (act_out) { a.add = act_out; a.add_is_mask = 1; a.oscale = act_slope; }
     if (d->stride == 1) {
       if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st, d->precision)) return rc;
     } else if (nc <= 4) {
@@ -1625,6 +1650,17 @@ extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const
     if (int rc = run_gconv_multi(multi, bm, bn, st)) return rc;
   }
   return SRX_OK;
+}
+
+extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
+                                   int accumulate, float* ws, size_t ws_floats, void* stream) {
+  return conv_bwd_data_impl(d, dy, wpk_bwd, dx, accumulate, nullptr, 1.f, ws, ws_floats, stream);
+}
+
+extern "C" int srx_conv2d_bwd_data_act(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, const float* x,
+                                       float slope, float* dx, float* ws, size_t ws_floats, void* stream) {
+  SRX_REQUIRE(x, "conv2d_bwd_data_act: null activation tensor");
+  return conv_bwd_data_impl(d, dy, wpk_bwd, dx, 0, x, slope, ws, ws_floats, stream);
 }
 
 extern "C" int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, int accumulate, float* ws,

@@ -606,6 +606,109 @@ def maxpool2x2(x: Tensor) -> Tensor:
     return _MaxPool.apply(x)
 
 
+class _FrozenConvStack(Function):
+    """A frozen stack of ``conv3x3 + ReLU`` and ``MaxPool2d(2)`` layers as ONE autograd node: the VGG19 feature
+    extractor of the perceptual loss (srgan/loss.py:30-34,52-53: pretrained, ``requires_grad = False``, eval).
+
+    Forward: ``source`` and ``target`` (loss.py:52 and :53) go through the stack TOGETHER as one batch of 2N -- same
+    weights, twice the rows per launch (the 6x6 and 12x12 layers alone fill a quarter of the chip).  Backward: only
+    the source half is differentiated (the target is ``high_res.detach()``, srgan/trainer.py:455), weights take no
+    gradient, and every ReLU backward rides in the epilogue of the data gradient above it
+    (``srx_conv2d_bwd_data_act``) or in the max-pool backward (``srx_maxpool2x2_relu_bwd``): 16 data-gradient
+    launches and 4 pool launches, no elementwise passes besides the topmost ReLU.
+    """
+
+    @staticmethod
+    def forward(ctx, source: Tensor, target: Optional[Tensor], layers, *weights):
+        ctx.set_materialize_grads(False)
+        source = _chk(source, 'conv_stack.source')
+        n_src = source.shape[0]
+        x = source if target is None else torch.cat([source, _chk(target, 'conv_stack.target')], dim=0)
+        L, s = _lib.lib(), _stream()
+        saved, plan = [x], []
+        for kind, conv in layers:
+            n, h, w, c = x.shape
+            if kind == 'pool':
+                y = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+                call('srx_maxpool2x2_fwd', _p(x), _p(y), n, h, w, c, s)
+                plan.append(('pool', None, None))
+            else:
+                st = conv._st
+                if st.act not in (ACT_RELU, ACT_LRELU) or st.stride != 1 or st.shuffle:
+                    raise RuntimeError('conv_stack: stride-1 conv + ReLU / LeakyReLU layers only')
+                d = st.desc(n, h, w)
+                st.pack(conv.weight, d)
+                dref = C.byref(d)
+                y = torch.empty(st.out_shape(n, h, w), dtype=torch.float32, device=x.device)
+                nws = L.srx_conv2d_fwd_ws_floats(dref)
+                ws = _ws(nws, x) if nws else None
+                b = None if conv.bias is None else _chk(conv.bias.detach(), 'conv_stack.bias')
+                call('srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(b), _p(y), None, _p(ws), nws, s)
+                plan.append(('conv', st, st.wpk_bwd))
+            saved.append(y)
+            x = y
+        ctx.plan, ctx.n_src = plan, n_src
+        ctx.save_for_backward(*saved)
+        if target is None:
+            return x, None
+        fs, ft = x[:n_src], x[n_src:]
+        ctx.mark_non_differentiable(ft)
+        return fs, ft
+
+    @staticmethod
+    def backward(ctx, dfs: Tensor, _dft=None):
+        saved, plan, n = ctx.saved_tensors, ctx.plan, ctx.n_src
+        if dfs is None or not ctx.needs_input_grad[0]:
+            return (None,) * len(ctx.needs_input_grad)
+        L, s = _lib.lib(), _stream()
+        g = _chk(dfs, 'conv_stack.grad')
+        # the topmost activation's backward is the only elementwise pass
+        top = saved[-1][:n]
+        kind, st, _ = plan[-1]
+        if kind == 'conv':
+            g2 = torch.empty_like(g)
+            call('srx_act_bwd_from_out', _p(g), _p(top), _p(g2), g.numel(), st.act, st.slope, s)
+            g = g2
+        for i in range(len(plan) - 1, -1, -1):
+            kind, st, wpk_bwd = plan[i]
+            x = saved[i][:n]                      # this layer's input (source half: batch-major, so a prefix)
+            below = plan[i - 1] if i > 0 else None
+            if kind == 'pool':
+                _, h, w, c = x.shape
+                dx = torch.empty_like(x)
+                # the pool's input is always a ReLU output in cfg 'E'; a pool fed by something else keeps the plain form
+                fn = 'srx_maxpool2x2_relu_bwd' if (below is not None and below[0] == 'conv' and below[1].act == ACT_RELU) \
+                    else 'srx_maxpool2x2_bwd'
+                call(fn, _p(g), _p(x), _p(dx), n, h, w, c, s)
+                if fn == 'srx_maxpool2x2_bwd' and below is not None and below[0] == 'conv':
+                    g2 = torch.empty_like(dx)
+                    call('srx_act_bwd_from_out', _p(dx), _p(x), _p(g2), dx.numel(), below[1].act, below[1].slope, s)
+                    dx = g2
+                g = dx
+                continue
+            _, h, w, _c = x.shape
+            d = st.desc(n, h, w)
+            dref = C.byref(d)
+            dx = torch.empty_like(x)
+            nws = L.srx_conv2d_bwd_data_ws_floats(dref)
+            ws = _ws(nws, x) if nws else None
+            if below is not None and below[0] == 'conv':   # x = act(conv below): fold that activation's backward in
+                slope = 0.0 if below[1].act == ACT_RELU else below[1].slope
+                call('srx_conv2d_bwd_data_act', dref, _p(g), _p(wpk_bwd), _p(x), slope, _p(dx), _p(ws), nws, s)
+            else:
+                call('srx_conv2d_bwd_data', dref, _p(g), _p(wpk_bwd), _p(dx), 0, _p(ws), nws, s)
+            g = dx
+        return (g, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+def frozen_conv_stack(source: Tensor, target: Optional[Tensor], layers):
+    """``layers``: [('conv', layers.Conv2d) | ('pool', None)].  Returns ``(features(source), features(target))``."""
+    weights = [p for _, m in layers if m is not None for p in (m.weight, m.bias) if p is not None]
+    if any(p.requires_grad for p in weights):
+        raise RuntimeError('frozen_conv_stack: the stack must be frozen (requires_grad = False on every parameter)')
+    return _FrozenConvStack.apply(source, target, layers, *weights)
+
+
 # --------------------------------------------------------------------------- linear
 class _Linear(Function):
     @staticmethod

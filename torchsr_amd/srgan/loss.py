@@ -98,9 +98,19 @@ class VGGLoss(nn.Module):
         """``self.features(target)`` of the detached branch (loss.py:53); no autograd state."""
         return self.features_nhwc(F.to_nhwc(target, 4))
 
+    def _stack(self):
+        return [('pool', None) if isinstance(m, MaxPool2x2) else ('conv', m) for m in self.features if not isinstance(m, Marker)]
+
     def forward(self, source: Tensor, target: Tensor = None, target_features: Tensor = None) -> Tensor:
-        """``l1_loss(features(source), features(target))``.  ``target_features`` may carry the second
-        term when the caller has already computed it."""
-        fs = self.features_nhwc(F.to_nhwc(source, 4))
-        ft = target_features if target_features is not None else self.target_features(target)
+        """``l1_loss(features(source), features(target))`` (loss.py:52-54).  Source and target run through the frozen
+        stack as ONE batch and the backward pass is the data-gradient chain of the source half with the ReLU
+        backwards folded into it (``functional.frozen_conv_stack``).  ``target_features`` may carry the second term
+        when the caller has already computed it."""
+        src4 = F.to_nhwc(source, 4)
+        if target_features is not None:
+            fs, _ = F.frozen_conv_stack(src4, None, self._stack())
+            return F.l1_loss(fs, target_features)
+        with torch.no_grad():
+            tgt4 = F.to_nhwc(target, 4)
+        fs, ft = F.frozen_conv_stack(src4, tgt4, self._stack())
         return F.l1_loss(fs, ft)
