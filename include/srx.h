@@ -215,6 +215,7 @@ int srx_bicubic_down(const float* in_nchw, float* out_nchw, int N, int C, int H,
  * srgan/generator.py:49; srgan/discriminator.py:36-60).
  * stats from an activation tensor: partial table [rows][C][2] */
 int srx_bn_stat_rows(int64_t M);
+int srx_bn_rows_per_block(int64_t M);  /* rows summed per partial row (and per row block of the backward reduction) */
 int srx_bn_partial_stats(const float* y, float* partials, int64_t M, int C, void* stream);
 /* reduce partials -> save_mean, save_invstd (biased variance); update running stats
  * (unbiased variance, momentum) and num_batches_tracked (int64) when non-NULL */
@@ -241,14 +242,17 @@ int srx_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, c
                          const float* gamma, const float* beta, const float* sums, float* dy, int64_t M,
                          int C, int act, float slope, const float* prelu, int training, void* stream);
 
-/* one-call forms used by the trainers; for small tensors they fuse the finalize step into the
- * streaming pass (one kernel boundary less per BatchNorm and direction) */
-int srx_bn_train_fwd(const float* y, const float* partials, int rows, int64_t M, int C, float eps, float momentum,
-                     const float* gamma, const float* beta, const float* residual, float* out, int act, float slope,
-                     const float* prelu, float* save_mean, float* save_invstd, float* running_mean,
+/* one-call forms used by the trainers.  `groups` > 1: the M rows are `groups` equal consecutive row ranges that are
+ * normalised independently -- several forward calls of the reference run as one batch (the discriminator on the real
+ * and on the fake images, srgan/trainer.py:446-447): save_mean / save_invstd are [groups][C], sums [groups][2C+4],
+ * the running statistics are updated once per group in order, num_batches_tracked advances by `groups`, and the
+ * parameter gradients sum over the groups.  Row blocks (conv tiles, srx_bn_stat_rows) must not straddle groups. */
+int srx_bn_train_fwd(const float* y, const float* partials, int rows, int64_t M, int C, int groups, float eps,
+                     float momentum, const float* gamma, const float* beta, const float* residual, float* out, int act,
+                     float slope, const float* prelu, float* save_mean, float* save_invstd, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, void* stream);
 int srx_bn_act_bwd(const float* dout, const float* y, const float* mean, const float* invstd, const float* gamma,
-                   const float* beta, float* sums, float* dy, int64_t M, int C, int act, float slope,
+                   const float* beta, float* sums, float* dy, int64_t M, int C, int groups, int act, float slope,
                    const float* prelu, int training, float* dgamma_acc, float* dbeta_acc, float* dprelu_acc,
                    float* ws, size_t ws_floats, void* stream);
 

@@ -367,6 +367,41 @@ def test_bn_act(dev, cfg, training):
     assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize('groups', [2, 3])
+def test_bn_act_groups_equal_consecutive_calls(dev, groups):
+    """groups = G: one call over G*N images == G consecutive training-mode calls of torch's BatchNorm2d (own batch
+    statistics each, running statistics updated G times in order, parameter gradients summed)."""
+    from torchsr_amd import functional as F
+    from torchsr_amd.layers import BatchNorm2d
+    from torchsr_amd._lib import ACT_LRELU
+    n, h, w, c = 2, 16, 16, 64
+    ys = [rnd((n, c, h, w), 20 + g) * (1 + g) + 0.2 * g for g in range(groups)]
+    gos = [rnd((n, c, h, w), 40 + g) for g in range(groups)]
+    bn_ref = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn_ref.weight.copy_(1 + 0.2 * rnd((c,), 7))
+        bn_ref.bias.copy_(0.1 * rnd((c,), 8))
+    bn = BatchNorm2d(c)
+    bn.load_state_dict(bn_ref.state_dict())
+    bn_ref.train()
+    ycs = [y.clone().requires_grad_(True) for y in ys]
+    for yc, go in zip(ycs, gos):
+        TF.leaky_relu(bn_ref(yc), 0.2).backward(go)
+    bn = bn.to(dev).train()
+    yg = torch.cat([nhwc(y) for y in ys], 0).to(dev).requires_grad_(True)
+    assert F.bn_groups_ok(groups * n * h * w, None, groups)
+    og = bn(yg, None, act=ACT_LRELU, slope=0.2, groups=groups)
+    og.backward(torch.cat([nhwc(g) for g in gos], 0).to(dev))
+    for g in range(groups):
+        assert rel_err(nchw(yg.grad[g * n:(g + 1) * n].cpu(), c), ycs[g].grad) < 5e-4, g
+    assert rel_err(bn.weight.grad, bn_ref.weight.grad) < 5e-4 and rel_err(bn.bias.grad, bn_ref.bias.grad) < 5e-4
+    assert rel_err(bn.running_mean, bn_ref.running_mean) < 1e-5 and rel_err(bn.running_var, bn_ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == groups
+    assert not F.bn_groups_ok(3 * 100, None, 2) and not F.bn_groups_ok(2 * 144, 1, 2)
+    with pytest.raises(RuntimeError, match='straddle|split'):
+        bn(torch.zeros(1, 6, 8, c, device=dev), None, groups=4)   # 48 rows: 12 per group, row blocks are 32
+
+
 def test_activations_and_pool(dev):
     from torchsr_amd import functional as F
     x = rnd((2, 16, 10, 12), 20)

@@ -97,6 +97,7 @@ _SIGS = {
     'srx_sigmoid_fwd': (_I, [_P, _P, _L, _P]),
     'srx_sigmoid_bwd': (_I, [_P, _P, _P, _L, _P]),
     'srx_bn_stat_rows': (_I, [_L]),
+    'srx_bn_rows_per_block': (_I, [_L]),
     'srx_bn_partial_stats': (_I, [_P, _P, _L, _I, _P]),
     'srx_bn_finalize': (_I, [_P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     'srx_bn_eval_stats': (_I, [_P, _P, _I, _F, _P, _P, _P]),
@@ -104,8 +105,8 @@ _SIGS = {
     'srx_bn_bwd_ws_floats': (_Z, [_L, _I]),
     'srx_bn_act_bwd_reduce': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_bn_act_bwd_apply': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _I, _P]),
-    'srx_bn_train_fwd': (_I, [_P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
-    'srx_bn_act_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    'srx_bn_train_fwd': (_I, [_P, _P, _I, _L, _I, _I, _F, _F, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
+    'srx_bn_act_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _Z, _P]),
     'srx_maxpool2x2_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'srx_maxpool2x2_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'srx_maxpool2x2_relu_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
@@ -124,7 +125,7 @@ _SIGS = {
     'srx_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
 }
 # functions whose int return value is data, not a status
-_UNCHECKED = {'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows'}
+_UNCHECKED = {'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows', 'srx_bn_rows_per_block'}
 
 EXPORTS = tuple(_SIGS.keys())
 

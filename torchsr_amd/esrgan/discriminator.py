@@ -1,4 +1,5 @@
 """ESRGAN discriminator -- interface of torchsr/esrgan/discriminator.py:26-95 (logits, no sigmoid)."""
+import torch
 from torch import nn, Tensor
 
 from .. import functional as F
@@ -24,14 +25,22 @@ class Discriminator(nn.Module):
             Linear(100, 1),
         )
 
-    def forward_nhwc(self, x4: Tensor) -> Tensor:
+    def forward_nhwc(self, x4: Tensor, groups: int = 1) -> Tensor:
+        """``groups`` > 1: the batch holds that many forward calls of the reference back to back (``forward_pair``);
+        every BatchNorm then normalises each call's rows with their own statistics."""
         mods = list(self.features)
         out = mods[0](x4)
         i = 2
         while i < len(mods):
             conv, bn = mods[i], mods[i + 1]
-            y, part = conv(out, want_stats=True) if bn.training else (conv(out), None)
-            out = bn(y, part, act=ACT_LRELU, slope=0.2)
+            stats = bn.training
+            if groups > 1 and bn.training:
+                # a conv tile must not straddle two calls; where the plan's tiles do, the BatchNorm pass gathers its
+                # own statistics (row blocks of srx_bn_rows_per_block) instead of taking them from the conv epilogue
+                n, h, w, _ = out.shape
+                stats = F.bn_groups_ok(conv._st.out_rows(n, h, w), F.conv_stat_tile_rows(conv._st, n, h, w), groups)
+            y, part = conv(out, want_stats=True) if stats else (conv(out), None)
+            out = bn(y, part, act=ACT_LRELU, slope=0.2, groups=groups)
             i += 3
         out = F.cut_point('d.head', out)  # data parallel: classifier.* gradients are a bucket of their own
         out = F.flatten_nchw(out)
@@ -40,3 +49,31 @@ class Discriminator(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         return self.forward_nhwc(F.to_nhwc(x, 4))
+
+    def _pair_fits(self, n2: int, h: int, w: int) -> bool:
+        """Do the conv tiles and reduction row blocks of every BatchNorm layer respect the boundary between the two
+        calls at this geometry?  (Pure geometry: nothing is launched, no state is touched.)"""
+        cache = self.__dict__.setdefault('_pair_cache', {})
+        key = (n2, h, w)
+        if key not in cache:
+            ok, mods, i = True, list(self.features), 2
+            n2, h, w, _ = mods[0]._st.out_shape(n2, h, w)
+            while ok and i < len(mods):  # (every layer can fall back to srx_bn_partial_stats: only its row blocks matter)
+                n2, h, w, _ = mods[i]._st.out_shape(n2, h, w)
+                ok = F.bn_groups_ok(n2 * h * w, None, 2)
+                i += 3
+            cache[key] = ok
+        return cache[key]
+
+    def forward_pair(self, first: Tensor, second: Tensor):
+        """``(self(first), self(second))`` -- two consecutive forward calls of the reference (the real and the fake
+        batch, trainer.py:446-447) executed as ONE batch of 2N: same weights, half the launches, twice the rows per
+        launch, and the 75 MB classifier weight is streamed once.  Training-mode BatchNorm keeps the two calls
+        apart (own batch statistics, running statistics updated for ``first`` and then for ``second``).  Falls
+        back to two calls when a layer's tiles would straddle the two halves (``_pair_fits``)."""
+        n = first.shape[0]
+        if second.shape != first.shape or (self.training and not self._pair_fits(2 * n, first.shape[2], first.shape[3])):
+            return self(first), self(second)
+        x4 = torch.cat([F.to_nhwc(first, 4), F.to_nhwc(second, 4)], dim=0)
+        out = self.forward_nhwc(x4, groups=2 if self.training else 1)
+        return F.split_batch(out, n)

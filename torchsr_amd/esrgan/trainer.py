@@ -41,8 +41,7 @@ class ESRGANTrainer(SRGANTrainer):
         self.disc_optimizer.zero_grad()                                          # :444
         with torch.no_grad():  # only ever used detached (:449); the generator has no BatchNorm state to update
             super_res = self.generator(low_res)                                  # :447
-        real_output = self.discriminator(high_res)                               # :448
-        fake_output = self.discriminator(super_res)                              # :449 (detached)
+        real_output, fake_output = self.discriminator.forward_pair(high_res, super_res)  # :448-449 as one batch
         d_real = self.bce_loss(real_output, 1.0, shift=F.mean(fake_output))      # :451
         d_fake = self.bce_loss(fake_output, 0.0, shift=F.mean(real_output))      # :452
         disc_loss = F.axpby(d_real, d_fake, 0.5, 0.5)                            # :453

@@ -215,6 +215,12 @@ class ConvState:
             self._descs[(n, h, w, self.precision)] = d
         return d
 
+    def out_rows(self, n, h, w) -> int:
+        """Rows of the output matrix (pixels the conv computes; before any PixelShuffle)."""
+        ho = (h + 2 * self.pad - self.k) // self.stride + 1
+        wo = (w + 2 * self.pad - self.k) // self.stride + 1
+        return n * ho * wo
+
     def out_shape(self, n, h, w):
         ho = (h + 2 * self.pad - self.k) // self.stride + 1
         wo = (w + 2 * self.pad - self.k) // self.stride + 1
@@ -408,66 +414,90 @@ class _BNAct(Function):
     @staticmethod
     def forward(ctx, y: Tensor, part: Optional[Tensor], gamma: Tensor, beta: Tensor, prelu: Optional[Tensor],
                 residual: Optional[Tensor], running_mean: Tensor, running_var: Tensor, nbt: Optional[Tensor],
-                training: bool, eps: float, momentum: float, act: int, slope: float):
+                training: bool, eps: float, momentum: float, act: int, slope: float, groups: int):
         ctx.set_materialize_grads(False)
         y = _chk(y, 'bn.input')
         c = y.shape[-1]
         m = y.numel() // c
         s = _stream()
-        mean = torch.empty(c, dtype=torch.float32, device=y.device)
-        invstd = torch.empty(c, dtype=torch.float32, device=y.device)
-        if training:
-            if part is None:
-                rows = _lib.lib().srx_bn_stat_rows(m)
-                part = torch.empty((rows, c, 2), dtype=torch.float32, device=y.device)
-                call('srx_bn_partial_stats', _p(y), _p(part), m, c, s)
-            fused = True
-        else:
-            call('srx_bn_eval_stats', _p(running_mean), _p(running_var), c, eps, _p(mean), _p(invstd), s)
-            fused = False
+        if not training:
+            groups = 1  # eval: one set of running statistics for every row
+        mean = torch.empty(groups * c, dtype=torch.float32, device=y.device)
+        invstd = torch.empty(groups * c, dtype=torch.float32, device=y.device)
         g = _chk(gamma.detach(), 'bn.weight')
         b = _chk(beta.detach(), 'bn.bias')
         pw = None if prelu is None else _chk(prelu.detach(), 'prelu.weight')
         res = None if residual is None else _chk(residual, 'bn.residual')
         out = torch.empty_like(y)
-        if fused:
-            call('srx_bn_train_fwd', _p(y), _p(part), part.shape[0], m, c, eps, momentum, _p(g), _p(b), _p(res), _p(out),
-                 act, slope, _p(pw), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt), s)
+        if training:
+            if part is None:
+                rows = _lib.lib().srx_bn_stat_rows(m)
+                part = torch.empty((rows, c, 2), dtype=torch.float32, device=y.device)
+                call('srx_bn_partial_stats', _p(y), _p(part), m, c, s)
+            call('srx_bn_train_fwd', _p(y), _p(part), part.shape[0], m, c, groups, eps, momentum, _p(g), _p(b), _p(res),
+                 _p(out), act, slope, _p(pw), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt), s)
         else:
+            call('srx_bn_eval_stats', _p(running_mean), _p(running_var), c, eps, _p(mean), _p(invstd), s)
             call('srx_bn_act_fwd', _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(res), _p(out), m, c, act, slope, _p(pw),
                  s)
         ctx.save_for_backward(y, mean, invstd, g, b, pw)
-        ctx.cfg = (m, c, act, slope, training, residual is not None, prelu is not None)
+        ctx.cfg = (m, c, act, slope, training, residual is not None, prelu is not None, groups)
         ctx.params = (gamma, beta, prelu)
         return out
 
     @staticmethod
     def backward(ctx, dout: Tensor):
         y, mean, invstd, g, b, pw = ctx.saved_tensors
-        m, c, act, slope, training, has_res, has_prelu = ctx.cfg
+        m, c, act, slope, training, has_res, has_prelu, groups = ctx.cfg
         dout = _chk(dout, 'bn.grad')
         s = _stream()
-        sums = torch.empty(2 * c + 4, dtype=torch.float32, device=y.device)
+        sums = torch.empty(groups * (2 * c + 4), dtype=torch.float32, device=y.device)
         nws = _lib.lib().srx_bn_bwd_ws_floats(m, c)
         gs, bs, ps = (_sink(t) for t in ctx.params)
         dy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
-        call('srx_bn_act_bwd', _p(dout), _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(sums), _p(dy), m, c, act, slope,
-             _p(pw), 1 if training else 0, _p(gs), _p(bs), _p(ps), _p(_ws(nws, y)), nws, s)
-        dgamma = sums[c:2 * c] if (ctx.needs_input_grad[2] and gs is None) else None
-        dbeta = sums[:c] if (ctx.needs_input_grad[3] and bs is None) else None
-        dprelu = sums[2 * c:2 * c + 1] if (has_prelu and ctx.needs_input_grad[4] and ps is None) else None
+        call('srx_bn_act_bwd', _p(dout), _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(sums), _p(dy), m, c, groups, act,
+             slope, _p(pw), 1 if training else 0, _p(gs), _p(bs), _p(ps), _p(_ws(nws, y)), nws, s)
+        per = sums.view(groups, 2 * c + 4)
+        tot = per[0] if groups == 1 else per.sum(0)  # (only read when gradients are returned instead of accumulated)
+        dgamma = tot[c:2 * c] if (ctx.needs_input_grad[2] and gs is None) else None
+        dbeta = tot[:c] if (ctx.needs_input_grad[3] and bs is None) else None
+        dprelu = tot[2 * c:2 * c + 1] if (has_prelu and ctx.needs_input_grad[4] and ps is None) else None
         dres = dout if (has_res and ctx.needs_input_grad[5]) else None
-        return dy, None, dgamma, dbeta, dprelu, dres, None, None, None, None, None, None, None, None
+        return (dy, None, dgamma, dbeta, dprelu, dres) + (None,) * 9
+
+
+def bn_groups_ok(m: int, tile_rows: Optional[int], groups: int) -> bool:
+    """Can ``m`` rows be normalised as ``groups`` independent row ranges?  ``tile_rows``: rows per entry of the conv
+    epilogue's partial-statistics table (``conv_stat_tile_rows``; ``None``: the statistics come from
+    ``srx_bn_partial_stats``).  No conv tile and no row block of the streaming reductions may straddle two groups."""
+    if groups == 1:
+        return True
+    if m % groups:
+        return False
+    per = m // groups
+    if per % _lib.lib().srx_bn_rows_per_block(m):
+        return False
+    return tile_rows is None or per % tile_rows == 0
+
+
+def conv_stat_tile_rows(st: ConvState, n: int, h: int, w: int) -> int:
+    """Output rows (pixels) summarised by one row of the partial-statistics table ``conv2d(..., want_stats=True)``
+    returns for this layer at this input size: the tile height of the launch plan."""
+    out = (C.c_int * 6)()
+    call('srx_conv2d_plan', C.byref(st.desc(n, h, w)), 0, out)
+    return int(out[0])
 
 
 def bn_act(y, part, bn, act=ACT_NONE, slope=0.0, prelu: Optional[Tensor] = None,
-           residual: Optional[Tensor] = None, frozen: bool = False) -> Tensor:
-    """``act(BatchNorm2d(y)) [+ residual]`` with ``bn`` an ``nn.BatchNorm2d``-compatible module."""
+           residual: Optional[Tensor] = None, frozen: bool = False, groups: int = 1) -> Tensor:
+    """``act(BatchNorm2d(y)) [+ residual]`` with ``bn`` an ``nn.BatchNorm2d``-compatible module.  ``groups``: the batch
+    is that many forward calls of the reference run together (independent batch statistics, see norm.hip)."""
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
     gamma, beta = (bn.weight.detach(), bn.bias.detach()) if frozen else (bn.weight, bn.bias)
     return _BNAct.apply(y, part, gamma, beta, prelu, residual, bn.running_mean, bn.running_var,
-                        bn.num_batches_tracked if training else None, training, bn.eps, momentum, act, float(slope))
+                        bn.num_batches_tracked if training else None, training, bn.eps, momentum, act, float(slope),
+                        int(groups))
 
 
 # --------------------------------------------------------------------------- activations
@@ -867,6 +897,32 @@ class _Mean(Function):
         dx = torch.empty_like(x)
         call('srx_mean_bwd', _p(x), _p(g), _p(dx), x.numel(), _stream())
         return dx
+
+
+class _SplitBatch(Function):
+    """``(x[:n], x[n:])`` of a batch-major tensor as two independent tensors; the backward is one concatenation."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, n: int):
+        ctx.set_materialize_grads(False)
+        ctx.shape, ctx.n = x.shape, n
+        return x[:n].clone(), x[n:].clone()
+
+    @staticmethod
+    def backward(ctx, da, db):
+        n, shape = ctx.n, ctx.shape
+        ref = da if da is not None else db
+        if ref is None:
+            return None, None
+        if da is None:
+            da = torch.zeros((n,) + tuple(shape[1:]), dtype=ref.dtype, device=ref.device)
+        if db is None:
+            db = torch.zeros((shape[0] - n,) + tuple(shape[1:]), dtype=ref.dtype, device=ref.device)
+        return torch.cat([da, db], dim=0), None
+
+
+def split_batch(x: Tensor, n: int):
+    return _SplitBatch.apply(x, n)
 
 
 def mean(x: Tensor) -> Tensor:

@@ -83,8 +83,9 @@ def set_conv_precision(module: nn.Module, precision: str) -> None:
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d parameter holder; applied through ``functional.bn_act``."""
 
-    def forward(self, y: Tensor, part=None, act=ACT_NONE, slope=0.0, prelu=None, residual=None) -> Tensor:
-        return F.bn_act(y, part, self, act=act, slope=slope, prelu=_w(prelu), residual=residual, frozen=_frozen[0])
+    def forward(self, y: Tensor, part=None, act=ACT_NONE, slope=0.0, prelu=None, residual=None, groups: int = 1) -> Tensor:
+        return F.bn_act(y, part, self, act=act, slope=slope, prelu=_w(prelu), residual=residual, frozen=_frozen[0],
+                        groups=groups)
 
 
 class PReLU(nn.PReLU):

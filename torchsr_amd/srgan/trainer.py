@@ -369,8 +369,9 @@ class SRGANTrainer:
         low_res, high_res = self._static['low_res'], self._static['high_res']
         self.disc_optimizer.zero_grad()                                      # :442
         self._super_res = self.generator(low_res)                            # :444
-        d_real = self.bce_loss(self.discriminator(high_res), 1.0)            # :446
-        d_fake = self.bce_loss(self.discriminator(self._super_res.detach()), 0.0)  # :447
+        p_real, p_fake = self.discriminator.forward_pair(high_res, self._super_res.detach())  # :446-447 as one batch
+        d_real = self.bce_loss(p_real, 1.0)                                  # :446
+        d_fake = self.bce_loss(p_fake, 0.0)                                  # :447
         disc_loss = F.axpby(d_real, d_fake, 1.0, 1.0)                        # :448
         self._backward(disc_loss)                                            # :450
         self._losses['gan/disc-loss'] = disc_loss.detach()
