@@ -114,6 +114,58 @@ def test_baseline_size_gan_step_vs_reference_and_oracle(dev):
     assert_elementwise(t.discriminator, orc.d, 'D')
 
 
+def test_baseline_size_gradients_vs_oracle(dev):
+    """Adam's first step is ~lr * sign(g): the post-step comparisons above pin every gradient's direction but not its
+    size.  This one compares the batch-16 GAN step's gradients themselves -- the flat .grad buffers right before each
+    optimiser step -- with the oracle's: every tensor's cosine, the classifier to rounding, the generator tail to 1e-3,
+    everything within the reach of a few LeakyReLU / PReLU / ReLU / max-pool decisions that fall the other way
+    (test_discriminator_forward_pair_equals_two_calls explains the 2 %)."""
+    gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
+    s_lr, s_hr = (int(v) for v in gold['b16_seeds'])
+    lr, hr = seeded_input((16, 3, 24, 24), s_lr), seeded_input((16, 3, 96, 96), s_hr)
+    t = make_trainer(dev, use_graphs=False, batch=16)
+    orc = oracle_for(t)
+    got, want = {}, {}
+
+    def tap(opt, mod, tag):
+        step = opt.step
+
+        def wrapped():
+            got[tag] = {k: p.grad.detach().cpu().clone() for k, p in mod.named_parameters()}
+            step()
+        opt.step = wrapped
+
+    def tap_oracle(opt, sd, tag):
+        step = opt.step
+
+        def wrapped():
+            want[tag] = {k: v.grad.clone() for k, v in sd.items() if v.requires_grad and v.grad is not None}
+            step()
+        opt.step = wrapped
+
+    tap(t.disc_optimizer, t.discriminator, 'D')
+    tap(t.gen_optimizer, t.generator, 'G')
+    tap_oracle(orc.disc_optimizer, orc.d, 'D')
+    tap_oracle(orc.gen_optimizer, orc.g, 'G')
+    orc.gan_step(lr, hr)
+    t.gan_step(lr.to(dev), hr.to(dev))
+    for tag in ('D', 'G'):
+        assert set(got[tag]) == set(want[tag])
+        errs = {}
+        for k, g in got[tag].items():
+            w = want[tag][k]
+            a, b = g.double().flatten(), w.double().flatten()
+            if b.numel() > 1:
+                assert (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item() > 0.9995, (tag, k)
+            errs[k] = ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+        assert max(errs.values()) < 2e-2, (tag, max(errs.items(), key=lambda kv: kv[1]))
+        assert sorted(errs.values())[len(errs) // 2] < 2e-3, (tag, errs)
+        # nothing but two Linear layers lies between the loss and the classifier's gradients; the generator's last
+        # layers sit behind VGG19's and the discriminator's activations
+        tight = [k for k in errs if k.startswith(('classifier', 'conv3', 'conv_layers.1'))]
+        assert tight and all(errs[k] < (1e-4 if tag == 'D' else 1e-3) for k in tight), (tag, {k: errs[k] for k in tight})
+
+
 def test_baseline_size_pretrain_step_vs_reference_and_oracle(dev):
     gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
     s_lr, s_hr = (int(v) for v in gold['b16_seeds'])
