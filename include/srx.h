@@ -142,12 +142,15 @@ int srx_conv2d_fwd_residual(const srx_conv2d_t* d, const float* x, const float* 
  * place of the torch.cat adjoint (esrgan/residual.py:81-85). */
 int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
                         int accumulate, float* ws, size_t ws_floats, void* stream);
-/* The same followed by the backward of the activation that PRODUCED this conv's input: dx = conv_transpose(dy, W) *
- * (x > 0 ? 1 : slope), x = that activation's output = the conv's saved input (laid out like dx).  In the VGG19
- * feature stack (srgan/loss.py:30-31,52: conv, ReLU, conv, ReLU, ...) every ReLU backward then rides in the
- * epilogue of the data gradient above it instead of being a pass of its own.  Stride-1 layers, generic kernel. */
+/* The same followed by the backward of the activation that PRODUCED this conv's input, for the input channels
+ * [c_lo, c_hi): dx[.., c] = (accumulate ? dx[.., c] : 0) + conv_transpose(dy, W)[.., c], then for c in the range
+ * dx[.., c] *= (x[.., c] > 0 ? 1 : slope), x = that activation's output = the conv's saved input (laid out like dx).
+ * In the VGG19 feature stack (srgan/loss.py:30-31,52: conv, ReLU, conv, ReLU, ...) every ReLU backward then rides
+ * in the epilogue of the data gradient above it (range = all channels); in ESRGAN's dense block
+ * (esrgan/residual.py:81-85) the conv that completes the gradient of a 32-channel slice of the shared buffer also
+ * applies that slice's LeakyReLU backward.  Stride-1 layers, generic kernel; range in whole channel quads. */
 int srx_conv2d_bwd_data_act(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, const float* x, float slope,
-                            float* dx, float* ws, size_t ws_floats, void* stream);
+                            int c_lo, int c_hi, int accumulate, float* dx, float* ws, size_t ws_floats, void* stream);
 /* dw (OIHW) = autograd of nn.Conv2d wrt its weight; accumulate != 0 adds into dw (a .grad buffer)
  * instead of overwriting it.  db (may be NULL; not for shuffle layers) receives the bias gradient
  * sum_m dy[m][co] under the same flag: the kernel stages every dy row anyway.  The same flag exists on srx_colsum, srx_linear_bwd_weight,

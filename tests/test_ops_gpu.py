@@ -278,8 +278,17 @@ def test_dgrad_with_folded_activation_backward(dev, case):
         nws = L.srx_conv2d_bwd_data_ws_floats(C.byref(d))
         ws = torch.empty(max(nws, 4), device=dev)
         _lib.call('srx_conv2d_bwd_data_act', C.byref(d), nhwc(dy).to(dev).data_ptr(), st.wpk_bwd.data_ptr(), xg.data_ptr(),
-                  slope, dx.data_ptr(), ws.data_ptr(), nws, torch.cuda.current_stream().cuda_stream)
+                  slope, 0, st.cin_s, 0, dx.data_ptr(), ws.data_ptr(), nws, torch.cuda.current_stream().cuda_stream)
         assert rel_err(nchw(dx.cpu(), cin), want.float()) < 2e-4, slope
+    # a channel range on top of an accumulated gradient (the dense block's shared buffer): dx += dgrad, then the slice
+    # [cin - 32, cin) takes the mask
+    base = rnd((n, cin, h, w), 3)
+    want = base.double() + torch.nn.grad.conv2d_input((n, cin, h, w), conv.weight.detach().cpu().double(), dy.double(), padding=1)
+    want[:, cin - 32:] *= torch.where(x[:, cin - 32:] > 0, 1.0, 0.2).double()
+    dx = nhwc(base).to(dev)
+    _lib.call('srx_conv2d_bwd_data_act', C.byref(d), nhwc(dy).to(dev).data_ptr(), st.wpk_bwd.data_ptr(), xg.data_ptr(),
+              0.2, cin - 32, cin, 1, dx.data_ptr(), ws.data_ptr(), nws, torch.cuda.current_stream().cuda_stream)
+    assert rel_err(nchw(dx.cpu(), cin), want.float()) < 2e-4
     del y
 
 

@@ -23,7 +23,7 @@ dev = torch.device('cuda:0')
 
 def targs(batch, amp=False):
     return Namespace(disable_amp=not amp, batch_size=batch, epochs=8, gan_checkpoint=None, local_rank=0, pretrain_epochs=1,
-                     psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1, use_graphs=True)
+                     psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1, use_graphs=True, vgg_weights='random')
 
 
 def timed(fn, steps, warm=4):

@@ -52,10 +52,14 @@ struct GArgs {
   // conv, `x + conv(...)` in one kernel).  Linear outputs only.
   const float* add;
   float oscale;  // applied to act(acc + bias) before the addend (conv5 * 0.2 + x of the dense block); 1 otherwise
-  // add_is_mask != 0: `add` is not an addend but the OUTPUT of the activation that produced this conv's input
-  // (laid out like `out`): the data gradient is multiplied by that activation's derivative on its way out,
-  // v * (add[i] > 0 ? 1 : oscale) -- ReLU / LeakyReLU backward of the layer below without a pass of its own.
-  int add_is_mask;
+  // mask (null: none): the OUTPUT of the activation that produced this conv's input, laid out like `out`.  The data
+  // gradient is multiplied by that activation's derivative on its way out, v * (mask[i] > 0 ? 1 : mask_slope), for
+  // the output columns [mask_lo, mask_hi) -- the ReLU / LeakyReLU backward of the layer below without a pass of its
+  // own.  Applied after the addend: in ESRGAN's dense block the convs' input gradients accumulate in one shared
+  // buffer and the conv that completes a 32-channel slice also applies that slice's LeakyReLU mask.
+  const float* mask;
+  float mask_slope;
+  int mask_lo, mask_hi;
 };
 
 
@@ -401,13 +405,16 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   const unsigned tb_hi = (unsigned)srx_uniform((int)(unsigned)(tile_base >> 32));
   const __amdgpu_buffer_rsrc_t rout = srx_rsrc(a.out + (((size_t)tb_hi << 32) | tb_lo), 0xfffffff0u);
   const __amdgpu_buffer_rsrc_t radd = srx_rsrc((a.add ? a.add : a.out) + (((size_t)tb_hi << 32) | tb_lo), 0xfffffff0u);
+  const __amdgpu_buffer_rsrc_t rmask = srx_rsrc((a.mask ? a.mask : a.out) + (((size_t)tb_hi << 32) | tb_lo), 0xfffffff0u);
 
   float bv[TN];
   unsigned ocol[TN];  // byte offset of the column inside its output row
   bool cok[TN];       // this lane stores the column
+  bool cmk[TN];       // ... and the column takes the activation mask
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * WN + j * 32 + l31;
+    cmk[j] = col >= a.mask_lo && col < a.mask_hi;
     int bidx = col, oc = col;
     if (a.out_shuffle) {
       const int ij = col / a.out_shuffle, cc = col - ij * a.out_shuffle;
@@ -422,9 +429,16 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
 
-  auto store_tile = [&](auto linear, auto accum) {  // one copy per addressing / epilogue mode (0 plain, 1 add, 2 mask), chosen by ONE branch
+  auto store_tile = [&](auto linear, auto accum) {  // one copy per addressing / epilogue mode (bit 0: addend, bit 1: mask), chosen by ONE branch
+    constexpr int MODE = decltype(accum)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      // Addend / mask values of the whole 32-row block are requested BEFORE the first store: vmcnt retires in issue
+      // order, so a load issued behind a store cannot be consumed until that store has landed, and an epilogue that
+      // alternates load -> store per element pays a full memory round trip for each of its 16 x TN elements
+      // (+4.5 us on a 15 us dense-block data gradient).
+      unsigned offs[16][TN];
+      float av[MODE & 1 ? 16 : 1][TN], mv[MODE & 2 ? 16 : 1][TN];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -433,31 +447,45 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
                                                         : 4u * (unsigned)(out_elem(mok ? m : m0) - tile_base);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+          const unsigned off = (mok && cok[j]) ? rowoff + ocol[j] : 0xffffffffu;
+          offs[r][j] = off;
+          if (MODE & 1) av[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
+          // (a column outside the mask range reads nothing: its offset is pointed out of range)
+          if (MODE & 2)
+            mv[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)(cmk[j] ? off : 0xffffffffu), 0, 0));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool mok = m < a.M;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
           float v = acc[i][j][r] + bv[j];
           const float vs = mok ? v : 0.f;
           csum[j] += vs;
           csq[j] += vs * vs;
           v = v > 0.f ? v : v * a.slope;
-          const unsigned off = (mok && cok[j]) ? rowoff + ocol[j] : 0xffffffffu;
-          if (decltype(accum)::value == 1)
-            v = v * a.oscale + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
-          if (decltype(accum)::value == 2)
-            v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0)) > 0.f ? v : v * a.oscale;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
+          if (MODE & 1) v = v * a.oscale + av[r][j];
+          if (MODE & 2) v = (cmk[j] && !(mv[r][j] > 0.f)) ? v * a.mask_slope : v;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, offs[r][j], 0, 0);
         }
       }
     }
   };
-  using M0 = std::integral_constant<int, 0>; using M1 = std::integral_constant<int, 1>; using M2 = std::integral_constant<int, 2>;
-  if (a.add && a.add_is_mask) {
-    if (a.linear_out) store_tile(std::true_type{}, M2{});
-    else store_tile(std::false_type{}, M2{});
-  } else if (a.add) {
-    if (a.linear_out) store_tile(std::true_type{}, M1{});
-    else store_tile(std::false_type{}, M1{});
+  using M0 = std::integral_constant<int, 0>; using M1 = std::integral_constant<int, 1>;
+  using M2 = std::integral_constant<int, 2>; using M3 = std::integral_constant<int, 3>;
+  const int emode = (a.add ? 1 : 0) | (a.mask ? 2 : 0);
+  if (a.linear_out) {
+    if (emode == 0) store_tile(std::true_type{}, M0{});
+    else if (emode == 1) store_tile(std::true_type{}, M1{});
+    else if (emode == 2) store_tile(std::true_type{}, M2{});
+    else store_tile(std::true_type{}, M3{});
   } else {
-    if (a.linear_out) store_tile(std::true_type{}, M0{});
-    else store_tile(std::false_type{}, M0{});
+    if (emode == 0) store_tile(std::false_type{}, M0{});
+    else if (emode == 1) store_tile(std::false_type{}, M1{});
+    else if (emode == 2) store_tile(std::false_type{}, M2{});
+    else store_tile(std::false_type{}, M3{});
   }
 
   float xs1 = 0.f, xs2 = 0.f;
@@ -483,9 +511,10 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       xs2 += vs * vs;
       v = v > 0.f ? v : v * a.slope;
       const unsigned off = (mok && xok) ? rowoff + 4u * (unsigned)oc : 0xffffffffu;
-      if (a.add) {
-        const float ld = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
-        v = a.add_is_mask ? (ld > 0.f ? v : v * a.oscale) : v * a.oscale + ld;
+      if (a.add) v = v * a.oscale + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
+      if (a.mask && col >= a.mask_lo && col < a.mask_hi) {
+        const float mv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)off, 0, 0));
+        v = mv > 0.f ? v : v * a.mask_slope;
       }
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
     }
@@ -586,14 +615,11 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const GArgs a) {
       }
       if (col < a.Cs) {  // Cs is a multiple of 4
         f32x4* o = reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col);
-        if (a.add) {
-          const f32x4 ld = *reinterpret_cast<const f32x4*>(a.add + (size_t)m * a.Co + col);
-          if (a.add_is_mask) {
+        if (a.add) v = v * a.oscale + *reinterpret_cast<const f32x4*>(a.add + (size_t)m * a.Co + col);
+        if (a.mask && col >= a.mask_lo && col < a.mask_hi) {  // (mask ranges are whole quads: channel counts are multiples of 4)
+          const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + (size_t)m * a.Co + col);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ld[e] > 0.f ? v[e] : v[e] * a.oscale;
-          } else {
-            v = v * a.oscale + ld;
-          }
+          for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : v[e] * a.mask_slope;
         }
         *o = v;
       }
@@ -1073,8 +1099,10 @@ Plan make_plan(int M, int Cnp, int kchunks, bool can_split, bool bf16 = false) {
     p.mtiles = (int)srx_cdiv(M, bm);
     p.ntiles = Cnp / bn;
     p.tiles = p.mtiles * p.ntiles;
-    // microseconds for one whole tile on an otherwise idle CU (4 SIMDs x 64 FLOP/clk at ~2.1 GHz)
-    const float t_tile = 2.0f * bm * bn * (float)kchunks * BK / (4 * 64 * 2.1e3f) / eff[i];
+    // microseconds for one whole tile on an otherwise idle CU (4 SIMDs x 64 FLOP/clk at ~2.1 GHz).  bf16 products:
+    // the loop is bound by the fp32 operand stream, not by the matrix pipe, and runs ~3x the fp32 rate (measured
+    // 240-360 vs ~105 TFLOP/s on the VGG layers) -- the fixed cost of a K-split fix-up pass weighs 3x more
+    const float t_tile = 2.0f * bm * bn * (float)kchunks * BK / (4 * 64 * 2.1e3f) / eff[i] / (bf16 ? 3.0f : 1.0f);
     const int rounds = p.tiles / P, r = p.tiles % P;
     p.full = rounds * P; p.tail = r; p.split = 1; p.kc_per_split = kchunks;
     float tail_cost = r ? t_tile : 0.f;
@@ -1587,15 +1615,18 @@ extern "C" int srx_conv2d_fwd_residual(const srx_conv2d_t* d, const float* x, co
 }
 
 static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx, int accumulate,
-                              const float* act_out, float act_slope, float* ws, size_t ws_floats, void* stream) {
+                              const float* act_out, float act_slope, int c_lo, int c_hi, float* ws, size_t ws_floats,
+                              void* stream) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(dy && wpk_bwd && dx, "conv2d_bwd_data: null pointer");
   SRX_REQUIRE(d->stride <= 4, "conv2d_bwd_data: stride > 4 unsupported");
   const bool rt36 = srx_rt36_applicable(d) && !act_out;  // (the row-tile kernel has no masked epilogue)
   if (accumulate && (d->stride != 1 || srx_thin_dgrad_applicable(d) || rt36))
     SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: accumulate is implemented for stride-1 layers on the generic kernel only");
-  if (act_out && (accumulate || d->stride != 1 || srx_thin_dgrad_applicable(d)))
-    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data_act: stride-1 layers on the generic kernel only, without accumulate");
+  if (act_out && (d->stride != 1 || srx_thin_dgrad_applicable(d)))
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data_act: stride-1 layers on the generic kernel only");
+  if (act_out) SRX_REQUIRE(c_lo >= 0 && c_lo < c_hi && c_lo % 4 == 0 && (c_hi % 4 == 0 || c_hi >= d->Cin),
+                           "conv2d_bwd_data_act: the masked channel range must be made of whole quads");
   hipStream_t st = srx_stream(stream);
   if (srx_thin_dgrad_applicable(d)) return srx_thin_fwd(d, dy, wpk_bwd, nullptr, dx, d->Cin, st);
   const Geo g = fwd_geo(d);
@@ -1635,7 +1666,7 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
     a.w_bytes = (unsigned)((size_t)pad_rows(d->Cin) * c.Kp * sizeof(float));
     a.add = accumulate ? dx : nullptr;
     a.oscale = 1.f;
-    if (act_out) { a.add = act_out; a.add_is_mask = 1; a.oscale = act_slope; }
+    if (act_out) { a.mask = act_out; a.mask_slope = act_slope; a.mask_lo = c_lo; a.mask_hi = c_hi; }
     if (d->stride == 1) {
       if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st, d->precision)) return rc;
     } else if (nc <= 4) {
@@ -1654,13 +1685,14 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
 
 extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
                                    int accumulate, float* ws, size_t ws_floats, void* stream) {
-  return conv_bwd_data_impl(d, dy, wpk_bwd, dx, accumulate, nullptr, 1.f, ws, ws_floats, stream);
+  return conv_bwd_data_impl(d, dy, wpk_bwd, dx, accumulate, nullptr, 1.f, 0, 0, ws, ws_floats, stream);
 }
 
 extern "C" int srx_conv2d_bwd_data_act(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, const float* x,
-                                       float slope, float* dx, float* ws, size_t ws_floats, void* stream) {
+                                       float slope, int c_lo, int c_hi, int accumulate, float* dx, float* ws,
+                                       size_t ws_floats, void* stream) {
   SRX_REQUIRE(x, "conv2d_bwd_data_act: null activation tensor");
-  return conv_bwd_data_impl(d, dy, wpk_bwd, dx, 0, x, slope, ws, ws_floats, stream);
+  return conv_bwd_data_impl(d, dy, wpk_bwd, dx, accumulate, x, slope, c_lo, c_hi, ws, ws_floats, stream);
 }
 
 extern "C" int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, int accumulate, float* ws,

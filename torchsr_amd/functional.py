@@ -457,11 +457,15 @@ class _BNAct(Function):
         dy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
         call('srx_bn_act_bwd', _p(dout), _p(y), _p(mean), _p(invstd), _p(g), _p(b), _p(sums), _p(dy), m, c, groups, act,
              slope, _p(pw), 1 if training else 0, _p(gs), _p(bs), _p(ps), _p(_ws(nws, y)), nws, s)
-        per = sums.view(groups, 2 * c + 4)
-        tot = per[0] if groups == 1 else per.sum(0)  # (only read when gradients are returned instead of accumulated)
-        dgamma = tot[c:2 * c] if (ctx.needs_input_grad[2] and gs is None) else None
-        dbeta = tot[:c] if (ctx.needs_input_grad[3] and bs is None) else None
-        dprelu = tot[2 * c:2 * c + 1] if (has_prelu and ctx.needs_input_grad[4] and ps is None) else None
+        want = ((ctx.needs_input_grad[2] and gs is None), (ctx.needs_input_grad[3] and bs is None),
+                (has_prelu and ctx.needs_input_grad[4] and ps is None))
+        dgamma = dbeta = dprelu = None
+        if any(want):  # gradients returned to autograd instead of accumulated by the kernel: total over the groups
+            per = sums.view(groups, 2 * c + 4)
+            tot = per[0] if groups == 1 else per.sum(0)
+            dgamma = tot[c:2 * c] if want[0] else None
+            dbeta = tot[:c] if want[1] else None
+            dprelu = tot[2 * c:2 * c + 1] if want[2] else None
         dres = dout if (has_res and ctx.needs_input_grad[5]) else None
         return (dy, None, dgamma, dbeta, dprelu, dres) + (None,) * 9
 
@@ -724,7 +728,7 @@ class _FrozenConvStack(Function):
             ws = _ws(nws, x) if nws else None
             if below is not None and below[0] == 'conv':   # x = act(conv below): fold that activation's backward in
                 slope = 0.0 if below[1].act == ACT_RELU else below[1].slope
-                call('srx_conv2d_bwd_data_act', dref, _p(g), _p(wpk_bwd), _p(x), slope, _p(dx), _p(ws), nws, s)
+                call('srx_conv2d_bwd_data_act', dref, _p(g), _p(wpk_bwd), _p(x), slope, 0, st.cin_s, 0, _p(dx), _p(ws), nws, s)
             else:
                 call('srx_conv2d_bwd_data', dref, _p(g), _p(wpk_bwd), _p(dx), 0, _p(ws), nws, s)
             g = dx
@@ -1115,10 +1119,8 @@ class _DenseBlock(Function):
             cin = c0 + k * g
             if k == 4:
                 gk, ldg = g5.data_ptr(), st.cout
-            else:  # this conv's output gradient is complete now: apply the LeakyReLU mask in place
+            else:  # this conv's output gradient is complete AND masked: the data gradient of conv k+1 finished the slice
                 gk, ldg = gbuf.data_ptr() + 4 * cin, total
-                call('srx_act_bwd_from_out_strided', gk, total, buf.data_ptr() + 4 * cin, total, gk, total, m, g,
-                     st.act, st.slope, s)
             wparam, bparam = ctx.params[2 * k], ctx.params[2 * k + 1]
             bias_done = False
             if ctx.needs_input_grad[4 + 2 * k]:
@@ -1151,8 +1153,15 @@ class _DenseBlock(Function):
             if k > 0 or ctx.needs_input_grad[0]:
                 nws = L.srx_conv2d_bwd_data_ws_floats(dref)
                 ws = _ws(nws, dy) if nws else None
-                # conv5 writes all `total` channels; the others add their share to the first `cin`
-                call('srx_conv2d_bwd_data', dref, gk, _p(ctx.packs[k]), _p(gbuf), 0 if k == 4 else 1, _p(ws), nws, s)
+                # conv5 writes all `total` channels; the others add their share to the first `cin`.  The slice of
+                # conv k's output, channels [cin - g, cin), is complete with this call (every later conv has added
+                # its share): the LeakyReLU backward of conv k (esrgan/residual.py:81-84) is applied to it on the way out
+                if k > 0:
+                    prev = ctx.states[k - 1]
+                    call('srx_conv2d_bwd_data_act', dref, gk, _p(ctx.packs[k]), _p(buf), prev.slope, cin - g, cin,
+                         0 if k == 4 else 1, _p(gbuf), _p(ws), nws, s)
+                else:
+                    call('srx_conv2d_bwd_data', dref, gk, _p(ctx.packs[k]), _p(gbuf), 1, _p(ws), nws, s)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(dy)
