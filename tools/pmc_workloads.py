@@ -1,0 +1,45 @@
+"""Single-kernel workloads for rocprofv3 --pmc passes (developer tool; the summaries go to profiles/).
+
+    rocprofv3 --pmc <counters> --kernel-trace --output-format csv -d <dir> -- python3 tools/pmc_workloads.py <name>
+
+  rt36     : the north-star kernel, 3x3 64->64 forward at 16x24x24 (66 launches per GAN step)
+  wgrad33  : the grouped weight gradient of the generator's 33 residual convs (one launch per step)
+  vgg256   : 3x3 256->256 at 32x24x24 -- the VGG19 block-3 layers with source and target as one batch
+  vgg256h  : the same at 16x24x24 (its data gradient: source half only)
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torchsr_amd import _lib  # noqa: E402
+from torchsr_amd.layers import Conv2d  # noqa: E402
+
+dev = torch.device('cuda:0')
+name = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+torch.manual_seed(0)
+if name in ('rt36', 'vgg256', 'vgg256h'):
+    n, h, w, cin, cout = {'rt36': (16, 24, 24, 64, 64), 'vgg256': (32, 24, 24, 256, 256), 'vgg256h': (16, 24, 24, 256, 256)}[name]
+    conv = Conv2d(cin, cout, 3, 1, 1, bias=False).to(dev)
+    x = torch.rand(n, h, w, cin, device=dev)
+    with torch.no_grad():
+        for _ in range(reps):
+            conv(x)
+elif name == 'wgrad33':
+    d = _lib.Conv2dDesc(16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
+    xs = [torch.rand(16, 24, 24, 64, device=dev) for _ in range(33)]
+    dys = [torch.rand(16, 24, 24, 64, device=dev) for _ in range(33)]
+    dws = [torch.zeros(64, 64, 3, 3, device=dev) for _ in range(33)]
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
+    nws = _lib.lib().srx_conv2d_bwd_weight_multi_ws_floats(C.byref(d), 33)
+    ws = torch.empty(nws, device=dev)
+    for _ in range(reps):
+        _lib.call('srx_conv2d_bwd_weight_multi', C.byref(d), 33, 1, arr(xs), arr(dys), arr(dws), 1, None, ws.data_ptr(), nws,
+                  torch.cuda.current_stream().cuda_stream)
+else:
+    sys.exit(f'unknown workload {name}')
+torch.cuda.synchronize()
+print('done', name)
