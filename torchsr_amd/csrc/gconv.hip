@@ -666,7 +666,7 @@ struct WArgs {
   // row split, so they add the column sums up on the way and write one [Cnw] row per split here
   // (null: not wanted); wgrad_reduce_kernel sums the rows.  Replaces two column-sum launches per layer.
   float* bslab;
-  int nsplit;
+  int nsplit, nprob;
 };
 
 // Several weight-gradient problems of ONE geometry in one launch (blockIdx.y = problem): the 33 residual convs
@@ -693,12 +693,23 @@ struct WReduce {
 template <int PR>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WMulti mp) {
   const WArgs& a = mp.a;
-  const int prob = blockIdx.y;
+  // Work item = (tile, problem, row split), tile fastest.  The (up to 9 x Cout/64) tiles of one problem's row split read the
+  // same dy and x rows, so they should share an L2: workgroups are dealt round-robin over the 8 XCDs, and this remap gives
+  // every XCD a contiguous range of work items (MI355X_MICROARCH.md, XCD placement; a speed matter only -- with the plain
+  // order the 33-problem group read 1.23 GB through the fabric per launch, 8x its operands).
+  int wi;
+  {
+    const int W = (int)gridDim.x, b = (int)blockIdx.x, xcd = b & 7, slot = b >> 3, q = W >> 3, r = W & 7;
+    wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tiles_ = a.ktiles * (a.Cnw / 64);
+  const int tile_id = wi % tiles_, rest_ = wi / tiles_;
+  const int prob = srx_uniform(rest_ % a.nprob), zsplit = srx_uniform(rest_ / a.nprob);
   constexpr int LROWS = PR ? 16 : 32;  // LDS rows per chunk (row pairs for bf16)
   __shared__ __attribute__((aligned(16))) float sD[2][LROWS * 64];
   __shared__ __attribute__((aligned(16))) float sX[2][LROWS * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
-  const int ntile = srx_uniform(blockIdx.x / a.ktiles), kt = blockIdx.x - ntile * a.ktiles;
+  const int ntile = srx_uniform(tile_id / a.ktiles), kt = srx_uniform(tile_id - ntile * a.ktiles);
   const int k0 = kt * 64, n0 = ntile * 64;
   const int q = tid & 15, r0 = tid >> 4;
   const __amdgpu_buffer_rsrc_t rx_ = srx_rsrc(mp.x[prob], a.in_bytes), rd_ = srx_rsrc(mp.dy[prob], a.dy_bytes);
@@ -724,7 +735,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WMulti mp) {
     sh_j = ij & 1;
   }
 
-  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mbeg = zsplit * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
   // Four register stages: a workgroup that is alone on its CU (small layers: one row split per CU)
@@ -841,7 +852,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WMulti mp) {
     swrite(0, rd0, rx0);
     __syncthreads();
   }
-  const size_t slab_id = (size_t)prob * a.nsplit + blockIdx.z;
+  const size_t slab_id = (size_t)prob * a.nsplit + zsplit;
   float* slab = a.slab + slab_id * a.Cnw * a.Kw;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -1766,6 +1777,7 @@ extern "C" int srx_conv2d_bwd_weight_multi(const srx_conv2d_t* d, int nprob, int
   const int nsplit = wgrad_nsplit(a.M, tiles, nprob, a.Cnw, a.Kw);
   a.rows_per_split = (int)srx_roundup(srx_cdiv(a.M, nsplit), 32);
   a.nsplit = nsplit;
+  a.nprob = nprob;
   const size_t nslabs = (size_t)nsplit * nprob;
   const size_t need = nslabs * a.Cnw * a.Kw + (any_db ? nslabs * a.Cnw : 0);
   if (need > ws_floats) SRX_FAIL(SRX_E_WORKSPACE, "conv2d_bwd_weight: workspace %zu < %zu floats", ws_floats, need);
@@ -1773,7 +1785,7 @@ extern "C" int srx_conv2d_bwd_weight_multi(const srx_conv2d_t* d, int nprob, int
   WReduce outs{};
   for (int i = 0; i < nprob; ++i) { mp.x[i] = xs[i]; mp.dy[i] = dys[i]; }
   for (int o = 0; o < nout; ++o) { outs.dw[o] = dws[o]; outs.db[o] = dbs ? dbs[o] : nullptr; }
-  dim3 grid((unsigned)tiles, (unsigned)nprob, nsplit);
+  dim3 grid((unsigned)(tiles * nprob * nsplit));
   const double wfl = 2.0 * a.M * d->Cout * a.K * nprob;
   char nm[112];
   if (srx_prof_on())

@@ -6,8 +6,8 @@ flat Adam, bucketed RCCL gradient exchange); differences follow the reference:
 * pre-training minimises L1 instead of MSE (esrgan/trainer.py:163,385);
 * relativistic-average GAN losses on logits, ``BCEWithLogits(real - mean(fake), 1)`` etc.
   (:451-453,468), ``disc_loss = (real + fake) / 2``;
-* the generator is run a second time for its own update (:462) and
-  ``gen_loss = 0.01 * L1 + 1 * VGG + 0.005 * adversarial`` (:469);
+* ``gen_loss = 0.01 * L1 + 1 * VGG + 0.005 * adversarial`` (:469); the reference's second generator forward
+  (:462) recomputes the first bit for bit and is not repeated here;
 * BOTH phases sit inside ``amp.autocast`` (:384,446,461), so without ``--disable-amp`` the generator,
   the discriminator and VGG19 all multiply bf16-rounded operands with fp32 accumulation in both
   phases (``amp_phases``; BASELINE config 4).  ``--disable-amp`` gives exact fp32.
@@ -39,9 +39,13 @@ class ESRGANTrainer(SRGANTrainer):
         """esrgan/trainer.py:444-455 (optimizer step is issued by ``_phase_gen`` after the all-reduce)."""
         low_res, high_res = self._static['low_res'], self._static['high_res']
         self.disc_optimizer.zero_grad()                                          # :444
-        with torch.no_grad():  # only ever used detached (:449); the generator has no BatchNorm state to update
-            super_res = self.generator(low_res)                                  # :447
-        real_output, fake_output = self.discriminator.forward_pair(high_res, super_res)  # :448-449 as one batch
+        # The reference runs the generator twice per step (:447 and again at :462) on the same input with the same
+        # weights -- only the discriminator is updated in between, and RRDBNet has no BatchNorm, dropout or other
+        # state -- so the second forward reproduces the first bit for bit.  It is run once, with its graph kept for
+        # the generator update (as the reference's own SRGAN loop does, srgan/trainer.py:444,455-456): 587 GFLOP and
+        # ~700 launches per step that change no result.
+        self._super_res = self.generator(low_res)                                # :447 (and :462)
+        real_output, fake_output = self.discriminator.forward_pair(high_res, self._super_res.detach())  # :448-449
         d_real = self.bce_loss(real_output, 1.0, shift=F.mean(fake_output))      # :451
         d_fake = self.bce_loss(fake_output, 0.0, shift=F.mean(real_output))      # :452
         disc_loss = F.axpby(d_real, d_fake, 0.5, 0.5)                            # :453
@@ -49,10 +53,9 @@ class ESRGANTrainer(SRGANTrainer):
         self._losses['gan/disc-loss'] = disc_loss.detach()
 
     def _phase_content(self) -> None:
-        """esrgan/trainer.py:459-467: second generator forward, pixel and perceptual terms."""
-        low_res, high_res = self._static['low_res'], self._static['high_res']
+        """esrgan/trainer.py:459-467: pixel and perceptual terms (the generator output of ``_phase_disc`` is reused)."""
+        high_res = self._static['high_res']
         self.gen_optimizer.zero_grad()                                           # :459
-        self._super_res = self.generator(low_res)                                # :462
         pixel = self.l1_loss(self._super_res, high_res)                          # :466
         content = self.vgg_loss(self._super_res, high_res)                       # :467
         self._content = F.axpby(pixel, content, 0.01, 1.0)
