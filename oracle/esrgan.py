@@ -10,14 +10,14 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
-from .srgan import Adam, State, _bn, _leaves, vgg_loss
+from .srgan import Adam, State, _bn, _leaves, conv2d, vgg_loss
 
 
 def residual_dense_block(sd: State, p: str, x: Tensor, scale_ratio: float = 0.2) -> Tensor:
     """ResidualDenseBlock.forward, torchsr/esrgan/residual.py:65-86."""
     def conv(i, inp, act=True):
         k = f'{p}conv{i}.0.' if i < 5 else f'{p}conv5.'
-        out = F.conv2d(inp, sd[k + 'weight'], sd[k + 'bias'], 1, 1)
+        out = conv2d(inp, sd[k + 'weight'], sd[k + 'bias'], 1, 1)
         return F.leaky_relu(out, 0.2) if act else out
     conv1 = conv(1, x)                                              # :81
     conv2 = conv(2, torch.cat((x, conv1), dim=1))                   # :82
@@ -38,18 +38,18 @@ def rrdb(sd: State, p: str, x: Tensor) -> Tensor:
 def generator_forward(sd: State, x: Tensor, prefix: str = '') -> Tensor:
     """Generator.forward, torchsr/esrgan/generator.py:54-81."""
     p = prefix
-    conv1 = F.conv2d(x, sd[p + 'conv1.weight'], sd[p + 'conv1.bias'], 1, 1)        # :69
+    conv1 = conv2d(x, sd[p + 'conv1.weight'], sd[p + 'conv1.bias'], 1, 1)        # :69
     n_blocks = len({k.split('.')[1] for k in sd if k.startswith(p + 'blocks.')})
     block = conv1
     for i in range(n_blocks):                                                        # :70
         block = rrdb(sd, f'{p}blocks.{i}.', block)
-    conv2 = F.conv2d(block, sd[p + 'conv2.weight'], sd[p + 'conv2.bias'], 1, 1)    # :71
+    conv2 = conv2d(block, sd[p + 'conv2.weight'], sd[p + 'conv2.bias'], 1, 1)    # :71
     out = torch.add(conv1, conv2)                                                    # :72
     for name in ('upsample1', 'upsample2'):                                          # :73-78
         out = F.interpolate(out, scale_factor=2, mode='nearest')
-        out = F.leaky_relu(F.conv2d(out, sd[f'{p}{name}.weight'], sd[f'{p}{name}.bias'], 1, 1), 0.2)
-    out = F.leaky_relu(F.conv2d(out, sd[p + 'conv3.0.weight'], sd[p + 'conv3.0.bias'], 1, 1), 0.2)  # :79
-    return F.conv2d(out, sd[p + 'conv4.weight'], sd[p + 'conv4.bias'], 1, 1)        # :80
+        out = F.leaky_relu(conv2d(out, sd[f'{p}{name}.weight'], sd[f'{p}{name}.bias'], 1, 1), 0.2)
+    out = F.leaky_relu(conv2d(out, sd[p + 'conv3.0.weight'], sd[p + 'conv3.0.bias'], 1, 1), 0.2)  # :79
+    return conv2d(out, sd[p + 'conv4.weight'], sd[p + 'conv4.bias'], 1, 1)        # :80
 
 
 D_CONVS = [(2, 3, 2), (5, 6, 1), (8, 9, 2), (11, 12, 1), (14, 15, 2), (17, 18, 1), (20, 21, 2), (23, 24, 1),
@@ -59,9 +59,9 @@ D_CONVS = [(2, 3, 2), (5, 6, 1), (8, 9, 2), (11, 12, 1), (14, 15, 2), (17, 18, 1
 def discriminator_forward(sd: State, x: Tensor, training: bool = True, prefix: str = '') -> Tensor:
     """Discriminator.forward, torchsr/esrgan/discriminator.py:78-95 (returns logits)."""
     p = prefix
-    out = F.leaky_relu(F.conv2d(x, sd[p + 'features.0.weight'], sd[p + 'features.0.bias'], 1, 1), 0.2)
+    out = F.leaky_relu(conv2d(x, sd[p + 'features.0.weight'], sd[p + 'features.0.bias'], 1, 1), 0.2)
     for ci, bi, stride in D_CONVS:
-        out = F.conv2d(out, sd[f'{p}features.{ci}.weight'], None, stride, 1)
+        out = conv2d(out, sd[f'{p}features.{ci}.weight'], None, stride, 1)
         out = F.leaky_relu(_bn(sd, f'{p}features.{bi}.', out, training), 0.2)
     out = torch.flatten(out, 1)
     out = F.leaky_relu(F.linear(out, sd[p + 'classifier.0.weight'], sd[p + 'classifier.0.bias']), 0.2)

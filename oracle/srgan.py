@@ -12,6 +12,7 @@ importable) asserts these functions against the reference's own modules and writ
 everywhere.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import this package.
 """
+import contextlib
 import math
 from typing import Dict, Tuple
 
@@ -20,6 +21,64 @@ import torch.nn.functional as F
 from torch import Tensor
 
 State = Dict[str, Tensor]
+
+# ------------------------------------------------------------------ conv arithmetic of an autocast region
+# The reference's autocast regions (srgan/trainer.py:382-385; esrgan/trainer.py:384,446,461) run their convs in half
+# precision.  BASELINE config 4 asks for bf16 on MI355X, which the product implements as "bf16 products": both operands
+# of every multiplication are rounded to bf16 (round to nearest even), products and sums stay fp32 -- in the forward
+# pass, in the stride-1 data gradient (dy and W rounded) and in the weight gradient (x and dy rounded); strided data
+# gradients and the layers with a 3-channel side keep exact fp32 operands.  ``bf16_products()`` switches this oracle to
+# the same recipe so that an autocast step can be pinned at ~1e-3 instead of "within bf16 rounding of the fp32 step".
+_BF16 = [False]
+
+
+@contextlib.contextmanager
+def bf16_products():
+    old = _BF16[0]
+    _BF16[0] = True
+    try:
+        yield
+    finally:
+        _BF16[0] = old
+
+
+def _r(t: Tensor) -> Tensor:
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _ConvBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad):
+        cout, cin = w.shape[0], w.shape[1]
+        ctx.cfg = (stride, pad, b is not None)
+        ctx.thin_in, ctx.thin_out = (cin <= 4 and cout == 64), (cout <= 4 and cin == 64)
+        ctx.save_for_backward(x, w)
+        if ctx.thin_out:  # the product's thin forward kernel is exact fp32
+            return F.conv2d(x, w, b, stride, pad)
+        return F.conv2d(_r(x), _r(w), b, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, has_b = ctx.cfg
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            exact = stride != 1 or ctx.thin_in
+            dx = torch.nn.grad.conv2d_input(x.shape, w if exact else _r(w), dy if exact else _r(dy), stride=stride, padding=pad)
+        if ctx.needs_input_grad[1]:
+            exact = ctx.thin_in or ctx.thin_out
+            dw = torch.nn.grad.conv2d_weight(x if exact else _r(x), w.shape, dy if exact else _r(dy), stride=stride, padding=pad)
+        if has_b and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3))
+        return dx, dw, db, None, None
+
+
+def conv2d(x: Tensor, w: Tensor, b, stride: int, pad: int) -> Tensor:
+    """``nn.Conv2d`` of the reference: exact fp32, or bf16 products inside ``bf16_products()``."""
+    if _BF16[0]:
+        return _ConvBF16.apply(x, w, b, stride, pad)
+    return F.conv2d(x, w, b, stride, pad)
+
 
 NUM_RESIDUAL = 16  # torchsr/srgan/generator.py:20
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1  # nn.BatchNorm2d defaults used at srgan/residual.py:65
@@ -35,17 +94,17 @@ def _bn(sd: State, p: str, x: Tensor, training: bool) -> Tensor:
 
 def residual_block(sd: State, p: str, x: Tensor, training: bool) -> Tensor:
     """ResidualBlock.forward, torchsr/srgan/residual.py:70-92."""
-    out = F.conv2d(x, sd[p + 'conv1.weight'], None, 1, 1)          # :86
+    out = conv2d(x, sd[p + 'conv1.weight'], None, 1, 1)          # :86
     out = _bn(sd, p + 'bn1.', out, training)                       # :87
     out = F.prelu(out, sd[p + 'prelu.weight'])                     # :88
-    out = F.conv2d(out, sd[p + 'conv2.weight'], None, 1, 1)        # :89
+    out = conv2d(out, sd[p + 'conv2.weight'], None, 1, 1)        # :89
     out = _bn(sd, p + 'bn2.', out, training)                       # :90
     return out + x                                                 # :91
 
 
 def subpixel_layer(sd: State, p: str, x: Tensor) -> Tensor:
     """SubpixelConvolutionLayer.forward, torchsr/srgan/residual.py:31-48."""
-    out = F.conv2d(x, sd[p + 'conv.weight'], sd[p + 'conv.bias'], 1, 1)  # :45
+    out = conv2d(x, sd[p + 'conv.weight'], sd[p + 'conv.bias'], 1, 1)  # :45
     out = F.pixel_shuffle(out, 2)                                        # :46
     return F.prelu(out, sd[p + 'prelu.weight'])                          # :47
 
@@ -53,17 +112,17 @@ def subpixel_layer(sd: State, p: str, x: Tensor) -> Tensor:
 def generator_forward(sd: State, x: Tensor, training: bool = True, prefix: str = '') -> Tensor:
     """Generator.forward, torchsr/srgan/generator.py:60-81."""
     p = prefix
-    conv1 = F.prelu(F.conv2d(x, sd[p + 'conv1.0.weight'], sd[p + 'conv1.0.bias'], 1, 4), sd[p + 'conv1.1.weight'])
+    conv1 = F.prelu(conv2d(x, sd[p + 'conv1.0.weight'], sd[p + 'conv1.0.bias'], 1, 4), sd[p + 'conv1.1.weight'])
     block = conv1
     for i in range(NUM_RESIDUAL):                                  # :76
         block = residual_block(sd, f'{p}blocks.{i}.', block, training)
-    conv2 = F.conv2d(block, sd[p + 'conv2.0.weight'], None, 1, 1)  # :77
+    conv2 = conv2d(block, sd[p + 'conv2.0.weight'], None, 1, 1)  # :77
     conv2 = _bn(sd, p + 'conv2.1.', conv2, training)
     out = torch.add(conv1, conv2)                                  # :78
     n_up = len({k.split('.')[1] for k in sd if k.startswith(p + 'conv_layers.')})
     for u in range(n_up):                                          # :79
         out = subpixel_layer(sd, f'{p}conv_layers.{u}.', out)
-    return F.conv2d(out, sd[p + 'conv3.weight'], sd[p + 'conv3.bias'], 1, 4)  # :80
+    return conv2d(out, sd[p + 'conv3.weight'], sd[p + 'conv3.bias'], 1, 4)  # :80
 
 
 D_CONVS = [(2, 3, 2), (5, 6, 1), (8, 9, 2), (11, 12, 1), (14, 15, 2), (17, 18, 1), (20, 21, 2)]  # (conv, bn, stride)
@@ -72,9 +131,9 @@ D_CONVS = [(2, 3, 2), (5, 6, 1), (8, 9, 2), (11, 12, 1), (14, 15, 2), (17, 18, 1
 def discriminator_forward(sd: State, x: Tensor, training: bool = True, prefix: str = '') -> Tensor:
     """Discriminator.forward, torchsr/srgan/discriminator.py:71-88 (layers :31-69)."""
     p = prefix
-    out = F.leaky_relu(F.conv2d(x, sd[p + 'features.0.weight'], sd[p + 'features.0.bias'], 1, 1), 0.2)
+    out = F.leaky_relu(conv2d(x, sd[p + 'features.0.weight'], sd[p + 'features.0.bias'], 1, 1), 0.2)
     for ci, bi, stride in D_CONVS:
-        out = F.conv2d(out, sd[f'{p}features.{ci}.weight'], None, stride, 1)
+        out = conv2d(out, sd[f'{p}features.{ci}.weight'], None, stride, 1)
         out = F.leaky_relu(_bn(sd, f'{p}features.{bi}.', out, training), 0.2)
     out = torch.flatten(out, 1)                                    # :86
     out = F.leaky_relu(F.linear(out, sd[p + 'classifier.0.weight'], sd[p + 'classifier.0.bias']), 0.2)
@@ -105,7 +164,7 @@ def vgg_features(sd: State, x: Tensor, feature_layer: int = 36, prefix: str = ''
     out = x
     for idx, kind in vgg_feature_layout(feature_layer):
         if kind == 'conv':
-            out = F.conv2d(out, sd[f'{prefix}{idx}.weight'], sd[f'{prefix}{idx}.bias'], 1, 1)
+            out = conv2d(out, sd[f'{prefix}{idx}.weight'], sd[f'{prefix}{idx}.bias'], 1, 1)
         elif kind == 'relu':
             out = F.relu(out)
         else:

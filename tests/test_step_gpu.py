@@ -329,6 +329,24 @@ def test_default_flags_gan_step_is_fp32_like_the_reference(dev):
     assert all(m._st.precision == 0 for m in t.generator.modules() if isinstance(m, Conv2d))
 
 
+def test_pretrain_step_bf16_products_vs_bf16_oracle(dev):
+    """The reference's one SRGAN autocast region, the pre-training body (torchsr/srgan/trainer.py:382-385), on bf16
+    products against the oracle rounding the same operands (oracle.srgan.bf16_products): loss within 2e-3, at the
+    fixture size and at batch 16."""
+    gold = np.load(os.path.join(GOLDEN, 'srgan_steps.npz'))
+    s_lr, s_hr = (int(v) for v in gold['b16_seeds'])
+    for batch, lr, hr in ((2, torch.from_numpy(gold['low_res']), torch.from_numpy(gold['high_res'])),
+                          (16, seeded_input((16, 3, 24, 24), s_lr), seeded_input((16, 3, 96, 96), s_hr))):
+        t = make_trainer(dev, False, batch=batch, disable_amp=False)
+        orc = oracle_for(t)
+        with O.bf16_products():
+            want = orc.pretrain_step(lr, hr)
+        got = t.pretrain_step(lr.to(dev), hr.to(dev)).item()
+        assert abs(got - want) <= 2e-3 * want, (batch, got, want)
+        fp32 = float(gold['pre_losses'][0] if batch == 2 else gold['b16_pre_loss'])
+        assert abs(want - fp32) > 3e-5 * fp32   # ... and bf16 products are a different arithmetic from the fp32 golden
+
+
 def test_precision_switch_on_a_warmed_model(dev):
     """Switching a model's conv precision after it has run (packed weights exist, pack tables built) must not
     leave any layer reading a stale layout: fp32 -> bf16 -> fp32 reproduces the first fp32 result exactly."""
