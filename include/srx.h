@@ -86,8 +86,11 @@ typedef struct srx_conv2d {
   int32_t act;        /* fused epilogue: SRX_ACT_NONE / RELU / LRELU (after bias) */
   float   slope;      /* LeakyReLU negative_slope */
   int32_t up;         /* 0/1, or 2: F.interpolate(scale_factor=2, mode='nearest') of the
-                         input fused into the gather (esrgan/generator.py:73,76); H,W are
-                         then the size of the tensor BEFORE upsampling */
+                         input fused into the gather (esrgan/generator.py:73,76): the forward reads
+                         pixel (h >> 1, w >> 1), the upsampled tensor is never written; H,W are then
+                         the size of the tensor BEFORE upsampling (stride 1, no shuffle).  The data
+                         gradient is taken at the upsampled size in scratch and summed per 2x2 block,
+                         the weight gradient reads a scratch copy (both from `ws`) */
   int32_t precision;  /* 0: exact fp32 MFMAs.  1: bf16 products with fp32 accumulation for the forward
                          and the stride-1 data gradient -- the reference's torch.cuda.amp.autocast
                          region (srgan/trainer.py:379-383, esrgan/trainer.py:418-484); tensors stay

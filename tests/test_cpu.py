@@ -304,8 +304,11 @@ def test_descriptor_validation_without_a_gpu():
     assert rc != 0 and 'Cin_s' in msg
     rc, msg = plan_error(16, 24, 24, 64, 64, 60, 60, 3, 3, 1, 1, 2, 0, 0.0, 0, 0)              # shuffle needs Cout % 16
     assert rc != 0 and 'shuffle' in msg
-    rc, msg = plan_error(16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 2, 0)              # fused upsample
-    assert rc == 2 and 'not implemented' in msg                                                 # SRX_E_UNSUPPORTED
+    rc, msg = plan_error(16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 3, 0)              # upsample factor
+    assert rc != 0 and 'up must be' in msg
+    rc, msg = plan_error(16, 24, 24, 64, 64, 64, 64, 3, 3, 2, 1, 0, 0, 0.0, 2, 0)              # fused upsample: stride 1 only
+    assert rc != 0 and 'up = 2' in msg
+    assert plan_error(16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 2, 0)[0] == 0 and out[3] >= 256  # 48x48 output rows
     rc, msg = plan_error(16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 7)              # precision
     assert rc != 0 and 'precision' in msg
     rc, msg = plan_error(16, 2, 2, 64, 64, 64, 64, 5, 5, 1, 0, 0, 0, 0.0, 0, 0)                # empty output

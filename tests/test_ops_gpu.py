@@ -306,6 +306,44 @@ def test_maxpool_relu_backward(dev):
     assert torch.equal(dx.cpu(), want)
 
 
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, True, 2), (1, 9, 13, 64, 32, False, 0), (16, 32, 32, 64, 64, True, 0)])
+@pytest.mark.parametrize('bf16', [False, True])
+def test_conv_with_fused_nearest_upsample(dev, case, bf16):
+    """up = 2: ``conv(F.interpolate(x, scale_factor=2, mode='nearest'))`` (esrgan/generator.py:73-78) with the upsampled
+    tensor never written -- forward, input gradient (sum over each 2x2 block of the upsampled gradient), weight and bias
+    gradients against torch on the CPU, incl. ESRGAN's own 64->64 layer at 16x32x32 -> 64x64 (that one without its
+    LeakyReLU: among 4 M activations a few land within rounding of 0 and take the other slope on the two sides)."""
+    from torchsr_amd.layers import Conv2d, set_conv_precision
+    n, h, w, cin, cout, bias, act = case
+    torch.manual_seed(h * w)
+    conv = Conv2d(cin, cout, 3, 1, 1, bias=bias, act=act, slope=0.2, up=2)
+    ref = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=bias)
+    ref.load_state_dict(conv.state_dict())
+    conv = conv.to(dev)
+    if bf16:
+        set_conv_precision(conv, 'bf16')
+    x = rnd((n, cin, h, w), 1)
+    xc = x.clone().requires_grad_(True)
+    xin = xc.to(torch.bfloat16).float() if bf16 else xc
+    wref = ref.weight.to(torch.bfloat16).float() if bf16 else ref.weight
+    yc = TF.conv2d(TF.interpolate(xin, scale_factor=2, mode='nearest'), wref, ref.bias, 1, 1)
+    if act:
+        yc = TF.leaky_relu(yc, 0.2)
+    go = rnd(yc.shape, 2)
+    yc.backward(go)
+    xg = nhwc(x).to(dev).requires_grad_(True)
+    yg = conv(xg)
+    assert yg.shape == (n, 2 * h, 2 * w, cout)
+    assert rel_err(nchw(yg.cpu(), cout), yc) < 2e-4
+    yg.backward(nhwc(go).to(dev))
+    tol = 1e-2 if bf16 else 2e-4   # (bf16: the product also rounds dy in the gradients, torch's autograd does not)
+    assert rel_err(nchw(xg.grad.cpu(), cin), xc.grad) < tol
+    if not bf16:
+        assert rel_err(conv.weight.grad, ref.weight.grad) < tol
+    if bias:
+        assert rel_err(conv.bias.grad, ref.bias.grad) < 2e-4
+
+
 def test_row_tile_plan(dev):
     """The SRGAN residual conv at the reference batch runs as 256 workgroups of 36 pixels (forward and
     data gradient); a layer the row tile does not cover falls back to the generic plan."""

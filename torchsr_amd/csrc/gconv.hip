@@ -35,6 +35,10 @@ struct GArgs {
   int Ho, Wo, Co;
   int out_stride, oh_off, ow_off;
   int out_shuffle, in_shuffle;
+  // up != 0: the conv reads a nearest-neighbour x2 upsampling of `in` that is never materialised (esrgan/generator.py:73,76:
+  // F.interpolate(scale_factor=2) feeding a conv).  Hi, Wi are the UPSAMPLED extents (bounds of the taps); the pixel
+  // (ih, iw) is fetched from (ih >> 1, iw >> 1) of the stored [N][Hi/2][Wi/2][Ci] tensor.
+  int up;
   int act; float slope;
   int linear_out;
   int mtiles;
@@ -140,7 +144,9 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       const int th = tap / a.ntw, tw = tap - th * a.ntw;
       const int dh = a.dh0 + th, dw = a.dw0 + tw;
       int koff;
-      if (a.in_shuffle) {
+      if (a.up) {
+        koff = c;  // the pixel part of the offset depends on the row's parity: added per load (gload)
+      } else if (a.in_shuffle) {
         const int ij = c / a.in_shuffle, cc = c - ij * a.in_shuffle;
         koff = ((2 * dh + (ij >> 1)) * (2 * a.Wi) + 2 * dw + (ij & 1)) * a.Ci + cc;
       } else {
@@ -168,8 +174,9 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       const int ih0 = mh * a.in_stride, iw0 = mw * a.in_stride;
       rih[p] = ih0;
       riw[p] = iw0;
-      rbase[p] = 4u * (unsigned)(a.in_shuffle ? ((n * 2 * a.Hi + 2 * ih0) * (2 * a.Wi) + 2 * iw0) * a.Ci
-                                              : ((n * a.Hi + ih0) * a.Wi + iw0) * a.Ci);
+      rbase[p] = 4u * (unsigned)(a.up ? n * (a.Hi >> 1) * (a.Wi >> 1) * a.Ci
+                                 : a.in_shuffle ? ((n * 2 * a.Hi + 2 * ih0) * (2 * a.Wi) + 2 * iw0) * a.Ci
+                                                : ((n * a.Hi + ih0) * a.Wi + iw0) * a.Ci);
     } else {
       rih[p] = INVALID; riw[p] = 0; rbase[p] = 0;
     }
@@ -202,7 +209,9 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
     for (int p = 0; p < RA; ++p) {
       const int ih = rih[p] + dh, iw = riw[p] + dw;
       const bool ok = live && ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
-      ra[p] = srx_bload(rin, ok ? rbase[p] + (unsigned)kt.y : 0xffffffffu, 0);  // out of range reads 0
+      // (a.up is wave-uniform: a scalar select; without upsampling the pixel offset sits in rbase + kt.y already)
+      const unsigned pix = a.up ? 4u * (unsigned)(((ih >> 1) * (a.Wi >> 1) + (iw >> 1)) * a.Ci) : 0u;
+      ra[p] = srx_bload(rin, ok ? rbase[p] + pix + (unsigned)kt.y : 0xffffffffu, 0);  // out of range reads 0
     }
 #pragma unroll
     for (int p = 0; p < RB; ++p)
@@ -1001,7 +1010,8 @@ int check_desc(const srx_conv2d_t* d) {
   SRX_REQUIRE(d->Cin_s >= d->Cin && d->Cin_s % 4 == 0, "conv2d: Cin_s must be a multiple of 4 and >= Cin");
   SRX_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
   SRX_REQUIRE(d->shuffle == 0 || d->shuffle == 2, "conv2d: shuffle must be 0 or 2");
-  if (d->up != 0 && d->up != 1) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: fused nearest upsample not implemented");
+  SRX_REQUIRE(d->up == 0 || d->up == 1 || d->up == 2, "conv2d: up must be 0 / 1 (none) or 2 (nearest x2 in the gather)");
+  if (d->up == 2) SRX_REQUIRE(d->stride == 1 && !d->shuffle, "conv2d: up = 2 needs stride 1 and no PixelShuffle");
   if (d->shuffle) {
     SRX_REQUIRE(d->Cout % 16 == 0, "conv2d: shuffle needs Cout multiple of 16");
     SRX_REQUIRE(d->Cout_s >= d->Cout / 4 && d->Cout_s % 4 == 0, "conv2d: bad Cout_s for shuffle");
@@ -1011,9 +1021,10 @@ int check_desc(const srx_conv2d_t* d) {
   }
   SRX_REQUIRE(d->act == SRX_ACT_NONE || d->act == SRX_ACT_RELU || d->act == SRX_ACT_LRELU, "conv2d: bad act");
   SRX_REQUIRE(d->precision == 0 || d->precision == 1, "conv2d: precision must be 0 (fp32) or 1 (bf16 products)");
-  const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  const int uf = d->up == 2 ? 2 : 1;
+  const int Ho = (uf * d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (uf * d->W + 2 * d->pad - d->KW) / d->stride + 1;
   SRX_REQUIRE(Ho > 0 && Wo > 0, "conv2d: empty output");
-  SRX_REQUIRE((int64_t)d->N * d->H * d->W < (1 << 24) && (int64_t)d->N * Ho * Wo < (1 << 24),
+  SRX_REQUIRE((int64_t)d->N * uf * d->H * uf * d->W < (1 << 24) && (int64_t)d->N * Ho * Wo < (1 << 24),
               "conv2d: more than 2^24 pixels per call; tile the image");
   SRX_REQUIRE((int64_t)d->N * d->H * d->W * d->Cin_s < (1LL << 30) - 4, "conv2d: input above 4 GiB; tile the image");
   SRX_REQUIRE(d->pad < 16000 && d->KH < 16000, "conv2d: kernel too large");
@@ -1024,8 +1035,9 @@ int pad_rows(int c) { return c <= 32 ? 32 : (int)srx_roundup(c, 64); }  // rows 
 
 Geo fwd_geo(const srx_conv2d_t* d) {
   Geo g;
-  g.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
-  g.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  const int uf = d->up == 2 ? 2 : 1;  // extents the conv sees
+  g.Ho = (uf * d->H + 2 * d->pad - d->KH) / d->stride + 1;
+  g.Wo = (uf * d->W + 2 * d->pad - d->KW) / d->stride + 1;
   g.Ck = (int)srx_roundup(d->Cin, 4);  // k-space channels; the tensor's channel stride Cin_s may be larger
   g.K = d->KH * d->KW * g.Ck;
   g.Kp = (int)srx_roundup(g.K, BK);
@@ -1336,8 +1348,20 @@ extern "C" size_t srx_conv2d_fwd_ws_floats(const srx_conv2d_t* d) {
   return plan_ws_floats(fwd_plan(d, g));
 }
 
+// up = 2 outside the forward pass: the data gradient is taken at the upsampled size into scratch and summed over each
+// 2x2 block (the adjoint of nearest upsampling), the weight gradient reads a scratch copy of the upsampled input.
+static srx_conv2d_t upsampled_desc(const srx_conv2d_t* d) {
+  srx_conv2d_t h = *d;
+  h.up = 0; h.H = 2 * d->H; h.W = 2 * d->W;
+  return h;
+}
+static size_t upsampled_floats(const srx_conv2d_t* d) { return (size_t)d->N * 2 * d->H * 2 * d->W * d->Cin_s; }
+extern "C" int srx_upsample_nearest2x_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+extern "C" int srx_upsample_nearest2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+
 extern "C" size_t srx_conv2d_bwd_data_ws_floats(const srx_conv2d_t* d) {
   if (check_desc(d)) return 0;
+  if (d->up == 2) { const srx_conv2d_t h = upsampled_desc(d); return upsampled_floats(d) + srx_conv2d_bwd_data_ws_floats(&h); }
   if (d->stride != 1) return 0;
   BwdClass cls[16];
   size_t total;
@@ -1370,6 +1394,7 @@ static int wgrad_nsplit(int M, int64_t tiles, int nprob, int Cnw, int Kw) {
 
 extern "C" size_t srx_conv2d_bwd_weight_multi_ws_floats(const srx_conv2d_t* d, int nprob) {
   if (check_desc(d) || nprob < 1 || nprob > WG_MAXP) return 0;
+  if (d->up == 2) { const srx_conv2d_t h = upsampled_desc(d); return nprob * upsampled_floats(d) + srx_conv2d_bwd_weight_multi_ws_floats(&h, nprob); }
   if (srx_thin_wgrad_applicable(d))  // (one call per problem) + the column-sum scratch of an optional bias gradient
     return srx_thin_wgrad_ws_floats(d) + srx_colsum_ws_floats((int64_t)d->N * d->H * d->W, d->Cout);
   const Geo g = fwd_geo(d);
@@ -1582,7 +1607,7 @@ static int conv_fwd_impl(const srx_conv2d_t* d, const float* x, const float* wpk
   SRX_REQUIRE(x && wpk && y, "conv2d_fwd: null pointer");
   if (residual && d->shuffle) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_fwd: residual with PixelShuffle is not implemented");
   hipStream_t st = srx_stream(stream);
-  if (srx_thin_fwd_applicable(d) && !bn_partials && !residual) return srx_thin_fwd(d, x, wpk, bias, y, d->Cout, st);
+  if (srx_thin_fwd_applicable(d) && !bn_partials && !residual && d->up != 2) return srx_thin_fwd(d, x, wpk, bias, y, d->Cout, st);
   if (srx_rt36_applicable(d) && out_scale == 1.f)
     return srx_rt36_run(d, x, wpk, bias, residual, y, bn_partials, d->act, d->slope, st);
   if (srx_rt36_applicable(d)) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_fwd_residual: out_scale != 1 on the 36-pixel row tile");
@@ -1590,7 +1615,8 @@ static int conv_fwd_impl(const srx_conv2d_t* d, const float* x, const float* wpk
   GArgs a{};
   a.in = x; a.w = wpk; a.bias = bias; a.part = nullptr;
   set_mgrid(a, d->N, g.Ho, g.Wo);
-  a.Hi = d->H; a.Wi = d->W; a.Ci = d->Cin_s;
+  a.up = d->up == 2;
+  a.Hi = (a.up ? 2 : 1) * d->H; a.Wi = (a.up ? 2 : 1) * d->W; a.Ci = d->Cin_s;
   a.in_stride = d->stride; a.nth = d->KH; a.ntw = d->KW; a.dh0 = -d->pad; a.dw0 = -d->pad;
   a.Ck = g.Ck; a.K = g.K; a.Kp = g.Kp;
   a.Cn = d->Cout;
@@ -1631,6 +1657,14 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(dy && wpk_bwd && dx, "conv2d_bwd_data: null pointer");
   SRX_REQUIRE(d->stride <= 4, "conv2d_bwd_data: stride > 4 unsupported");
+  if (d->up == 2) {
+    if (accumulate || act_out) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: up = 2 with accumulate / a folded activation");
+    const srx_conv2d_t h = upsampled_desc(d);
+    const size_t tmp = upsampled_floats(d);
+    SRX_REQUIRE(ws && ws_floats >= tmp + srx_conv2d_bwd_data_ws_floats(&h), "conv2d_bwd_data: workspace too small for up = 2");
+    if (int rc = conv_bwd_data_impl(&h, dy, wpk_bwd, ws, 0, nullptr, 1.f, 0, 0, ws + tmp, ws_floats - tmp, stream)) return rc;
+    return srx_upsample_nearest2x_bwd(ws, dx, d->N, d->H, d->W, d->Cin_s, stream);
+  }
   const bool rt36 = srx_rt36_applicable(d) && !act_out;  // (the row-tile kernel has no masked epilogue)
   if (accumulate && (d->stride != 1 || srx_thin_dgrad_applicable(d) || rt36))
     SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: accumulate is implemented for stride-1 layers on the generic kernel only");
@@ -1717,6 +1751,19 @@ extern "C" int srx_conv2d_bwd_weight_multi(const srx_conv2d_t* d, int nprob, int
   SRX_REQUIRE(nprob >= 1 && nprob <= WG_MAXP && per_out >= 1 && nprob % per_out == 0,
               "conv2d_bwd_weight_multi: 1..%d problems, a whole number of outputs", WG_MAXP);
   SRX_REQUIRE(xs && dys && dws && ws, "conv2d_bwd_weight: null pointer");
+  if (d->up == 2) {
+    const srx_conv2d_t h = upsampled_desc(d);
+    const size_t tmp = upsampled_floats(d);
+    SRX_REQUIRE(ws_floats >= nprob * tmp + srx_conv2d_bwd_weight_multi_ws_floats(&h, nprob), "conv2d_bwd_weight: workspace too small for up = 2");
+    const float* up_x[WG_MAXP];
+    for (int i = 0; i < nprob; ++i) {
+      SRX_REQUIRE(xs[i], "conv2d_bwd_weight: null tensor in problem %d", i);
+      up_x[i] = ws + (size_t)i * tmp;
+      if (int rc = srx_upsample_nearest2x_fwd(xs[i], ws + (size_t)i * tmp, d->N, d->H, d->W, d->Cin_s, stream)) return rc;
+    }
+    return srx_conv2d_bwd_weight_multi(&h, nprob, per_out, up_x, dys, dws, accumulate, dbs, ws + nprob * tmp,
+                                       ws_floats - nprob * tmp, stream);
+  }
   const int nout = nprob / per_out;
   bool any_db = false;
   for (int i = 0; i < nprob; ++i) SRX_REQUIRE(xs[i] && dys[i], "conv2d_bwd_weight: null tensor in problem %d", i);

@@ -12,7 +12,8 @@ class Generator(nn.Module):
     """``Generator(num_rrdb_blocks=23)``; ``forward([N,3,h,w]) -> [N,3,4h,4w]``.
 
     No BatchNorm, no PixelShuffle: two nearest-neighbour x2 upsamples, each followed by a
-    conv + LeakyReLU (fused epilogue).
+    conv + LeakyReLU; the upsampled tensors are never written (the conv gathers pixel (h >> 1, w >> 1))
+    and the LeakyReLU is the conv's epilogue.
     """
 
     # tiled inference (torchsr_amd/test.py): the true receptive field radius is ~350 low-resolution pixels, more than a
@@ -25,8 +26,8 @@ class Generator(nn.Module):
         self.blocks = nn.Sequential(*[ResidualInResidualDenseBlock(channels=64, growth_channels=32, scale_ratio=0.2)
                                       for _ in range(num_rrdb_blocks)])
         self.conv2 = Conv2d(64, 64, kernel_size=3, stride=1, padding=1)
-        self.upsample1 = Conv2d(64, 64, kernel_size=3, stride=1, padding=1, act=ACT_LRELU, slope=0.2)
-        self.upsample2 = Conv2d(64, 64, kernel_size=3, stride=1, padding=1, act=ACT_LRELU, slope=0.2)
+        self.upsample1 = Conv2d(64, 64, kernel_size=3, stride=1, padding=1, act=ACT_LRELU, slope=0.2, up=2)
+        self.upsample2 = Conv2d(64, 64, kernel_size=3, stride=1, padding=1, act=ACT_LRELU, slope=0.2, up=2)
         self.conv3 = nn.Sequential(Conv2d(64, 64, kernel_size=3, stride=1, padding=1, act=ACT_LRELU, slope=0.2),
                                    Marker('LeakyReLU(0.2) (conv epilogue)'))
         self.conv4 = Conv2d(64, 3, kernel_size=3, stride=1, padding=1)
@@ -36,8 +37,8 @@ class Generator(nn.Module):
         conv2 = self.conv2(self.blocks(conv1))
         out = F.axpby(conv1, conv2, 1.0, 1.0)                       # torch.add, generator.py:72
         out = F.cut_point('g.tail', out)                            # data parallel: upsample* / conv3 / conv4 gradients go out first
-        out = self.upsample1(F.upsample_nearest2x(out))             # :73-75
-        out = self.upsample2(F.upsample_nearest2x(out))             # :76-78
+        out = self.upsample1(out)                                   # :73-75 (nearest x2 in the conv's gather)
+        out = self.upsample2(out)                                   # :76-78
         return self.conv4(self.conv3[0](out))                       # :79-80
 
     def forward(self, x: Tensor) -> Tensor:

@@ -195,9 +195,10 @@ def flatten_nchw(x: Tensor) -> Tensor:
 class ConvState:
     """Per-layer host state: geometry descriptors and packed weight copies."""
 
-    def __init__(self, cin, cout, k, stride, pad, shuffle=0, act=ACT_NONE, slope=0.0):
+    def __init__(self, cin, cout, k, stride, pad, shuffle=0, act=ACT_NONE, slope=0.0, up=0):
         self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
         self.shuffle, self.act, self.slope = shuffle, act, float(slope)
+        self.up = 2 if up == 2 else 0  # nearest x2 upsampling of the input fused into the gather (srx_conv2d_t::up)
         self.cin_s = round4(cin)
         self.cout_s = round4(cout // 4) if shuffle else round4(cout)
         self._descs = {}
@@ -211,19 +212,21 @@ class ConvState:
         d = self._descs.get((n, h, w, self.precision))
         if d is None:
             d = Conv2dDesc(n, h, w, self.cin, self.cin_s, self.cout, self.cout_s, self.k, self.k, self.stride,
-                           self.pad, self.shuffle, self.act, self.slope, 0, self.precision)
+                           self.pad, self.shuffle, self.act, self.slope, self.up, self.precision)
             self._descs[(n, h, w, self.precision)] = d
         return d
 
     def out_rows(self, n, h, w) -> int:
         """Rows of the output matrix (pixels the conv computes; before any PixelShuffle)."""
-        ho = (h + 2 * self.pad - self.k) // self.stride + 1
-        wo = (w + 2 * self.pad - self.k) // self.stride + 1
+        uf = 2 if self.up == 2 else 1
+        ho = (uf * h + 2 * self.pad - self.k) // self.stride + 1
+        wo = (uf * w + 2 * self.pad - self.k) // self.stride + 1
         return n * ho * wo
 
     def out_shape(self, n, h, w):
-        ho = (h + 2 * self.pad - self.k) // self.stride + 1
-        wo = (w + 2 * self.pad - self.k) // self.stride + 1
+        uf = 2 if self.up == 2 else 1
+        ho = (uf * h + 2 * self.pad - self.k) // self.stride + 1
+        wo = (uf * w + 2 * self.pad - self.k) // self.stride + 1
         if self.shuffle:
             return (n, 2 * ho, 2 * wo, self.cout_s)
         return (n, ho, wo, self.cout_s)
@@ -1014,7 +1017,8 @@ class FoldedConv:
                 if self.prelu.weight.numel() != 1 or src.act != ACT_NONE:
                     raise RuntimeError('FoldedConv: PReLU must have one parameter and follow a linear conv')
                 act, slope = ACT_LRELU, float(self.prelu.weight.detach().reshape(()).item())
-            self.st = ConvState(src.cin, src.cout, src.k, src.stride, src.pad, shuffle=src.shuffle, act=act, slope=slope)
+            self.st = ConvState(src.cin, src.cout, src.k, src.stride, src.pad, shuffle=src.shuffle, act=act, slope=slope,
+                                up=src.up)
             self.st.precision = src.precision
         self._key = key
 

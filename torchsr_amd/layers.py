@@ -43,15 +43,16 @@ class Conv2d(nn.Conv2d):
     """nn.Conv2d on NHWC activations with an optional fused epilogue.
 
     ``act``: fused ReLU / LeakyReLU after the bias; ``shuffle=2`` fuses the
-    ``nn.PixelShuffle(2)`` that follows the conv in srgan/residual.py:27-28.
+    ``nn.PixelShuffle(2)`` that follows the conv in srgan/residual.py:27-28; ``up=2`` fuses the
+    ``F.interpolate(scale_factor=2, mode='nearest')`` that precedes it in esrgan/generator.py:73-78.
     """
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, act=ACT_NONE,
-                 slope=0.0, shuffle=0):
+                 slope=0.0, shuffle=0, up=0):
         super().__init__(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
                          bias=bias)
         self._st = F.ConvState(in_channels, out_channels, kernel_size, stride, padding, shuffle=shuffle, act=act,
-                               slope=slope)
+                               slope=slope, up=up)
 
     def forward(self, x: Tensor, want_stats: bool = False):
         y, part = F.conv2d(x, _w(self.weight), _w(self.bias), self._st, want_stats, self.weight)
@@ -65,7 +66,7 @@ class Conv2d(nn.Conv2d):
 
     def __deepcopy__(self, memo):
         new = Conv2d(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0],
-                     self.bias is not None, self._st.act, self._st.slope, self._st.shuffle)
+                     self.bias is not None, self._st.act, self._st.slope, self._st.shuffle, self._st.up)
         new.load_state_dict(self.state_dict())
         return new
 
