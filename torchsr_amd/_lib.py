@@ -11,7 +11,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libsrx_hip.so')
+LIB_PATH = os.environ.get('SRX_LIB') or os.path.join(CSRC, 'libsrx_hip.so')  # SRX_LIB: developer A/B builds on one GPU box
 SOURCES = ['api.cpp', 'gconv.hip', 'thin.hip', 'rowtile.hip', 'augment.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'optim.hip']
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3

@@ -87,7 +87,7 @@ constexpr int INVALID = -20000;  // coordinate that fails every bounds check
 // 32 k-values are rounded to bf16 when they are written to LDS (64-byte rows) and multiplied by two
 // v_mfma_f32_32x32x16_bf16 per 32x32 block instead of sixteen fp32 MFMAs -- the loop is then bound by the
 // L2 -> LDS stream, not by the matrix pipe.
-template <int BM, int BN, int WM, int WN, int KS, int XR, int PR>
+template <int BM, int BN, int WM, int WN, int KS, int XR, int PR, int UP = 0>
 __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   static_assert(XR == 0 || (XR == 16 && KS == 1), "extra rows: 16, without the in-workgroup K split");
   static_assert(PR == 0 || XR == 0, "the 16-row extension is fp32 only");
@@ -144,7 +144,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       const int th = tap / a.ntw, tw = tap - th * a.ntw;
       const int dh = a.dh0 + th, dw = a.dw0 + tw;
       int koff;
-      if (a.up) {
+      if (UP) {
         koff = c;  // the pixel part of the offset depends on the row's parity: added per load (gload)
       } else if (a.in_shuffle) {
         const int ij = c / a.in_shuffle, cc = c - ij * a.in_shuffle;
@@ -174,7 +174,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       const int ih0 = mh * a.in_stride, iw0 = mw * a.in_stride;
       rih[p] = ih0;
       riw[p] = iw0;
-      rbase[p] = 4u * (unsigned)(a.up ? n * (a.Hi >> 1) * (a.Wi >> 1) * a.Ci
+      rbase[p] = 4u * (unsigned)(UP ? n * (a.Hi >> 1) * (a.Wi >> 1) * a.Ci
                                  : a.in_shuffle ? ((n * 2 * a.Hi + 2 * ih0) * (2 * a.Wi) + 2 * iw0) * a.Ci
                                                 : ((n * a.Hi + ih0) * a.Wi + iw0) * a.Ci);
     } else {
@@ -205,13 +205,21 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
     const bool live = kc < kc_end;  // wave-uniform
     const int2 kt = ktab[(live ? kc - kc_beg : 0) * 8 + q];
     const int dh = (int)(short)(kt.x & 0xffff), dw = kt.x >> 16;
+    if (UP) {  // compile time: a run-time test here, even a scalar one, cost the fp32 step 1.2 % (same-box A/B)
 #pragma unroll
-    for (int p = 0; p < RA; ++p) {
-      const int ih = rih[p] + dh, iw = riw[p] + dw;
-      const bool ok = live && ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
-      // (a.up is wave-uniform: a scalar select; without upsampling the pixel offset sits in rbase + kt.y already)
-      const unsigned pix = a.up ? 4u * (unsigned)(((ih >> 1) * (a.Wi >> 1) + (iw >> 1)) * a.Ci) : 0u;
-      ra[p] = srx_bload(rin, ok ? rbase[p] + pix + (unsigned)kt.y : 0xffffffffu, 0);  // out of range reads 0
+      for (int p = 0; p < RA; ++p) {
+        const int ih = rih[p] + dh, iw = riw[p] + dw;
+        const bool ok = live && ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
+        const unsigned pix = 4u * (unsigned)(((ih >> 1) * (a.Wi >> 1) + (iw >> 1)) * a.Ci);  // source pixel of the upsampled one
+        ra[p] = srx_bload(rin, ok ? rbase[p] + pix + (unsigned)kt.y : 0xffffffffu, 0);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < RA; ++p) {
+        const int ih = rih[p] + dh, iw = riw[p] + dw;
+        const bool ok = live && ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
+        ra[p] = srx_bload(rin, ok ? rbase[p] + (unsigned)kt.y : 0xffffffffu, 0);  // out of range reads 0
+      }
     }
 #pragma unroll
     for (int p = 0; p < RB; ++p)
@@ -567,7 +575,9 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
 
 template <int BM, int BN, int WM, int WN, int KS, int XR, int PR>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KS) void gconv_kernel(const GArgs a) {
-  gconv_body<BM, BN, WM, WN, KS, XR, PR>(a, blockIdx.x);
+  // the fused-upsample gather is a second copy of the body, entered by ONE scalar branch: the common loop is untouched
+  if (a.up) gconv_body<BM, BN, WM, WN, KS, XR, PR, 1>(a, blockIdx.x);
+  else gconv_body<BM, BN, WM, WN, KS, XR, PR, 0>(a, blockIdx.x);
 }
 
 // several independent gather-GEMMs in one launch: the stride-parity classes of a strided data
