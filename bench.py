@@ -15,11 +15,11 @@ at N > 1 the gradient buckets are all-reduced over RCCL as the backward pass com
 Rank 0 prints ONE JSON line.  At N = 1 it also carries
   "parity":       the four losses of the FIRST step (seeded default-init weights) on the HIP path and on the
                   CPU oracle from the same weights and batch; ``rel`` is the generator-loss difference;
-  "roofline":     the dominant (kernel, GEMM shape) pair by device time, measured live with HIP events on the
-                  launch stream in an instrumented eager pass of the same step: algorithmic FLOPs of its
-                  launches / their event-measured duration, against the 157.3 TFLOP/s fp32 MFMA peak of
-                  MI355X; ``traffic`` = HBM bytes per launch of that pair from the committed rocprofv3 --pmc
-                  passes (profiles/r02_traffic.json), null when that pair was not profiled;
+  "roofline":     the dominant kernel by device time, measured live with HIP events on the launch stream in an
+                  instrumented eager pass of the same step: algorithmic FLOPs of its launches / their
+                  event-measured duration, against the 157.3 TFLOP/s fp32 MFMA peak of MI355X; ``by_shape``
+                  lists the layer shapes it serves, ``traffic`` = HBM bytes per launch of the heaviest one from
+                  the committed rocprofv3 --pmc passes (profiles/r02_traffic.json; null if not profiled);
                   ``north_star`` = the 3x3 64->64 residual conv at 16x24x24 timed the way the step runs it,
                   as back-to-back launches inside a replayed hipGraph (HIP events on the replay stream);
   "cpu_baseline": the CPU oracle (oracle/srgan.py, stock torch ops) running the identical step on the host
@@ -171,27 +171,35 @@ def roofline_pass(trainer, lr, hr, reps=2):
             for k, v in sorted(pairs.items(), key=lambda kv: -kv[1][0]):
                 f.write(f'{v[0] / reps * 1e3:9.1f} us/step {v[2] // reps:3d} launches {v[0] / v[2] * 1e3:8.1f} us each '
                         f'{v[1] / (v[0] * 1e-3) / 1e12:6.1f} TF/s  {k}\n')
-    full, (ms, fl, cnt) = max(pairs.items(), key=lambda kv: kv[1][0])
-    kname, _, shape = full.partition(' MxNxK=')
+    # the dominant kernel = the kernel (template instance) with the most device time per step, over all the layer
+    # shapes it serves; its shapes are listed one by one, each with the HBM traffic of the committed --pmc passes
+    kname, (ms, fl, cnt) = max(kernels.items(), key=lambda kv: kv[1][0])
     achieved = fl / (ms * 1e-3) / 1e12
     table = {k: {'ms_per_step': round(v[0] / reps, 4), 'gflop_per_step': round(v[1] / reps / 1e9, 3),
                  'launches_per_step': v[2] // reps, 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 2)}
              for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][0])}
-    # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE: tools/pmc_traffic.py) of
-    # tools/bench_kernels.py restricted to ONE layer shape; counters cannot be read from inside the process
-    traffic, alg_bytes = None, None
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE: tools/pmc_run.sh) of
+    # tools/pmc_workloads.py restricted to ONE layer shape; counters cannot be read from inside the process
     tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
-    if os.path.exists(tpath):
-        ent = json.load(open(tpath)).get(full)
-        if ent:
-            traffic, alg_bytes = round(ent['hbm_bytes_per_launch']), ent.get('algorithmic_bytes_per_launch')
+    measured = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    shapes = []
+    for full, v in sorted(pairs.items(), key=lambda kv: -kv[1][0]):
+        if full.split(' MxNxK=')[0] != kname:
+            continue
+        ent = measured.get(full) or {}
+        shapes.append({'MxNxK': full.split(' MxNxK=')[1], 'launches_per_step': v[2] // reps,
+                       'avg_launch_us': round(v[0] / v[2] * 1e3, 2), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 2),
+                       'traffic': round(ent['hbm_bytes_per_launch']) if ent else None,
+                       'algorithmic_bytes': ent.get('algorithmic_bytes_per_launch')})
+    top = shapes[0] if shapes else {}
     return {
-        'bound': 'mfma', 'kernel': kname, 'shape_MxNxK': shape, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS,
-        'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS, 4), 'traffic': traffic,
-        'algorithmic_bytes_per_launch': alg_bytes,
+        'bound': 'mfma', 'kernel': kname, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': round(achieved / PEAK_TFLOPS, 4),
+        'traffic': top.get('traffic'), 'traffic_shape_MxNxK': top.get('MxNxK'),
+        'algorithmic_bytes_per_launch': top.get('algorithmic_bytes'),
         'avg_launch_us': round(ms / cnt * 1e3, 2), 'launches_per_step': cnt // reps,
         'gflop_per_launch': round(fl / cnt / 1e9, 4),
-        'conv_ms_per_step': round(total_ms / reps, 3), 'by_kernel': table,
+        'conv_ms_per_step': round(total_ms / reps, 3), 'by_shape': shapes, 'by_kernel': table,
     }
 
 
