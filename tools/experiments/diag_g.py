@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import srgan as O  # noqa: E402
 from oracle.weights import closed_form_state, seeded_input  # noqa: E402
 from torchsr_amd.srgan.generator import Generator  # noqa: E402
