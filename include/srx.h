@@ -145,6 +145,11 @@ int srx_conv2d_fwd_residual(const srx_conv2d_t* d, const float* x, const float* 
  * place of the torch.cat adjoint (esrgan/residual.py:81-85). */
 int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
                         int accumulate, float* ws, size_t ws_floats, void* stream);
+/* dx = conv_transpose(dy, W) + addend (laid out like dx, not dx itself): the gradient of `x` in `x + f(conv(x))` --
+ * the skip connection of the residual block (srgan/residual.py:86-91) -- without autograd's separate add pass.
+ * Stride-1 layers. */
+int srx_conv2d_bwd_data_add(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, const float* addend,
+                            float* dx, float* ws, size_t ws_floats, void* stream);
 /* The same followed by the backward of the activation that PRODUCED this conv's input, for the input channels
  * [c_lo, c_hi): dx[.., c] = (accumulate ? dx[.., c] : 0) + conv_transpose(dy, W)[.., c], then for c in the range
  * dx[.., c] *= (x[.., c] > 0 ? 1 : slope), x = that activation's output = the conv's saved input (laid out like dx).

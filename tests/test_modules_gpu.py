@@ -128,6 +128,41 @@ def test_discriminator_forward_pair_equals_two_calls(dev, kind, n, size):
         assert rel(er, b(real)) < 1e-5 and rel(ef, b(fake)) < 1e-5
 
 
+def test_residual_block_one_node_equals_layer_by_layer(dev):
+    """Under a trainer (gradients accumulate straight into the flat buffers) every ResidualBlock is one autograd node
+    whose conv1 data gradient carries the skip connection's gradient in its epilogue; without one it is five nodes
+    plus autograd's add.  Same kernels otherwise: outputs bit-equal, gradients and BatchNorm state to rounding."""
+    from torchsr_amd import functional as F
+    from torchsr_amd.optim import FlatParams
+    from torchsr_amd.srgan.generator import Generator
+    torch.manual_seed(21)
+    a, b = Generator().to(dev).train(), Generator().to(dev).train()
+    b.load_state_dict(a.state_dict())
+    flat = FlatParams(a)
+    x = torch.rand(2, 3, 12, 12, device=dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    old = F.direct_grads[0]
+    try:
+        F.direct_grads[0] = True
+        assert F.residual_block_fused_ok(a.blocks[0])
+        ya = a(xa)
+        ya.square().mean().backward()
+        F.direct_grads[0] = False
+        assert not F.residual_block_fused_ok(b.blocks[0])
+        yb = b(xb)
+        yb.square().mean().backward()
+    finally:
+        F.direct_grads[0] = old
+    assert torch.equal(ya, yb)
+    assert rel(xa.grad, xb.grad) < 1e-5
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel(pa.grad, pb.grad) < 1e-5, k
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        if 'running_' in k or 'num_batches' in k:
+            assert torch.equal(va, vb), k
+    assert flat.grad.abs().sum() > 0
+
+
 def test_vgg_loss_vs_golden(dev):
     from torchsr_amd import functional as F
     from torchsr_amd.srgan.loss import VGGLoss

@@ -75,6 +75,7 @@ _SIGS = {
     'srx_conv2d_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_conv2d_fwd_residual': (_I, [_D, _P, _P, _P, _P, _F, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_data': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
+    'srx_conv2d_bwd_data_add': (_I, [_D, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_data_act': (_I, [_D, _P, _P, _P, _F, _I, _I, _I, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_weight': (_I, [_D, _P, _P, _P, _I, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_weight_multi_ws_floats': (_Z, [_D, _I]),

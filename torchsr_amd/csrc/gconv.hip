@@ -1663,7 +1663,7 @@ extern "C" int srx_conv2d_fwd_residual(const srx_conv2d_t* d, const float* x, co
 
 static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx, int accumulate,
                               const float* act_out, float act_slope, int c_lo, int c_hi, float* ws, size_t ws_floats,
-                              void* stream) {
+                              void* stream, const float* addend = nullptr) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(dy && wpk_bwd && dx, "conv2d_bwd_data: null pointer");
   SRX_REQUIRE(d->stride <= 4, "conv2d_bwd_data: stride > 4 unsupported");
@@ -1676,6 +1676,8 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
     return srx_upsample_nearest2x_bwd(ws, dx, d->N, d->H, d->W, d->Cin_s, stream);
   }
   const bool rt36 = srx_rt36_applicable(d) && !act_out;  // (the row-tile kernel has no masked epilogue)
+  if (addend && (accumulate || d->stride != 1 || srx_thin_dgrad_applicable(d) || d->up == 2))
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data_add: stride-1 layers without accumulate only");
   if (accumulate && (d->stride != 1 || srx_thin_dgrad_applicable(d) || rt36))
     SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: accumulate is implemented for stride-1 layers on the generic kernel only");
   if (act_out && (d->stride != 1 || srx_thin_dgrad_applicable(d)))
@@ -1689,7 +1691,7 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
   size_t total;
   const int nc = bwd_classes(d, cls, total);
   if (rt36)  // 3x3 / stride 1 / pad 1: one class, same geometry as the forward, flipped taps
-    return srx_rt36_run(d, dy, wpk_bwd + cls[0].woff, nullptr, nullptr, dx, nullptr, SRX_ACT_NONE, 0.f, st);
+    return srx_rt36_run(d, dy, wpk_bwd + cls[0].woff, nullptr, addend, dx, nullptr, SRX_ACT_NONE, 0.f, st);
   bool any_empty = false;
   for (int i = 0; i < nc; ++i) any_empty |= (cls[i].K == 0);
   if (any_empty) {
@@ -1719,7 +1721,7 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
     a.out = dx;
     a.in_bytes = (unsigned)dy_bytes;
     a.w_bytes = (unsigned)((size_t)pad_rows(d->Cin) * c.Kp * sizeof(float));
-    a.add = accumulate ? dx : nullptr;
+    a.add = accumulate ? dx : addend;
     a.oscale = 1.f;
     if (act_out) { a.mask = act_out; a.mask_slope = act_slope; a.mask_lo = c_lo; a.mask_hi = c_hi; }
     if (d->stride == 1) {
@@ -1741,6 +1743,12 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
 extern "C" int srx_conv2d_bwd_data(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
                                    int accumulate, float* ws, size_t ws_floats, void* stream) {
   return conv_bwd_data_impl(d, dy, wpk_bwd, dx, accumulate, nullptr, 1.f, 0, 0, ws, ws_floats, stream);
+}
+
+extern "C" int srx_conv2d_bwd_data_add(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, const float* addend,
+                                       float* dx, float* ws, size_t ws_floats, void* stream) {
+  SRX_REQUIRE(addend && addend != dx, "conv2d_bwd_data_add: the addend must be a tensor of its own");
+  return conv_bwd_data_impl(d, dy, wpk_bwd, dx, 0, nullptr, 1.f, 0, 0, ws, ws_floats, stream, addend);
 }
 
 extern "C" int srx_conv2d_bwd_data_act(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, const float* x,

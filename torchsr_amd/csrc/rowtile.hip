@@ -159,23 +159,29 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   const __amdgpu_buffer_rsrc_t rres = srx_rsrc(a.res ? a.res : a.out, a.out_bytes);  // eval-mode skip input
   const unsigned obase = ((unsigned)m0 * 64u + (unsigned)col + 256u * h2) * 4u;
   float s1 = 0.f, s2 = 0.f;
+  const unsigned obase4 = h2 == 0 ? ((unsigned)m0 * 64u + (unsigned)col) * 4u : 0xffffffffu;  // half 0 stores
+  // the addend (eval-mode skip input, or the skip connection's gradient when this is a data gradient) is requested for
+  // all 20 rows before the first store: a load issued behind a store cannot be consumed until that store has landed
+  float rv[16], rv4[4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    rv[r] = a.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)obase, ((r & 3) + 8 * (r >> 2)) * 256, 0)) : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    rv4[i] = a.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)obase4, (32 + i) * 256, 0)) : 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float v = acc[r] + bv;
     s1 += v;
     s2 += v * v;
-    float o = v > 0.f ? v : v * a.slope;
-    if (a.res)
-      o += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)obase, ((r & 3) + 8 * (r >> 2)) * 256, 0));
+    const float o = (v > 0.f ? v : v * a.slope) + rv[r];
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rout, obase, ((r & 3) + 8 * (r >> 2)) * 256, 0);
   }
-  const unsigned obase4 = h2 == 0 ? ((unsigned)m0 * 64u + (unsigned)col) * 4u : 0xffffffffu;  // half 0 stores
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float v = acc4[i] + bv;
     if (h2 == 0) { s1 += v; s2 += v * v; }
-    float o = v > 0.f ? v : v * a.slope;
-    if (a.res) o += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)obase4, (32 + i) * 256, 0));
+    const float o = (v > 0.f ? v : v * a.slope) + rv4[i];
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rout, obase4, (32 + i) * 256, 0);
   }
   if (a.part) {  // per-channel (sum, sum of squares) of this workgroup's 36 rows

@@ -507,6 +507,120 @@ def bn_act(y, part, bn, act=ACT_NONE, slope=0.0, prelu: Optional[Tensor] = None,
                         int(groups))
 
 
+class _ResidualBlock(Function):
+    """SRGAN's ``ResidualBlock.forward`` -- ``x + BN2(conv2(PReLU(BN1(conv1(x)))))`` (srgan/residual.py:86-91) -- as ONE
+    autograd node in training mode.  Same kernels as the layer-by-layer path; what the node buys is the backward
+    pass: autograd would add the skip connection's gradient to conv1's input gradient in a pass of its own (17 such
+    adds per generator backward); here that sum is the epilogue of conv1's data gradient
+    (``srx_conv2d_bwd_data_add``).  Parameter gradients accumulate straight into the flat ``.grad`` buffers; the
+    conv weight gradients go to the ``WeightGradQueue`` when one is installed.
+    """
+
+    @staticmethod
+    def forward(ctx, x: Tensor, block, *params):
+        ctx.set_materialize_grads(False)
+        x = _chk(x, 'residual_block.input')
+        n, h, w, c = x.shape
+        m = n * h * w
+        L, s = _lib.lib(), _stream()
+        convs, bns = (block.conv1, block.conv2), (block.bn1, block.bn2)
+        descs, ys, stats = [], [], []
+        inp = x
+        for i in range(2):
+            st, bn = convs[i]._st, bns[i]
+            d = st.desc(n, h, w)
+            dref = C.byref(d)
+            st.pack(convs[i].weight, d)
+            y = torch.empty_like(x)
+            part = torch.empty((L.srx_conv2d_stat_rows(dref), c, 2), dtype=torch.float32, device=x.device)
+            nws = L.srx_conv2d_fwd_ws_floats(dref)
+            call('srx_conv2d_fwd', dref, _p(inp), _p(st.wpk_fwd), None, _p(y), _p(part), _p(_ws(nws, x)) if nws else None, nws, s)
+            mean = torch.empty(c, dtype=torch.float32, device=x.device)
+            invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+            out = torch.empty_like(x)
+            momentum = 0.1 if bn.momentum is None else bn.momentum
+            g, b = bn.weight.detach(), bn.bias.detach()
+            if i == 0:   # BN1 + PReLU
+                call('srx_bn_train_fwd', _p(y), _p(part), part.shape[0], m, c, 1, bn.eps, momentum, _p(g), _p(b), None, _p(out),
+                     ACT_PRELU, 0.0, _p(block.prelu.weight.detach()), _p(mean), _p(invstd), _p(bn.running_mean),
+                     _p(bn.running_var), _p(bn.num_batches_tracked), s)
+            else:        # BN2 + skip connection
+                call('srx_bn_train_fwd', _p(y), _p(part), part.shape[0], m, c, 1, bn.eps, momentum, _p(g), _p(b), _p(x), _p(out),
+                     ACT_NONE, 0.0, None, _p(mean), _p(invstd), _p(bn.running_mean), _p(bn.running_var),
+                     _p(bn.num_batches_tracked), s)
+            descs.append(d)
+            ys.append(y)
+            stats += [mean, invstd]
+            if i == 0:
+                a1 = inp = out
+        ctx.block, ctx.descs = block, descs
+        ctx.packs = (convs[0]._st.wpk_bwd, convs[1]._st.wpk_bwd)
+        ctx.save_for_backward(x, ys[0], a1, ys[1], *stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        x, y1, a1, y2, mean1, inv1, mean2, inv2 = ctx.saved_tensors
+        block = ctx.block
+        dout = _chk(dout, 'residual_block.grad')
+        n, h, w, c = x.shape
+        m = n * h * w
+        L, s = _lib.lib(), _stream()
+        queue = wgrad_queue[0]
+
+        def bn_bwd(dz_in, y, mean, invstd, bn, act, prelu):
+            sums = torch.empty(2 * c + 4, dtype=torch.float32, device=x.device)
+            dy = torch.empty_like(y)
+            nws = L.srx_bn_bwd_ws_floats(m, c)
+            pw = None if prelu is None else prelu.detach()
+            call('srx_bn_act_bwd', _p(dz_in), _p(y), _p(mean), _p(invstd), _p(bn.weight.detach()), _p(bn.bias.detach()),
+                 _p(sums), _p(dy), m, c, 1, act, 0.0, _p(pw), 1, _p(bn.weight.grad), _p(bn.bias.grad),
+                 None if prelu is None else _p(prelu.grad), _p(_ws(nws, y)), nws, s)
+            return dy
+
+        def wgrad(conv, d, inp, dy):
+            if queue is not None:
+                queue.add(d, _p(inp), _p(dy), _p(conv.weight.grad), None, (inp, dy))
+                return
+            dref = C.byref(d)
+            nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
+            call('srx_conv2d_bwd_weight', dref, _p(inp), _p(dy), _p(conv.weight.grad), 1, None, _p(_ws(nws, inp)), nws, s)
+
+        dy2 = bn_bwd(dout, y2, mean2, inv2, block.bn2, ACT_NONE, None)
+        wgrad(block.conv2, ctx.descs[1], a1, dy2)
+        da1 = torch.empty_like(x)
+        dref = C.byref(ctx.descs[1])
+        nws = L.srx_conv2d_bwd_data_ws_floats(dref)
+        call('srx_conv2d_bwd_data', dref, _p(dy2), _p(ctx.packs[1]), _p(da1), 0, _p(_ws(nws, x)) if nws else None, nws, s)
+        dy1 = bn_bwd(da1, y1, mean1, inv1, block.bn1, ACT_PRELU, block.prelu.weight)
+        wgrad(block.conv1, ctx.descs[0], x, dy1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            dref = C.byref(ctx.descs[0])
+            nws = L.srx_conv2d_bwd_data_ws_floats(dref)
+            call('srx_conv2d_bwd_data_add', dref, _p(dy1), _p(ctx.packs[0]), _p(dout), _p(dx), _p(_ws(nws, x)) if nws else None,
+                 nws, s)
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+def residual_block_fused_ok(block) -> bool:
+    """The one-node form applies in training mode with autograd on, when every parameter of the block accumulates
+    its gradient straight into a flat ``.grad`` buffer (``direct_grads``: the trainers)."""
+    if not (block.training and torch.is_grad_enabled() and direct_grads[0]):
+        return False
+    ps = (block.conv1.weight, block.bn1.weight, block.bn1.bias, block.prelu.weight, block.conv2.weight, block.bn2.weight,
+          block.bn2.bias)
+    return block.bn1.training and block.bn2.training and block.prelu.weight.numel() == 1 and \
+        all(p.requires_grad and _sink(p) is not None for p in ps)
+
+
+def residual_block(x: Tensor, block) -> Tensor:
+    ps = (block.conv1.weight, block.bn1.weight, block.bn1.bias, block.prelu.weight, block.conv2.weight, block.bn2.weight,
+          block.bn2.bias)
+    return _ResidualBlock.apply(x, block, *ps)
+
+
 # --------------------------------------------------------------------------- activations
 class _PReLU(Function):
     @staticmethod

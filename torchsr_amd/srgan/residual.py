@@ -51,6 +51,8 @@ class ResidualBlock(nn.Module):
                 f = self.__dict__.setdefault('_folded', (F.FoldedConv(self.conv1, self.bn1, self.prelu),
                                                          F.FoldedConv(self.conv2, self.bn2, None)))
             return f[1](f[0](x), residual=x)
+        if F.residual_block_fused_ok(self):  # training under a trainer: one autograd node (skip gradient fused into conv1's dgrad)
+            return F.residual_block(x, self)
         y, part = self.conv1(x, want_stats=True) if self.bn1.training else (self.conv1(x), None)
         out = self.bn1(y, part, act=ACT_PRELU, prelu=self.prelu.weight)
         y, part = self.conv2(out, want_stats=True) if self.bn2.training else (self.conv2(out), None)
