@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ prelu, int rpb,
                                                             int64_t rows_per_group) {
   __shared__ f32x4 red[2][256];
-  __shared__ float redp[256];
+  __shared__ float redp[4];
   if (act == SRX_ACT_PRELU) slope = prelu[0];
   const int cq = C / 4, nrl = 256 / cq;
   const int tid = threadIdx.x;
@@ -172,7 +172,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
   red[0][tid] = s;
   red[1][tid] = s2;
-  redp[tid] = sp;
+  // PReLU slope gradient: a fixed butterfly inside each wave, then the four waves in order (one thread walking
+  // 256 LDS words took as long as the streaming part of this kernel on the generator's 2.4 MB tensors)
+  sp = srx_wave_sum(sp);
+  if ((tid & 63) == 0) redp[tid >> 6] = sp;
   __syncthreads();
   float* o = ws + (size_t)blockIdx.x * (2 * C + 4);
   if (tid < cq) {
@@ -181,11 +184,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 4; ++e) { o[tid * 4 + e] = t[e]; o[C + tid * 4 + e] = t2[e]; }
   }
-  if (tid == 0) {
-    float t = 0.f;
-    for (int k = 0; k < 256; ++k) t += redp[k];
-    o[2 * C] = t;
-  }
+  if (tid == 0) o[2 * C] = (redp[0] + redp[1]) + (redp[2] + redp[3]);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ ws, int rows, int C, int groups,
