@@ -73,9 +73,13 @@ class Discriminator(nn.Module):
         launch, and the 75 MB classifier weight is streamed once.  Training-mode BatchNorm keeps the two calls
         apart (own batch statistics, running statistics updated for ``first`` and then for ``second``).  Falls
         back to two calls when a layer's tiles would straddle the two halves (``_pair_fits``)."""
-        n = first.shape[0]
-        if second.shape != first.shape or (self.training and not self._pair_fits(2 * n, first.shape[2], first.shape[3])):
-            return self(first), self(second)
-        x4 = torch.cat([F.to_nhwc(first, 4), F.to_nhwc(second, 4)], dim=0)
+        return self.forward_pair_nhwc(F.to_nhwc(first, 4), F.to_nhwc(second, 4))
+
+    def forward_pair_nhwc(self, first4: Tensor, second4: Tensor):
+        """``forward_pair`` on NHWC ``[N,S,S,4]`` inputs (4th channel zero), as the trainers call it."""
+        n = first4.shape[0]
+        if second4.shape != first4.shape or (self.training and not self._pair_fits(2 * n, first4.shape[1], first4.shape[2])):
+            return self.forward_nhwc(first4), self.forward_nhwc(second4)
+        x4 = torch.cat([first4, second4], dim=0)
         out = self.forward_nhwc(x4, groups=2 if self.training else 1)
         return F.split_batch(out, n)

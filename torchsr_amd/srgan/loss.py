@@ -106,11 +106,14 @@ class VGGLoss(nn.Module):
         stack as ONE batch and the backward pass is the data-gradient chain of the source half with the ReLU
         backwards folded into it (``functional.frozen_conv_stack``).  ``target_features`` may carry the second term
         when the caller has already computed it."""
-        src4 = F.to_nhwc(source, 4)
+        with torch.no_grad():
+            tgt4 = None if target is None else F.to_nhwc(target, 4)
+        return self.forward_nhwc(F.to_nhwc(source, 4), tgt4, target_features)
+
+    def forward_nhwc(self, src4: Tensor, tgt4: Tensor = None, target_features: Tensor = None) -> Tensor:
+        """``forward`` on NHWC ``[N,H,W,4]`` images (4th channel zero), as the trainers call it."""
         if target_features is not None:
             fs, _ = F.frozen_conv_stack(src4, None, self._stack())
             return F.l1_loss(fs, target_features)
-        with torch.no_grad():
-            tgt4 = F.to_nhwc(target, 4)
-        fs, ft = F.frozen_conv_stack(src4, tgt4, self._stack())
+        fs, ft = F.frozen_conv_stack(src4, tgt4.detach(), self._stack())
         return F.l1_loss(fs, ft)

@@ -366,10 +366,14 @@ class SRGANTrainer:
     def _phase_disc(self) -> None:
         """trainer.py:442-450: G forward, D on real and fake, D backward (down to the 'd.head' cut when data
         parallel: the classifier's gradients are complete then, the convolutions' follow in ``_phase_disc_body``)."""
-        low_res, high_res = self._static['low_res'], self._static['high_res']
+        # the three networks exchange NHWC tensors directly: the batch is converted once, the super-resolved image
+        # never goes through the NCHW module boundary (8 layout passes forward, 4 backward in the reference's call form)
+        with torch.no_grad():
+            low4 = F.to_nhwc(self._static['low_res'], 4)
+            self._high4 = F.to_nhwc(self._static['high_res'], 4)
         self.disc_optimizer.zero_grad()                                      # :442
-        self._super_res = self.generator(low_res)                            # :444
-        p_real, p_fake = self.discriminator.forward_pair(high_res, self._super_res.detach())  # :446-447 as one batch
+        self._super_res = self.generator.forward_nhwc(low4)                  # :444
+        p_real, p_fake = self.discriminator.forward_pair_nhwc(self._high4, self._super_res.detach())  # :446-447 as one batch
         d_real = self.bce_loss(p_real, 1.0)                                  # :446
         d_fake = self.bce_loss(p_fake, 0.0)                                  # :447
         disc_loss = F.axpby(d_real, d_fake, 1.0, 1.0)                        # :448
@@ -382,20 +386,20 @@ class SRGANTrainer:
     def _phase_content(self) -> None:
         """trainer.py:453-455: VGG19 perceptual loss (does not need the updated discriminator)."""
         self.gen_optimizer.zero_grad()                                       # :453
-        self._content = self.vgg_loss(self._super_res, self._static['high_res'])  # :455
+        self._content = self.vgg_loss.forward_nhwc(self._super_res, self._high4)  # :455
 
     def _phase_gen(self) -> None:
         """trainer.py:451,456-468: D update, adversarial term through the UPDATED D, G backward (down to the
         'g.tail' cut when data parallel)."""
         self.disc_optimizer.step()                                           # :451
         with no_weight_grad():  # C5: D's weight gradients are never consumed here
-            adversarial = self.bce_loss(self.discriminator(self._super_res), 1.0)  # :456
+            adversarial = self.bce_loss(self.discriminator.forward_nhwc(self._super_res), 1.0)  # :456
         gen_loss = F.axpby(self._content, adversarial, 1.0, 0.001)           # :457
         self._backward(gen_loss)                                             # :468
         self._losses['gan/content-loss'] = self._content.detach()
         self._losses['gan/adversarial-loss'] = adversarial.detach()
         self._losses['gan/train-loss'] = gen_loss.detach()
-        self._super_res = self._content = None
+        self._super_res = self._content = self._high4 = None
 
     def _phase_gen_body(self) -> None:
         self._resume('g.tail')
