@@ -62,3 +62,19 @@ def test_device_data_pipeline_cli(dev, tmp_path, monkeypatch):
           '--pretrain-epochs', '1', '--disable-amp', '--seed', '5', '--device-data', '--skip-image-save',
           '--vgg-weights', 'random'])
     assert os.path.exists('srgan-gan-latest.pth')
+
+
+def test_esrgan_train_cli(dev, tmp_path, monkeypatch):
+    """`torchsr train --model esrgan` end to end (23-RRDB generator, 128x128 crops, bf16 products: the default AMP
+    flags): both phases, the per-epoch PSNR test on a shard smaller than the batch, the four checkpoint files."""
+    from torchsr_amd.torchsr import main
+    monkeypatch.chdir(tmp_path)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'SLURM_NTASKS'):
+        monkeypatch.delenv(k, raising=False)
+    main(['train', '--model', 'esrgan', '--train-dir', 'synthetic:8', '--batch-size', '2', '--epochs', '1',
+          '--pretrain-epochs', '1', '--seed', '7', '--vgg-weights', 'random', '--skip-image-save'])
+    for f in ('esrgan-psnr-best.pth', 'esrgan-psnr-latest.pth', 'esrgan-gan-best.pth', 'esrgan-gan-latest.pth'):
+        assert os.path.exists(f), f
+    ckpt = torch.load('esrgan-gan-latest.pth', map_location='cpu')
+    assert ckpt['phase'] == 'esrgan-gan' and len(ckpt['state']) == 702
+    assert all(torch.isfinite(v).all() for v in ckpt['state'].values() if v.is_floating_point())

@@ -216,3 +216,26 @@ def test_esrgan_bf16_step_vs_bf16_oracle(dev):
     # (an operand that sits on a bf16 rounding boundary rounds the other way when it differs in its last fp32 bit, which
     # moves that product by 2^-9: the noise floor under Adam's normalisation is higher than in fp32 -- measured 2.1 %)
     assert moved_wrong <= 5e-2 * total, (moved_wrong, total)
+
+
+def test_esrgan_segmented_step_equals_fused(dev):
+    """The data-parallel form of the ESRGAN step (backward paused at 'd.head' / 'g.tail', gradient buckets between hipGraph
+    segments; world size 1, so the all-reduces are no-ops) against the single-graph step."""
+    from torchsr_amd import functional as F
+    from torchsr_amd.ddp import BackwardCuts, GradBuckets
+    gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
+    lr, hr = torch.from_numpy(gold['low_res']).to(dev), torch.from_numpy(gold['high_res']).to(dev)
+    ta, tb = make_trainer(dev), make_trainer(dev, use_graphs=True)
+    tb.distributed = True
+    tb._cuts = BackwardCuts()
+    tb.gen_sync = GradBuckets(tb.gen_flat, (tb.gen_tail_bucket,), tb.generator)
+    tb.disc_sync = GradBuckets(tb.disc_flat, (tb.disc_head_bucket,), tb.discriminator)
+    tail = 3 * (64 * 64 * 9 + 64) + 3 * 64 * 9 + 3   # upsample1/2, conv3.0, conv4 (+ the flat buffer's alignment padding)
+    assert tail <= tb.gen_sync.slices[1].numel() < tail + 4
+    for step in range(4):
+        la, lb = ta.gan_step(lr, hr), tb.gan_step(lr, hr)
+        for k in la:
+            assert la[k].item() == pytest.approx(lb[k].item(), rel=1e-5, abs=1e-7), (step, k)
+        assert not tb._cuts.pairs
+    assert {'gan.disc.head', 'gan.disc.body', 'gan.content', 'gan.gen.head', 'gan.gen.body', 'gan.gopt'} <= set(tb._graphs)
+    assert F.cut_hook[0] is None
