@@ -46,6 +46,33 @@ def test_tiled_inference_equals_untiled(dev):
     assert (whole - tiled).abs().max().item() <= 1e-4 * whole.abs().max().item()
 
 
+def test_1080p_inference_windows_vs_oracle(dev):
+    """BASELINE config 5 at full size: one 1920x1080 frame -> 7680x4320 through the tiled eval path, checked against the
+    CPU oracle's generator on windows of the frame (two image corners, where the zero padding is the real border, the
+    centre, and an arbitrary interior point).  A 40x40 window of the input is cut out with 48 pixels of context -- more than
+    the generator's receptive field -- so the oracle's output on the cut-out equals the full frame's there."""
+    from oracle import srgan as O
+    from oracle.weights import closed_form_state
+    from torchsr_amd.srgan.generator import Generator
+    from torchsr_amd.test import upscale
+    gen = Generator().to(dev)
+    sd = closed_form_state(gen.state_dict())
+    gen.load_state_dict(sd)
+    g = torch.Generator().manual_seed(11)
+    frame = torch.rand(1, 3, 1080, 1920, generator=g)
+    out = upscale(gen, frame.to(dev))
+    assert out.shape == (1, 3, 4320, 7680) and torch.isfinite(out).all()
+    win, ctx = 40, 48
+    for y0, x0 in ((0, 0), (1080 - win, 1920 - win), (520, 940), (301, 1203)):
+        ya, xa, yb, xb = max(0, y0 - ctx), max(0, x0 - ctx), min(1080, y0 + win + ctx), min(1920, x0 + win + ctx)
+        with torch.no_grad():
+            ref = O.generator_forward(sd, frame[:, :, ya:yb, xa:xb].contiguous(), training=False)
+        ref = ref[:, :, 4 * (y0 - ya):4 * (y0 - ya + win), 4 * (x0 - xa):4 * (x0 - xa + win)]
+        got = out[:, :, 4 * y0:4 * (y0 + win), 4 * x0:4 * (x0 + win)].cpu()
+        err = (got - ref).abs().max().item()
+        assert err <= 1e-4 * max(ref.abs().max().item(), 1e-3), (y0, x0, err)
+
+
 def test_device_data_pipeline_cli(dev, tmp_path, monkeypatch):
     """--device-data: images decoded once, crop / flips / bicubic x1/4 on the GPU."""
     from PIL import Image

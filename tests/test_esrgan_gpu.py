@@ -165,6 +165,31 @@ def test_esrgan_config4_geometry_step_vs_reference_trainer(dev):
     assert_digests(gold['ds_keys'], t.discriminator.state_dict(), gold['b4_gan_d_digest'], 'D b4')
 
 
+def test_esrgan_config4_full_batch_step_vs_reference_trainer(dev):
+    """BASELINE config 4 at its FULL size -- 23 RRDBs, 128x128 crops, batch 16 per GPU -- tied to the
+    reference trainer without a 16-crop CPU run: the batch is the batch-4 fixture's four crops repeated four times.  Every
+    loss is a batch mean, every gradient the gradient of one, the discriminator's BatchNorm statistics (biased, as training
+    mode normalises with) are those of the four crops: losses and post-step parameters must equal the batch-4 golden's.
+    (Only the running variances differ -- PyTorch stores the unbiased estimate, n/(n-1) -- and are left out.)"""
+    gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
+    s_lr, s_hr = (int(v) for v in gold['b4_seeds'])
+    lr = seeded_input((4, 3, 32, 32), s_lr).repeat(4, 1, 1, 1).to(dev)
+    hr = seeded_input((4, 3, 128, 128), s_hr).repeat(4, 1, 1, 1).to(dev)
+    t = make_trainer(dev, batch=16)
+    losses = t.gan_step(lr, hr)
+    got = [losses[k].item() for k in LOSS_KEYS]
+    for g, w in zip(got, gold['b4_gan_losses']):
+        assert abs(g - w) <= TOL * max(abs(w), 1e-3), (got, list(gold['b4_gan_losses']))
+    assert_digests(gold['gs_keys'], t.generator.state_dict(), gold['b4_gan_g_digest'], 'G b16')
+    keep = [i for i, k in enumerate(gold['ds_keys']) if 'running_var' not in str(k)]
+    assert_digests(gold['ds_keys'][keep], t.discriminator.state_dict(), gold['b4_gan_d_digest'][keep], 'D b16')
+    # the same step in the precision config 4 is quoted at (autocast in both phases): within bf16 rounding of it
+    tb = make_trainer(dev, batch=16, disable_amp=False)
+    lb = tb.gan_step(lr, hr)
+    for k, w in zip(LOSS_KEYS, gold['b4_gan_losses']):
+        assert abs(lb[k].item() - w) <= 2e-2 * max(abs(w), 1e-3), (k, lb[k].item(), w)
+
+
 def test_esrgan_gan_step_with_bf16_products(dev):
     """Without --disable-amp both ESRGAN phases sit in the reference's autocast regions (esrgan/trainer.py:384,446,
     461): every generic conv of G, D and VGG19 multiplies bf16-rounded operands (fp32 accumulation, fp32 everything
