@@ -159,6 +159,30 @@ int srx_conv2d_bwd_data_add(const srx_conv2d_t* d, const float* dy, const float*
  * applies that slice's LeakyReLU backward.  Stride-1 layers, generic kernel; range in whole channel quads. */
 int srx_conv2d_bwd_data_act(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, const float* x, float slope,
                             int c_lo, int c_hi, int accumulate, float* dx, float* ws, size_t ws_floats, void* stream);
+/* The general form of the three calls above, for a chain of blocks whose tensors have different channel strides:
+ *   dx[m][c] = (accumulate ? dx[m][c] : 0) + out_scale * conv_transpose(dy, W)[m][c]
+ *              + (c < addend_channels ? addend_scale * addend[m * addend_ld + c] : 0),
+ * followed by the activation backward on [c_lo, c_hi) when act_out is given.  ESRGAN's RRDB trunk (esrgan/generator.py:
+ * 54-56,70; esrgan/residual.py:81-86,125-128) keeps every dense block's input in the first 64 channels of that block's
+ * 192-channel buffer: with this call conv5's data gradient takes `scale_ratio` and the block's own output gradient
+ * (the `+ x` of :86, a dense 64-channel tensor) in its epilogue, and conv1's writes the block's input gradient as a
+ * dense tensor, adding what the other four convs left in the first 64 channels of the shared gradient buffer --
+ * the three elementwise passes per block that autograd runs for `out * 0.2 + x` are gone.  Zero fields mean: no
+ * accumulate, scales 1, addend laid out like dx, all channels.  Stride-1 layers on the generic kernel; an addend
+ * excludes accumulate; strides and channel counts in whole quads. */
+typedef struct srx_dgrad_epilogue {
+  int accumulate;
+  float out_scale;
+  const float* addend;
+  int addend_ld;
+  int addend_channels;
+  float addend_scale;
+  const float* act_out;
+  float act_slope;
+  int c_lo, c_hi;
+} srx_dgrad_epilogue_t;
+int srx_conv2d_bwd_data_ex(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
+                           const srx_dgrad_epilogue_t* e, float* ws, size_t ws_floats, void* stream);
 /* dw (OIHW) = autograd of nn.Conv2d wrt its weight; accumulate != 0 adds into dw (a .grad buffer)
  * instead of overwriting it.  db (may be NULL; not for shuffle layers) receives the bias gradient
  * sum_m dy[m][co] under the same flag: the kernel stages every dy row anyway.  The same flag exists on srx_colsum, srx_linear_bwd_weight,
@@ -176,6 +200,12 @@ size_t srx_conv2d_bwd_weight_multi_ws_floats(const srx_conv2d_t* d, int nprob);
 int srx_conv2d_bwd_weight_multi(const srx_conv2d_t* d, int nprob, int per_out, const float* const* xs,
                                 const float* const* dys, float* const* dws, int accumulate, float* const* dbs,
                                 float* ws, size_t ws_floats, void* stream);
+/* The same with one multiplier per output (out_scales: nprob / per_out host floats, NULL = all 1), applied to the
+ * weight and the bias gradient: the dy handed over stands for out_scale * dy.  The dense block's conv5 sees the
+ * block's output gradient times scale_ratio (esrgan/residual.py:86), which then is never written out. */
+int srx_conv2d_bwd_weight_multi_scaled(const srx_conv2d_t* d, int nprob, int per_out, const float* const* xs,
+                                       const float* const* dys, float* const* dws, int accumulate, float* const* dbs,
+                                       const float* out_scales, float* ws, size_t ws_floats, void* stream);
 
 /* ------------------------------------------------- elementwise / reductions */
 /* out[c] = sum_m x[m][c]  (bias gradient of Conv2d / Linear); ws >= 2*rows*C floats */
@@ -198,6 +228,10 @@ int srx_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx
 int srx_lrelu_fwd(const float* x, float* y, int64_t n, float slope, void* stream);
 /* y = a*x + b*z  (residual scaling of esrgan/residual.py:86,128; torch.add of srgan/generator.py:78) */
 int srx_axpby(const float* x, const float* z, float* y, int64_t n, float a, float b, void* stream);
+/* y[m][y_off+c] = a*x[m][x_off+c] + b*z[m][z_off+c], c < C: the same on channel slices of tensors with their own
+ * channel strides (`out * 0.2 + x` of an RRDB, esrgan/residual.py:128, between two dense-block buffers) */
+int srx_axpby_channels(const float* x, int x_cs, int x_off, const float* z, int z_cs, int z_off, float* y, int y_cs,
+                       int y_off, int C, int64_t M, float a, float b, void* stream);
 /* channel concat / split of NHWC tensors: dst[m][dst_off+c] (+)= src[m][src_off+c], c < C
  * (torch.cat((x, conv1, ...), dim=1) of the dense block, esrgan/residual.py:82-85, and its adjoint) */
 int srx_copy_channels(const float* src, int src_cs, int src_off, float* dst, int dst_cs, int dst_off, int C,

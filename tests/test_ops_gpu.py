@@ -292,6 +292,92 @@ def test_dgrad_with_folded_activation_backward(dev, case):
     del y
 
 
+@pytest.mark.parametrize('case', [(2, 16, 16, 192, 64, 192, 64, 64),     # a dense block's conv5: strided out, dense addend on 64 channels
+                                  (2, 16, 16, 64, 32, 64, 192, 64),      # ... conv1: dense out, addend read from the 192-wide buffer
+                                  (16, 32, 32, 192, 64, 192, 64, 64),    # config 4's size (K-split tails, several column tiles)
+                                  (1, 10, 14, 96, 32, 128, 96, 32),      # ragged image, padded strides
+                                  (2, 24, 24, 64, 64, 64, 64, 64)])      # 144-row tiles (extra rows) + plain layout, scales only
+@pytest.mark.parametrize('bf16', [False, True])
+def test_dgrad_general_epilogue(dev, case, bf16):
+    """srx_conv2d_bwd_data_ex: dx = out_scale * conv_transpose(dy, W) + addend_scale * addend on the leading channels,
+    the addend with a row stride of its own, then the activation mask on a channel range -- against the same
+    arithmetic in fp64 on the CPU."""
+    from torchsr_amd import _lib
+    from torchsr_amd.layers import Conv2d, set_conv_precision
+    n, h, w, cin, cout, ld_dx, ld_add, add_ch = case
+    torch.manual_seed(cin + h)
+    conv = Conv2d(cin, cout, 3, 1, 1, bias=False).to(dev)
+    if bf16:
+        set_conv_precision(conv, 'bf16')
+    conv(torch.zeros(1, 4, 4, (cin + 3) // 4 * 4, device=dev))   # packs the weights
+    st = conv._st
+    x = rnd((n, cin, h, w), 1)
+    dy = rnd((n, cout, h, w), 2)
+    add = rnd((n, add_ch, h, w), 3)
+    wt = conv.weight.detach().cpu()
+    r = (lambda t: t.bfloat16().double()) if bf16 else (lambda t: t.double())
+    mm = torch.nn.grad.conv2d_input((n, cin, h, w), r(wt), r(dy), padding=1)
+    d = _lib.Conv2dDesc(n, h, w, cin, ld_dx, cout, (cout + 3) // 4 * 4, 3, 3, 1, 1, 0, 0, 0.0, 0, 1 if bf16 else 0)
+    L = _lib.lib()
+    nws = L.srx_conv2d_bwd_data_ws_floats(C.byref(d))
+    ws = torch.empty(max(nws, 4), device=dev)
+    gdy, gadd, gx = nhwc(dy).to(dev), nhwc(add, ld_add).to(dev), nhwc(x, ld_dx).to(dev)
+    for out_scale, add_scale, masked in ((0.04, 0.2, True), (1.0, 1.0, False), (0.2, 1.0, True)):
+        want = out_scale * mm
+        want[:, :add_ch] += add_scale * add.double()
+        lo, hi = (cin - 32, cin) if masked else (0, 0)
+        if masked:
+            want[:, lo:hi] *= torch.where(x[:, lo:hi] > 0, 1.0, 0.2).double()
+        e = _lib.DgradEpilogue()
+        e.out_scale, e.addend, e.addend_ld, e.addend_channels, e.addend_scale = out_scale, gadd.data_ptr(), ld_add, add_ch, add_scale
+        if masked:
+            e.act_out, e.act_slope, e.c_lo, e.c_hi = gx.data_ptr(), 0.2, lo, hi
+        dx = torch.full((n, h, w, ld_dx), 7.0, device=dev)
+        _lib.call('srx_conv2d_bwd_data_ex', C.byref(d), gdy.data_ptr(), st.wpk_bwd.data_ptr(), dx.data_ptr(), C.byref(e),
+                  ws.data_ptr(), nws, torch.cuda.current_stream().cuda_stream)
+        assert rel_err(nchw(dx.cpu(), cin), want.float()) < (2e-5 if bf16 else 2e-4), (out_scale, add_scale, masked)
+        if ld_dx > cin:
+            assert bool((dx[..., cin:] == 7.0).all())   # channels past Cin belong to someone else
+    e = _lib.DgradEpilogue()
+    e.out_scale = 0.5
+    with pytest.raises(RuntimeError, match='without an addend'):
+        _lib.call('srx_conv2d_bwd_data_ex', C.byref(d), gdy.data_ptr(), st.wpk_bwd.data_ptr(), dx.data_ptr(), C.byref(e),
+                  ws.data_ptr(), nws, torch.cuda.current_stream().cuda_stream)
+
+
+def test_scaled_grouped_weight_gradient_and_channel_axpby(dev):
+    """srx_conv2d_bwd_weight_multi_scaled (one multiplier per output, on weight and bias gradient) and
+    srx_axpby_channels (axpby between channel slices of tensors with different row strides)."""
+    from torchsr_amd import _lib
+    n, h, w, cin, cout = 2, 12, 12, 64, 32
+    d = _lib.Conv2dDesc(n, h, w, cin, 192, cout, 32, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
+    xs, dys = [rnd((n, cin, h, w), 10 + i) for i in range(4)], [rnd((n, cout, h, w), 20 + i) for i in range(4)]
+    scales = [1.0, 0.2, 0.04, 3.0]
+    gw = [torch.zeros(cout, cin, 3, 3, device=dev) for _ in range(4)]
+    gb = [torch.zeros(cout, device=dev) for _ in range(4)]
+    nws = L.srx_conv2d_bwd_weight_multi_ws_floats(C.byref(d), 4)
+    ws = torch.empty(max(nws, 4), device=dev)
+    gx, gdy = [nhwc(x, 192).to(dev) for x in xs], [nhwc(t).to(dev) for t in dys]
+    _lib.call('srx_conv2d_bwd_weight_multi_scaled', C.byref(d), 4, 1, arr(gx), arr(gdy), arr(gw), 0, arr(gb),
+              (C.c_float * 4)(*scales), ws.data_ptr(), nws, s)
+    for i in range(4):
+        want = scales[i] * torch.nn.grad.conv2d_weight(xs[i].double(), (cout, cin, 3, 3), dys[i].double(), padding=1)
+        assert rel_err(gw[i], want.float()) < 2e-4, i
+        assert rel_err(gb[i], scales[i] * dys[i].sum((0, 2, 3))) < 2e-4, i
+    m = 2 * 5 * 7
+    a, b = torch.randn(m, 192, device=dev), torch.randn(m, 96, device=dev)
+    y = torch.full((m, 64), 5.0, device=dev)
+    _lib.call('srx_axpby_channels', a.data_ptr(), 192, 64, b.data_ptr(), 96, 32, y.data_ptr(), 64, 8, 48, m, 0.2, 1.0, s)
+    assert torch.allclose(y[:, 8:56], 0.2 * a[:, 64:112] + b[:, 32:80], rtol=1e-6, atol=1e-6)
+    assert bool((y[:, :8] == 5.0).all()) and bool((y[:, 56:] == 5.0).all())
+    _lib.call('srx_axpby_channels', a.data_ptr(), 192, 0, b.data_ptr(), 96, 0, a.data_ptr(), 192, 0, 64, m, 0.2, 1.0, s)  # in place
+    with pytest.raises(RuntimeError, match='slice out of range'):
+        _lib.call('srx_axpby_channels', a.data_ptr(), 192, 160, b.data_ptr(), 96, 0, y.data_ptr(), 64, 0, 64, m, 1.0, 1.0, s)
+
+
 def test_maxpool_relu_backward(dev):
     from torchsr_amd import _lib
     x = torch.relu(rnd((2, 8, 8, 8), 3)).to(dev)    # NHWC, a ReLU output: many exact zeros

@@ -28,6 +28,15 @@ class Conv2dDesc(C.Structure):
     ]
 
 
+class DgradEpilogue(C.Structure):
+    """Mirror of ``srx_dgrad_epilogue_t`` (include/srx.h); zero fields are the defaults."""
+    _fields_ = [
+        ('accumulate', C.c_int32), ('out_scale', C.c_float), ('addend', C.c_void_p), ('addend_ld', C.c_int32),
+        ('addend_channels', C.c_int32), ('addend_scale', C.c_float), ('act_out', C.c_void_p), ('act_slope', C.c_float),
+        ('c_lo', C.c_int32), ('c_hi', C.c_int32),
+    ]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into ``csrc/libsrx_hip.so`` (in-tree)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
@@ -77,9 +86,11 @@ _SIGS = {
     'srx_conv2d_bwd_data': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
     'srx_conv2d_bwd_data_add': (_I, [_D, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_data_act': (_I, [_D, _P, _P, _P, _F, _I, _I, _I, _P, _P, _Z, _P]),
+    'srx_conv2d_bwd_data_ex': (_I, [_D, _P, _P, _P, C.POINTER(DgradEpilogue), _P, _Z, _P]),
     'srx_conv2d_bwd_weight': (_I, [_D, _P, _P, _P, _I, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_weight_multi_ws_floats': (_Z, [_D, _I]),
     'srx_conv2d_bwd_weight_multi': (_I, [_D, _I, _I, _P, _P, _P, _I, _P, _P, _Z, _P]),
+    'srx_conv2d_bwd_weight_multi_scaled': (_I, [_D, _I, _I, _P, _P, _P, _I, _P, _P, _P, _Z, _P]),
     'srx_colsum_ws_floats': (_Z, [_L, _I]),
     'srx_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     'srx_crop_flip_u8': (_I, [_P, _P, _P, _I, _I, _P]),
@@ -90,6 +101,7 @@ _SIGS = {
     'srx_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _I, _L, _P, _P]),
     'srx_lrelu_fwd': (_I, [_P, _P, _L, _F, _P]),
     'srx_axpby': (_I, [_P, _P, _P, _L, _F, _F, _P]),
+    'srx_axpby_channels': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _L, _F, _F, _P]),
     'srx_copy_channels': (_I, [_P, _I, _I, _P, _I, _I, _I, _L, _I, _P]),
     'srx_upsample_nearest2x_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'srx_upsample_nearest2x_bwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -144,7 +156,12 @@ def lib() -> C.CDLL:
                 'There is no CPU fallback for the product path.')
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
-            fn = getattr(handle, name)
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                if os.environ.get('SRX_LIB'):  # a developer's older A/B build: calling the missing entry point raises
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = handle

@@ -295,6 +295,21 @@ __global__ void copy_channels_kernel(const float* __restrict__ src, int scs, int
   }
 }
 
+// y[m][yoff + c] = a * x[m][xoff + c] + b * z[m][zoff + c]: axpby on channel slices of tensors with different row strides
+// (ESRGAN's trunk: `out * 0.2 + x` of an RRDB between the first 64 channels of two 192-channel dense-block buffers)
+__global__ void axpby_channels_kernel(const float* __restrict__ x, int xcs, int xoff, const float* __restrict__ z, int zcs,
+                                      int zoff, float* __restrict__ y, int ycs, int yoff, int C, int64_t M, float a, float b) {
+  const int cq = C / 4;
+  const int64_t total = M * cq;
+  GRID_STRIDE(i, total) {
+    const int64_t m = i / cq;
+    const int q = (int)(i - m * cq);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + m * xcs + xoff + q * 4);
+    const f32x4 zv = *reinterpret_cast<const f32x4*>(z + m * zcs + zoff + q * 4);
+    *reinterpret_cast<f32x4*>(y + m * ycs + yoff + q * 4) = xv * a + zv * b;
+  }
+}
+
 // F.interpolate(scale_factor=2, mode='nearest') on NHWC and its adjoint
 __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
   const int cq = C / 4;
@@ -339,6 +354,19 @@ extern "C" int srx_copy_channels(const float* src, int src_cs, int src_off, floa
   hipLaunchKernelGGL(copy_channels_kernel, dim3(stream_grid(M * (C / 4))), dim3(256), 0, srx_stream(stream), src, src_cs,
                      src_off, dst, dst_cs, dst_off, C, M, accumulate);
   SRX_CHECK_LAUNCH("copy_channels_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_axpby_channels(const float* x, int x_cs, int x_off, const float* z, int z_cs, int z_off, float* y,
+                                  int y_cs, int y_off, int C, int64_t M, float a, float b, void* stream) {
+  SRX_REQUIRE(x && z && y && C > 0 && M > 0, "axpby_channels: bad argument");
+  SRX_REQUIRE(C % 4 == 0 && x_cs % 4 == 0 && z_cs % 4 == 0 && y_cs % 4 == 0 && x_off % 4 == 0 && z_off % 4 == 0 && y_off % 4 == 0,
+              "axpby_channels: channel counts and offsets must be multiples of 4");
+  SRX_REQUIRE(x_off >= 0 && z_off >= 0 && y_off >= 0 && x_off + C <= x_cs && z_off + C <= z_cs && y_off + C <= y_cs,
+              "axpby_channels: slice out of range");
+  hipLaunchKernelGGL(axpby_channels_kernel, dim3(stream_grid(M * (C / 4))), dim3(256), 0, srx_stream(stream), x, x_cs, x_off,
+                     z, z_cs, z_off, y, y_cs, y_off, C, M, a, b);
+  SRX_CHECK_LAUNCH("axpby_channels_kernel");
   return SRX_OK;
 }
 

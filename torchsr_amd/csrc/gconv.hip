@@ -56,6 +56,12 @@ struct GArgs {
   // conv, `x + conv(...)` in one kernel).  Linear outputs only.
   const float* add;
   float oscale;  // applied to act(acc + bias) before the addend (conv5 * 0.2 + x of the dense block); 1 otherwise
+  // The addend may have a row stride of its own (add_ld floats; linear outputs only -- otherwise it equals Co), may cover
+  // only the leading columns [0, add_hi), and is scaled by ascale: out = act(acc + bias) * oscale + add * ascale.  ESRGAN's
+  // trunk keeps every dense block's input in the first 64 of a 192-channel buffer (stride 192) while block gradients
+  // are dense 64-channel tensors, and the gradient entering a block is added to the block's input gradient there.
+  int add_ld, add_hi;
+  float ascale;
   // mask (null: none): the OUTPUT of the activation that produced this conv's input, laid out like `out`.  The data
   // gradient is multiplied by that activation's derivative on its way out, v * (mask[i] > 0 ? 1 : mask_slope), for
   // the output columns [mask_lo, mask_hi) -- the ReLU / LeakyReLU backward of the layer below without a pass of its
@@ -421,7 +427,14 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   const unsigned tb_lo = (unsigned)srx_uniform((int)(unsigned)(tile_base & 0xffffffffu));
   const unsigned tb_hi = (unsigned)srx_uniform((int)(unsigned)(tile_base >> 32));
   const __amdgpu_buffer_rsrc_t rout = srx_rsrc(a.out + (((size_t)tb_hi << 32) | tb_lo), 0xfffffff0u);
-  const __amdgpu_buffer_rsrc_t radd = srx_rsrc((a.add ? a.add : a.out) + (((size_t)tb_hi << 32) | tb_lo), 0xfffffff0u);
+  // (the addend's tile base differs from the output's when it has its own row stride -- linear outputs only; built
+  // inside the add-mode paths so that the other epilogues do not carry its scalars)
+  auto make_radd = [&]() {
+    const size_t add_base = a.linear_out ? (size_t)m0 * a.add_ld : tile_base;
+    const unsigned ab_lo = (unsigned)srx_uniform((int)(unsigned)(add_base & 0xffffffffu));
+    const unsigned ab_hi = (unsigned)srx_uniform((int)(unsigned)(add_base >> 32));
+    return srx_rsrc(a.add + (((size_t)ab_hi << 32) | ab_lo), 0xfffffff0u);
+  };
   const __amdgpu_buffer_rsrc_t rmask = srx_rsrc((a.mask ? a.mask : a.out) + (((size_t)tb_hi << 32) | tb_lo), 0xfffffff0u);
 
   float bv[TN];
@@ -448,6 +461,13 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
 
   auto store_tile = [&](auto linear, auto accum) {  // one copy per addressing / epilogue mode (bit 0: addend, bit 1: mask), chosen by ONE branch
     constexpr int MODE = decltype(accum)::value;
+    __amdgpu_buffer_rsrc_t radd = rout;
+    bool cak[TN];  // the column takes the addend
+    if constexpr ((MODE & 1) != 0) {
+      radd = make_radd();
+#pragma unroll
+      for (int j = 0; j < TN; ++j) cak[j] = n0 + wn * WN + j * 32 + l31 < a.add_hi;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       // Addend / mask values of the whole 32-row block are requested BEFORE the first store: vmcnt retires in issue
@@ -462,11 +482,15 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
         const bool mok = m < a.M;
         const unsigned rowoff = decltype(linear)::value ? 4u * (unsigned)((m - m0) * a.Co)
                                                         : 4u * (unsigned)(out_elem(mok ? m : m0) - tile_base);
+        const unsigned arow = decltype(linear)::value ? 4u * (unsigned)((m - m0) * a.add_ld) : rowoff;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const unsigned off = (mok && cok[j]) ? rowoff + ocol[j] : 0xffffffffu;
           offs[r][j] = off;
-          if (MODE & 1) av[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
+          // (a column past add_hi reads nothing -- an out-of-range offset returns 0)
+          if (MODE & 1)
+            av[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                radd, (int)((mok && cok[j] && cak[j]) ? arow + ocol[j] : 0xffffffffu), 0, 0));
           // (a column outside the mask range reads nothing: its offset is pointed out of range)
           if (MODE & 2)
             mv[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)(cmk[j] ? off : 0xffffffffu), 0, 0));
@@ -483,7 +507,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
           csum[j] += vs;
           csq[j] += vs * vs;
           v = v > 0.f ? v : v * a.slope;
-          if (MODE & 1) v = v * a.oscale + av[r][j];
+          if (MODE & 1) v = v * a.oscale + av[r][j] * a.ascale;
           if (MODE & 2) v = (cmk[j] && !(mv[r][j] > 0.f)) ? v * a.mask_slope : v;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, offs[r][j], 0, 0);
         }
@@ -528,7 +552,12 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       xs2 += vs * vs;
       v = v > 0.f ? v : v * a.slope;
       const unsigned off = (mok && xok) ? rowoff + 4u * (unsigned)oc : 0xffffffffu;
-      if (a.add) v = v * a.oscale + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)off, 0, 0));
+      if (a.add) {
+        const __amdgpu_buffer_rsrc_t radd = make_radd();
+        const unsigned arow = a.linear_out ? 4u * (unsigned)((m - m0) * a.add_ld) : rowoff;
+        const unsigned aoff = (mok && xok && col < a.add_hi) ? arow + 4u * (unsigned)oc : 0xffffffffu;
+        v = v * a.oscale + a.ascale * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)aoff, 0, 0));
+      }
       if (a.mask && col >= a.mask_lo && col < a.mask_hi) {
         const float mv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)off, 0, 0));
         v = mv > 0.f ? v : v * a.mask_slope;
@@ -634,7 +663,10 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const GArgs a) {
       }
       if (col < a.Cs) {  // Cs is a multiple of 4
         f32x4* o = reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col);
-        if (a.add) v = v * a.oscale + *reinterpret_cast<const f32x4*>(a.add + (size_t)m * a.Co + col);
+        if (a.add) {  // (add_hi is a multiple of 4 or covers every column)
+          v = v * a.oscale;
+          if (col < a.add_hi) v += *reinterpret_cast<const f32x4*>(a.add + (size_t)m * a.add_ld + col) * a.ascale;
+        }
         if (a.mask && col >= a.mask_lo && col < a.mask_hi) {  // (mask ranges are whole quads: channel counts are multiples of 4)
           const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + (size_t)m * a.Co + col);
 #pragma unroll
@@ -703,6 +735,9 @@ struct WMulti {
 struct WReduce {
   float* dw[WG_MAXP];
   float* db[WG_MAXP];  // entries may be null
+  // multiplies the output's weight and bias gradient: the layer's dy tensor stands for scale * dy (a dense block's conv5
+  // sees the block's output gradient times scale_ratio, which is then never written out)
+  float scale[WG_MAXP];
 };
 
 // PR = 1: bf16 products (the autocast mode).  The contraction runs over pixels, so an MFMA operand is eight
@@ -904,6 +939,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab_all, int nsla
     const float* __restrict__ bslab = bslab_all + (size_t)o * nslab * Cnw;
     float s = 0.f;
     for (int z = 0; z < nslab; ++z) s += bslab[(size_t)z * Cnw + idx];
+    s *= outs.scale[o];
     db[idx] = accumulate ? db[idx] + s : s;
   }
   if (idx >= (int64_t)Cout * K) return;
@@ -921,7 +957,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab_all, int nsla
     s3 += sp[(size_t)(z + 3) * zs];
   }
   for (; z < nslab; ++z) s0 += sp[(size_t)z * zs];
-  const float s = (s0 + s1) + (s2 + s3);
+  const float s = ((s0 + s1) + (s2 + s3)) * outs.scale[o];
   int co = np;
   if (shuffle_cps) { const int ij = np / shuffle_cps, cc = np - ij * shuffle_cps; co = cc * 4 + ij; }
   const int kh = tap / KW, kw = tap - kh * KW;
@@ -1644,6 +1680,7 @@ static int conv_fwd_impl(const srx_conv2d_t* d, const float* x, const float* wpk
   a.out = y;
   a.add = residual;
   a.oscale = out_scale;
+  a.add_ld = a.Co; a.add_hi = 0x7fffffff; a.ascale = 1.f;
   a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin_s * sizeof(float));
   a.w_bytes = (unsigned)((size_t)g.Cnp * g.Kp * sizeof(float));
   return run_gconv(a, fwd_plan(d, g), ws, ws_floats, st, d->precision);
@@ -1663,19 +1700,30 @@ extern "C" int srx_conv2d_fwd_residual(const srx_conv2d_t* d, const float* x, co
 
 static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx, int accumulate,
                               const float* act_out, float act_slope, int c_lo, int c_hi, float* ws, size_t ws_floats,
-                              void* stream, const float* addend = nullptr) {
+                              void* stream, const float* addend = nullptr, int addend_ld = 0, int addend_channels = 0,
+                              float addend_scale = 1.f, float out_scale = 1.f) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(dy && wpk_bwd && dx, "conv2d_bwd_data: null pointer");
   SRX_REQUIRE(d->stride <= 4, "conv2d_bwd_data: stride > 4 unsupported");
+  if (addend_ld == 0) addend_ld = d->Cin_s;
+  if (addend_channels == 0) addend_channels = 0x7fffffff;
+  const bool plain_addend = addend_ld == d->Cin_s && addend_channels >= d->Cin && addend_scale == 1.f && out_scale == 1.f;
+  if (!plain_addend) {
+    SRX_REQUIRE(addend && !accumulate, "conv2d_bwd_data_ex: addend stride / channels / scales without an addend");
+    SRX_REQUIRE(addend_ld >= 4 && addend_ld % 4 == 0 && (addend_channels % 4 == 0 || addend_channels >= d->Cin),
+                "conv2d_bwd_data_ex: the addend's stride and channel count must be made of whole quads");
+  }
   if (d->up == 2) {
-    if (accumulate || act_out) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: up = 2 with accumulate / a folded activation");
+    if (accumulate || act_out || addend)
+      SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: up = 2 with accumulate / an addend / a folded activation");
     const srx_conv2d_t h = upsampled_desc(d);
     const size_t tmp = upsampled_floats(d);
     SRX_REQUIRE(ws && ws_floats >= tmp + srx_conv2d_bwd_data_ws_floats(&h), "conv2d_bwd_data: workspace too small for up = 2");
     if (int rc = conv_bwd_data_impl(&h, dy, wpk_bwd, ws, 0, nullptr, 1.f, 0, 0, ws + tmp, ws_floats - tmp, stream)) return rc;
     return srx_upsample_nearest2x_bwd(ws, dx, d->N, d->H, d->W, d->Cin_s, stream);
   }
-  const bool rt36 = srx_rt36_applicable(d) && !act_out;  // (the row-tile kernel has no masked epilogue)
+  // (the row-tile kernel has neither a masked epilogue nor a strided / scaled addend)
+  const bool rt36 = srx_rt36_applicable(d) && !act_out && plain_addend;
   if (addend && (accumulate || d->stride != 1 || srx_thin_dgrad_applicable(d) || d->up == 2))
     SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data_add: stride-1 layers without accumulate only");
   if (accumulate && (d->stride != 1 || srx_thin_dgrad_applicable(d) || rt36))
@@ -1722,7 +1770,9 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
     a.in_bytes = (unsigned)dy_bytes;
     a.w_bytes = (unsigned)((size_t)pad_rows(d->Cin) * c.Kp * sizeof(float));
     a.add = accumulate ? dx : addend;
-    a.oscale = 1.f;
+    a.oscale = out_scale;
+    a.add_ld = accumulate ? a.Co : addend_ld; a.add_hi = accumulate ? 0x7fffffff : addend_channels;
+    a.ascale = accumulate ? 1.f : addend_scale;
     if (act_out) { a.mask = act_out; a.mask_slope = act_slope; a.mask_lo = c_lo; a.mask_hi = c_hi; }
     if (d->stride == 1) {
       if (int rc = run_gconv(a, bwd_plan(d, c), ws, ws_floats, st, d->precision)) return rc;
@@ -1758,13 +1808,34 @@ extern "C" int srx_conv2d_bwd_data_act(const srx_conv2d_t* d, const float* dy, c
   return conv_bwd_data_impl(d, dy, wpk_bwd, dx, accumulate, x, slope, c_lo, c_hi, ws, ws_floats, stream);
 }
 
+extern "C" int srx_conv2d_bwd_data_ex(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
+                                      const srx_dgrad_epilogue_t* e, float* ws, size_t ws_floats, void* stream) {
+  SRX_REQUIRE(e, "conv2d_bwd_data_ex: null epilogue");
+  SRX_REQUIRE(!e->addend || e->addend != dx, "conv2d_bwd_data_ex: the addend must be a tensor of its own (use accumulate)");
+  return conv_bwd_data_impl(d, dy, wpk_bwd, dx, e->accumulate, e->act_out, e->act_slope, e->c_lo, e->c_hi, ws, ws_floats,
+                            stream, e->addend, e->addend_ld, e->addend_channels, e->addend_scale == 0.f ? 1.f : e->addend_scale,
+                            e->out_scale == 0.f ? 1.f : e->out_scale);
+}
+
 extern "C" int srx_colsum(const float* x, float* out, int64_t M, int C, int Cs, int accumulate, float* ws,
                           size_t ws_floats, void* stream);
 extern "C" size_t srx_colsum_ws_floats(int64_t M, int C);
 
+extern "C" int srx_conv2d_bwd_weight_multi_scaled(const srx_conv2d_t* d, int nprob, int per_out, const float* const* xs,
+                                                  const float* const* dys, float* const* dws, int accumulate,
+                                                  float* const* dbs, const float* out_scales, float* ws, size_t ws_floats,
+                                                  void* stream);
+
 extern "C" int srx_conv2d_bwd_weight_multi(const srx_conv2d_t* d, int nprob, int per_out, const float* const* xs,
                                            const float* const* dys, float* const* dws, int accumulate, float* const* dbs,
                                            float* ws, size_t ws_floats, void* stream) {
+  return srx_conv2d_bwd_weight_multi_scaled(d, nprob, per_out, xs, dys, dws, accumulate, dbs, nullptr, ws, ws_floats, stream);
+}
+
+extern "C" int srx_conv2d_bwd_weight_multi_scaled(const srx_conv2d_t* d, int nprob, int per_out, const float* const* xs,
+                                                  const float* const* dys, float* const* dws, int accumulate,
+                                                  float* const* dbs, const float* out_scales, float* ws, size_t ws_floats,
+                                                  void* stream) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(nprob >= 1 && nprob <= WG_MAXP && per_out >= 1 && nprob % per_out == 0,
               "conv2d_bwd_weight_multi: 1..%d problems, a whole number of outputs", WG_MAXP);
@@ -1779,8 +1850,8 @@ extern "C" int srx_conv2d_bwd_weight_multi(const srx_conv2d_t* d, int nprob, int
       up_x[i] = ws + (size_t)i * tmp;
       if (int rc = srx_upsample_nearest2x_fwd(xs[i], ws + (size_t)i * tmp, d->N, d->H, d->W, d->Cin_s, stream)) return rc;
     }
-    return srx_conv2d_bwd_weight_multi(&h, nprob, per_out, up_x, dys, dws, accumulate, dbs, ws + nprob * tmp,
-                                       ws_floats - nprob * tmp, stream);
+    return srx_conv2d_bwd_weight_multi_scaled(&h, nprob, per_out, up_x, dys, dws, accumulate, dbs, out_scales,
+                                              ws + nprob * tmp, ws_floats - nprob * tmp, stream);
   }
   const int nout = nprob / per_out;
   bool any_db = false;
@@ -1792,6 +1863,8 @@ extern "C" int srx_conv2d_bwd_weight_multi(const srx_conv2d_t* d, int nprob, int
   if (any_db && d->shuffle) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_weight: bias gradient of a PixelShuffle layer is not fused");
   hipStream_t st = srx_stream(stream);
   if (srx_thin_wgrad_applicable(d)) {  // 3-channel layers: their own kernel, one problem at a time
+    for (int o = 0; out_scales && o < nout; ++o)
+      if (out_scales[o] != 1.f) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_weight: output scales on a 3-channel layer");
     const size_t thin_ws = srx_thin_wgrad_ws_floats(d);
     const int64_t m = (int64_t)d->N * d->H * d->W;  // thin layers are stride 1, same size
     for (int i = 0; i < nprob; ++i) {
@@ -1849,7 +1922,9 @@ extern "C" int srx_conv2d_bwd_weight_multi(const srx_conv2d_t* d, int nprob, int
   a.bslab = any_db ? ws + nslabs * a.Cnw * a.Kw : nullptr;
   WReduce outs{};
   for (int i = 0; i < nprob; ++i) { mp.x[i] = xs[i]; mp.dy[i] = dys[i]; }
-  for (int o = 0; o < nout; ++o) { outs.dw[o] = dws[o]; outs.db[o] = dbs ? dbs[o] : nullptr; }
+  for (int o = 0; o < nout; ++o) {
+    outs.dw[o] = dws[o]; outs.db[o] = dbs ? dbs[o] : nullptr; outs.scale[o] = out_scales ? out_scales[o] : 1.f;
+  }
   dim3 grid((unsigned)(tiles * nprob * nsplit));
   const double wfl = 2.0 * a.M * d->Cout * a.K * nprob;
   char nm[112];

@@ -34,7 +34,9 @@ class Generator(nn.Module):
 
     def forward_nhwc(self, x4: Tensor) -> Tensor:
         conv1 = self.conv1(x4)
-        conv2 = self.conv2(self.blocks(conv1))
+        # the RRDB chain is one autograd node (functional._RRDBTrunk): every dense block finds its input where the
+        # block before wrote it; the modules in self.blocks hold the parameters (and run one by one when called alone)
+        conv2 = self.conv2(F.rrdb_trunk(conv1, list(self.blocks)))   # :70
         out = F.axpby(conv1, conv2, 1.0, 1.0)                       # torch.add, generator.py:72
         out = F.cut_point('g.tail', out)                            # data parallel: upsample* / conv3 / conv4 gradients go out first
         out = self.upsample1(out)                                   # :73-75 (nearest x2 in the conv's gather)

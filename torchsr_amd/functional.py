@@ -64,9 +64,10 @@ class WeightGradQueue:
     def __init__(self):
         self.groups = {}
 
-    def add(self, d: Conv2dDesc, x_ptr: int, dy_ptr: int, sink_ptr: int, bias_ptr, keep) -> None:
+    def add(self, d: Conv2dDesc, x_ptr: int, dy_ptr: int, sink_ptr: int, bias_ptr, keep, scale: float = 1.0) -> None:
+        """``scale``: the tensor at ``dy_ptr`` stands for ``scale * dy`` (one value per sink)."""
         key = tuple(getattr(d, f) for f, _ in Conv2dDesc._fields_)
-        self.groups.setdefault(key, [d, []])[1].append((x_ptr, dy_ptr, sink_ptr, bias_ptr or 0, keep))
+        self.groups.setdefault(key, [d, []])[1].append((x_ptr, dy_ptr, sink_ptr, bias_ptr or 0, keep, float(scale)))
 
     def flush(self) -> None:
         groups, self.groups = self.groups, {}
@@ -92,7 +93,14 @@ class WeightGradQueue:
                     dws, dbs = arr([sk[0] for sk, _ in part]), arr([sk[1] or None for sk, _ in part])
                     nws = L.srx_conv2d_bwd_weight_multi_ws_floats(dref, n)
                     ws = torch.empty(max(int(nws), 4), dtype=torch.float32, device=probs[0][4][0].device)
-                    call('srx_conv2d_bwd_weight_multi', dref, n, per_out, xs, dys, dws, 1, dbs, _p(ws), nws, s)
+                    scales = [its[0][5] for _, its in part]
+                    if any(its[k][5] != its[0][5] for _, its in part for k in range(len(its))):
+                        raise RuntimeError('WeightGradQueue: the segments of one gradient must share their scale')
+                    if all(v == 1.0 for v in scales):
+                        call('srx_conv2d_bwd_weight_multi', dref, n, per_out, xs, dys, dws, 1, dbs, _p(ws), nws, s)
+                    else:
+                        call('srx_conv2d_bwd_weight_multi_scaled', dref, n, per_out, xs, dys, dws, 1, dbs,
+                             (C.c_float * len(scales))(*scales), _p(ws), nws, s)
 
 
 wgrad_queue = [None]
@@ -1295,6 +1303,179 @@ def dense_block(x: Tensor, scale: float, convs) -> Tensor:
     for c in convs:
         wb += [_w(c.weight), _w(c.bias)]
     return _DenseBlock.apply(x, scale, [c._st for c in convs], [c.weight for c in convs], *wb)
+
+
+class _RRDBTrunk(Function):
+    """ESRGAN's chain of residual-in-residual dense blocks (esrgan/generator.py:54-56,70; esrgan/residual.py:81-86,
+    125-128) as ONE autograd node, so that nothing but convolutions touches the activations.
+
+    Every dense block owns a ``[N,H,W,64+4*32]`` buffer as in ``_DenseBlock``; here the block's INPUT lives in the
+    first 64 channels of its own buffer, because the conv5 of the block before wrote it there
+    (``conv5 * scale + x`` in the conv epilogue, 192-channel row stride on both sides).  Per dense block the forward
+    is five conv launches (before: a channel copy, five convs, and every third block an ``out * 0.2 + x`` pass that
+    stays -- it has two addends).  In the backward the block's output gradient ``dy`` is never scaled or copied:
+    conv5's data gradient takes ``scale`` and adds ``dy`` onto the first 64 channels (``srx_conv2d_bwd_data_ex``), its
+    weight gradient takes ``scale`` in the slab reduction (``srx_conv2d_bwd_weight_multi_scaled``), and conv1's data
+    gradient writes the block's input gradient as a dense tensor, adding what conv2..5 left in the shared gradient
+    buffer.  Per RRDB one elementwise pass is left in each direction (before: four and ten).
+    """
+
+    @staticmethod
+    def forward(ctx, x: Tensor, rdb_scales, rrdb_scale: float, states, masters, *wb):
+        ctx.set_materialize_grads(False)
+        x = _chk(x, 'rrdb_trunk.input')
+        n, h, w, c0 = x.shape
+        nb = len(states)
+        g = states[0][0].cout
+        total = c0 + 4 * g
+        m = n * h * w
+        L = _lib.lib()
+        s = _stream()
+        need_bwd = any(ctx.needs_input_grad)
+        # without a backward pass four rotating buffers are enough (an RRDB reads its first block's input at its end)
+        pool = [torch.empty((n, h, w, total), dtype=torch.float32, device=x.device) for _ in range(nb + 1 if need_bwd else 4)]
+        bufs = [pool[i % len(pool)] for i in range(nb + 1)]
+        call('srx_copy_channels', _p(x), c0, 0, _p(bufs[0]), total, 0, c0, m, 0, s)
+        descs = []
+        y = None
+        for i in range(nb):
+            buf, nxt = bufs[i], bufs[i + 1]
+            row = []
+            for k in range(5):
+                st = states[i][k]
+                cin = c0 + k * g
+                d = Conv2dDesc(n, h, w, cin, total, st.cout, total, st.k, st.k, st.stride, st.pad, 0, st.act, st.slope, 0,
+                               st.precision)
+                row.append(d)
+                dref = C.byref(d)
+                st.pack(masters[i][k], d)
+                bias = wb[10 * i + 2 * k + 1]
+                bp = None if bias is None else _p(_chk(bias.detach(), 'rrdb_trunk.bias'))
+                nws = L.srx_conv2d_fwd_ws_floats(dref)
+                ws = _ws(nws, x) if nws else None
+                if k == 4:  # the next block's input = conv5 * scale + x, x = the first 64 channels of this buffer (:86)
+                    call('srx_conv2d_fwd_residual', dref, _p(buf), _p(st.wpk_fwd), bp, _p(buf), float(rdb_scales[i]), _p(nxt),
+                         _p(ws), nws, s)
+                else:
+                    call('srx_conv2d_fwd', dref, _p(buf), _p(st.wpk_fwd), bp, buf.data_ptr() + 4 * cin, None, _p(ws), nws, s)
+            descs.append(row)
+            if i % 3 == 2:  # end of an RRDB: out * 0.2 + x, x = the input of its first dense block (:128)
+                first = bufs[i - 2]
+                if i == nb - 1:
+                    y = torch.empty_like(x)
+                    call('srx_axpby_channels', _p(nxt), total, 0, _p(first), total, 0, _p(y), c0, 0, c0, m, float(rrdb_scale),
+                         1.0, s)
+                else:
+                    call('srx_axpby_channels', _p(nxt), total, 0, _p(first), total, 0, _p(nxt), total, 0, c0, m,
+                         float(rrdb_scale), 1.0, s)
+        ctx.states, ctx.descs = states, descs
+        ctx.scales = ([float(v) for v in rdb_scales], float(rrdb_scale))
+        ctx.dims = (n, h, w, c0, g, total, m, nb)
+        ctx.params = wb
+        if need_bwd:
+            ctx.save_for_backward(*bufs[:nb])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        bufs = ctx.saved_tensors
+        grad = _chk(dy, 'rrdb_trunk.grad')
+        n, h, w, c0, g, total, m, nb = ctx.dims
+        rdb_scales, rrdb_scale = ctx.scales
+        L = _lib.lib()
+        s = _stream()
+        dev = grad.device
+        grads = [None] * (10 * nb)
+        queue = wgrad_queue[0]
+        rrdb_grad = None
+        for i in range(nb - 1, -1, -1):
+            j = i % 3
+            buf = bufs[i]
+            gbuf = torch.empty((n, h, w, total), dtype=torch.float32, device=dev)
+            # `grad` is the gradient of the value this block produced, up to the factor `eff`: the last block of an RRDB
+            # receives the RRDB's output gradient, of which it sees rrdb_scale (out * 0.2 + x, :128)
+            if j == 2:
+                rrdb_grad, eff = grad, rrdb_scale
+            else:
+                eff = 1.0
+            # the `+ x` of :86 hands eff * grad to the block's input; the first block's input is also the RRDB's x
+            skip, skip_scale = grad, eff
+            if j == 0:
+                skip = torch.empty_like(grad)
+                call('srx_axpby', _p(grad), _p(rrdb_grad), _p(skip), grad.numel(), eff, 1.0, s)
+                skip_scale = 1.0
+            dx = torch.empty((n, h, w, c0), dtype=torch.float32, device=dev)
+            keep = (buf, gbuf, grad)
+            for k in (4, 3, 2, 1, 0):
+                st, d = ctx.states[i][k], ctx.descs[i][k]
+                cin = c0 + k * g
+                if k == 4:  # conv5's output gradient is the block's: a dense 64-channel tensor (the forward wrote 192-strided)
+                    d = Conv2dDesc(n, h, w, cin, total, st.cout, st.cout, st.k, st.k, st.stride, st.pad, 0, st.act, st.slope, 0,
+                                   st.precision)
+                    gk, wscale = grad.data_ptr(), eff * rdb_scales[i]
+                else:  # complete and masked: the data gradient of conv k+1 finished this slice of the shared buffer
+                    gk, wscale = gbuf.data_ptr() + 4 * cin, 1.0
+                dref = C.byref(d)
+                wparam, bparam = ctx.params[10 * i + 2 * k], ctx.params[10 * i + 2 * k + 1]
+                if ctx.needs_input_grad[5 + 10 * i + 2 * k]:
+                    sink = _sink(wparam)
+                    dw = None if sink is not None else torch.empty((st.cout, st.cin, st.k, st.k), dtype=torch.float32,
+                                                                     device=dev)
+                    bptr = None
+                    if bparam is not None and ctx.needs_input_grad[6 + 10 * i + 2 * k]:
+                        bsink = _sink(bparam)
+                        if (bsink is None) != (sink is None):
+                            raise RuntimeError('rrdb_trunk: weight and bias of a conv must both (or neither) have a gradient sink')
+                        if bsink is None:
+                            grads[10 * i + 2 * k + 1] = torch.empty(st.cout, dtype=torch.float32, device=dev)
+                        bptr = _p(grads[10 * i + 2 * k + 1] if bsink is None else bsink)
+                    if queue is not None and sink is not None:
+                        queue.add(d, _p(buf), gk, _p(sink), bptr, keep, wscale)
+                    else:
+                        nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
+                        one = lambda v: (C.c_void_p * 1)(v)  # noqa: E731
+                        call('srx_conv2d_bwd_weight_multi_scaled', dref, 1, 1, one(_p(buf)), one(gk),
+                             one(_p(dw if sink is None else sink)), 0 if sink is None else 1, one(bptr),
+                             (C.c_float * 1)(wscale), _p(_ws(nws, grad)), nws, s)
+                    grads[10 * i + 2 * k] = dw
+                elif bparam is not None and ctx.needs_input_grad[6 + 10 * i + 2 * k]:
+                    raise RuntimeError('rrdb_trunk: a bias gradient without its weight gradient is not implemented')
+                e = _lib.DgradEpilogue()
+                if k > 0:  # LeakyReLU backward of conv k on the slice this call completes (esrgan/residual.py:81-84)
+                    e.act_out, e.act_slope, e.c_lo, e.c_hi = _p(buf), ctx.states[i][k - 1].slope, cin - g, cin
+                if k == 4:    # overwrites all 192 channels; `+ x`: the block's output gradient lands on the first 64
+                    e.out_scale = eff * rdb_scales[i]
+                    e.addend, e.addend_ld, e.addend_channels, e.addend_scale = _p(skip), c0, c0, skip_scale
+                    out, dd = gbuf, d
+                elif k > 0:
+                    e.accumulate = 1
+                    out, dd = gbuf, d
+                else:         # the block's input gradient, dense: this conv's share + the first 64 channels of the buffer
+                    e.addend, e.addend_ld, e.addend_channels = _p(gbuf), total, c0
+                    dd = Conv2dDesc(n, h, w, c0, c0, st.cout, total, st.k, st.k, st.stride, st.pad, 0, st.act, st.slope, 0,
+                                    st.precision)
+                    out = dx
+                ddref = C.byref(dd)
+                nws = L.srx_conv2d_bwd_data_ws_floats(ddref)
+                ws = _ws(nws, grad) if nws else None
+                call('srx_conv2d_bwd_data_ex', ddref, gk, _p(st.wpk_bwd), _p(out), C.byref(e), _p(ws), nws, s)
+            grad = dx
+        return (grad, None, None, None, None, *grads)
+
+
+def rrdb_trunk(x: Tensor, rrdbs) -> Tensor:
+    """``rrdbs``: the generator's ``ResidualInResidualDenseBlock`` modules, in order (``nn.Sequential(*blocks)(x)``)."""
+    from .layers import _w
+    states, masters, wb, scales = [], [], [], []
+    for rr in rrdbs:
+        for rdb in (rr.RDB1, rr.RDB2, rr.RDB3):
+            convs = (rdb.conv1[0], rdb.conv2[0], rdb.conv3[0], rdb.conv4[0], rdb.conv5)
+            states.append([c._st for c in convs])
+            masters.append([c.weight for c in convs])
+            scales.append(rdb.scale_ratio)
+            for c in convs:
+                wb += [_w(c.weight), _w(c.bias)]
+    return _RRDBTrunk.apply(x, scales, 0.2, states, masters, *wb)
 
 
 class _Upsample2x(Function):
