@@ -206,6 +206,16 @@ int srx_conv2d_bwd_weight_multi(const srx_conv2d_t* d, int nprob, int per_out, c
 int srx_conv2d_bwd_weight_multi_scaled(const srx_conv2d_t* d, int nprob, int per_out, const float* const* xs,
                                        const float* const* dys, float* const* dws, int accumulate, float* const* dbs,
                                        const float* out_scales, float* ws, size_t ws_floats, void* stream);
+/* Pairs: every problem is TWO convs of d->Cout / 2 output channels each that read the same input buffer and whose
+ * output gradients are adjacent channel slices of one tensor -- conv1 + conv2 and conv3 + conv4 of a dense block
+ * (esrgan/residual.py:81-85: conv k reads the first 64 + 32 (k - 1) channels of the block's buffer and its output gradient
+ * is the next 32-channel slice of the gradient buffer).  d describes the pair as one layer: Cin = the larger input
+ * width, Cout = both slices; the first conv has only cin_lo input channels, the rest of its rows is not written.
+ * Alone, a 32-column problem leaves half of every 64-column MFMA tile multiplying padding; paired, 10-17 % of the tile
+ * is unused.  dws_lo / dws_hi (and dbs_lo / dbs_hi, both or neither) hold nprob pointers each. */
+int srx_conv2d_bwd_weight_multi_pair(const srx_conv2d_t* d, int nprob, const float* const* xs, const float* const* dys,
+                                     float* const* dws_lo, float* const* dws_hi, int cin_lo, int accumulate,
+                                     float* const* dbs_lo, float* const* dbs_hi, float* ws, size_t ws_floats, void* stream);
 
 /* ------------------------------------------------- elementwise / reductions */
 /* out[c] = sum_m x[m][c]  (bias gradient of Conv2d / Linear); ws >= 2*rows*C floats */

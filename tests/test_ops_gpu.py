@@ -378,6 +378,41 @@ def test_scaled_grouped_weight_gradient_and_channel_axpby(dev):
         _lib.call('srx_axpby_channels', a.data_ptr(), 192, 160, b.data_ptr(), 96, 0, y.data_ptr(), 64, 0, 64, m, 1.0, 1.0, s)
 
 
+@pytest.mark.parametrize('bf16', [False, True])
+def test_paired_weight_gradient(dev, bf16):
+    """srx_conv2d_bwd_weight_multi_pair: conv_a (cin_lo -> 32) and conv_b (Cin -> 32) of a dense block read the same
+    192-channel buffer and their output gradients are adjacent 32-channel slices of one gradient buffer; issued as ONE
+    64-column problem each pair, three pairs in one launch, accumulating into existing gradients, biases riding along."""
+    from torchsr_amd import _lib
+    n, h, w, cin_lo, cin, g = 2, 16, 16, 128, 160, 32
+    d = _lib.Conv2dDesc(n, h, w, cin, 192, 2 * g, 192, 3, 3, 1, 1, 0, 2, 0.2, 0, 1 if bf16 else 0)
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t if isinstance(t, int) else t.data_ptr() for t in ts])  # noqa: E731
+    r = (lambda t: t.bfloat16().double()) if bf16 else (lambda t: t.double())
+    nprob = 3
+    bufs = [rnd((n, 192, h, w), 10 + i) for i in range(nprob)]
+    gbufs = [rnd((n, 192, h, w), 20 + i) for i in range(nprob)]
+    base = lambda shape, seed: [rnd(shape, seed + i) for i in range(nprob)]  # noqa: E731
+    wa, wb, ba, bb = base((g, cin_lo, 3, 3), 30), base((g, cin, 3, 3), 40), base((g,), 50), base((g,), 60)
+    gx, gg = [nhwc(t).to(dev) for t in bufs], [nhwc(t).to(dev) for t in gbufs]
+    gwa, gwb, gba, gbb = ([t.to(dev) for t in ts] for ts in (wa, wb, ba, bb))
+    nws = L.srx_conv2d_bwd_weight_multi_ws_floats(C.byref(d), nprob)
+    ws = torch.empty(max(nws, 4), device=dev)
+    _lib.call('srx_conv2d_bwd_weight_multi_pair', C.byref(d), nprob, arr(gx), arr([t.data_ptr() + 4 * cin_lo for t in gg]),
+              arr(gwa), arr(gwb), cin_lo, 1, arr(gba), arr(gbb), ws.data_ptr(), nws, s)
+    tol = 2e-5 if bf16 else 2e-4
+    for i in range(nprob):
+        dya, dyb = gbufs[i][:, cin_lo:cin_lo + g], gbufs[i][:, cin_lo + g:cin_lo + 2 * g]
+        want_a = wa[i].double() + torch.nn.grad.conv2d_weight(r(bufs[i][:, :cin_lo]), (g, cin_lo, 3, 3), r(dya), padding=1)
+        want_b = wb[i].double() + torch.nn.grad.conv2d_weight(r(bufs[i][:, :cin]), (g, cin, 3, 3), r(dyb), padding=1)
+        assert rel_err(gwa[i], want_a.float()) < tol and rel_err(gwb[i], want_b.float()) < tol, i
+        assert rel_err(gba[i], ba[i] + dya.sum((0, 2, 3))) < 2e-4 and rel_err(gbb[i], bb[i] + dyb.sum((0, 2, 3))) < 2e-4, i
+    with pytest.raises(RuntimeError, match='both convs or neither'):
+        _lib.call('srx_conv2d_bwd_weight_multi_pair', C.byref(d), nprob, arr(gx), arr(gg), arr(gwa), arr(gwb), cin_lo, 1,
+                  arr(gba), None, ws.data_ptr(), nws, s)
+
+
 def test_maxpool_relu_backward(dev):
     from torchsr_amd import _lib
     x = torch.relu(rnd((2, 8, 8, 8), 3)).to(dev)    # NHWC, a ReLU output: many exact zeros

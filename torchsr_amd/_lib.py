@@ -91,6 +91,7 @@ _SIGS = {
     'srx_conv2d_bwd_weight_multi_ws_floats': (_Z, [_D, _I]),
     'srx_conv2d_bwd_weight_multi': (_I, [_D, _I, _I, _P, _P, _P, _I, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_weight_multi_scaled': (_I, [_D, _I, _I, _P, _P, _P, _I, _P, _P, _P, _Z, _P]),
+    'srx_conv2d_bwd_weight_multi_pair': (_I, [_D, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _Z, _P]),
     'srx_colsum_ws_floats': (_Z, [_L, _I]),
     'srx_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     'srx_crop_flip_u8': (_I, [_P, _P, _P, _I, _I, _P]),

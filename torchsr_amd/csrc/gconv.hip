@@ -738,6 +738,13 @@ struct WReduce {
   // multiplies the output's weight and bias gradient: the layer's dy tensor stands for scale * dy (a dense block's conv5
   // sees the block's output gradient times scale_ratio, which is then never written out)
   float scale[WG_MAXP];
+  // Paired problems (rows_lo > 0): the tile rows [0, rows_lo) are the gradient of one conv (dw, db; cin_lo input channels)
+  // and the rows above that of a second conv (dw_hi, db_hi; Cin input channels) that reads the SAME input buffer and
+  // whose output gradient is the adjacent channel slice -- two convs of a dense block (esrgan/residual.py:81-85), which
+  // alone are 32 columns wide and would each leave half of every 64-column tile multiplying padding.
+  float* dw_hi[WG_MAXP];
+  float* db_hi[WG_MAXP];
+  int rows_lo, cin_lo;
 };
 
 // PR = 1: bf16 products (the autocast mode).  The contraction runs over pixels, so an MFMA operand is eight
@@ -935,18 +942,28 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab_all, int nsla
   float* __restrict__ db = outs.db[o];
   const float* __restrict__ slab = slab_all + (size_t)o * nslab * Cnw * Kw;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (db && idx < Cout) {  // bias gradient: the slabs' column sums (the grid has >= Cout threads)
-    const float* __restrict__ bslab = bslab_all + (size_t)o * nslab * Cnw;
-    float s = 0.f;
-    for (int z = 0; z < nslab; ++z) s += bslab[(size_t)z * Cnw + idx];
-    s *= outs.scale[o];
-    db[idx] = accumulate ? db[idx] + s : s;
+  const int rows_lo = outs.rows_lo;  // 0: one conv per output
+  if (idx < Cout) {  // bias gradient: the slabs' column sums (the grid has >= Cout threads)
+    float* __restrict__ dbp = (rows_lo && idx >= rows_lo) ? outs.db_hi[o] : db;
+    if (dbp) {
+      const float* __restrict__ bslab = bslab_all + (size_t)o * nslab * Cnw;
+      float s = 0.f;
+      for (int z = 0; z < nslab; ++z) s += bslab[(size_t)z * Cnw + idx];
+      s *= outs.scale[o];
+      const int bi = (rows_lo && idx >= rows_lo) ? (int)idx - rows_lo : (int)idx;
+      dbp[bi] = accumulate ? dbp[bi] + s : s;
+    }
   }
   if (idx >= (int64_t)Cout * K) return;
-  const int np = (int)(idx / K), k = (int)(idx - (int64_t)np * K);
+  const int srow = (int)(idx / K);  // row of the slab
+  const int k = (int)(idx - (int64_t)srow * K);
   const int tap = k / Ck, ci = k - tap * Ck;
+  int np = srow;                    // output channel of the conv the row belongs to
+  if (rows_lo) {  // (no PixelShuffle on paired problems)
+    if (np < rows_lo) { Cin = outs.cin_lo; } else { np -= rows_lo; dw = outs.dw_hi[o]; }
+  }
   if (ci >= Cin) return;
-  const float* sp = slab + (size_t)np * Kw + k;
+  const float* sp = slab + (size_t)srow * Kw + k;
   const size_t zs = (size_t)Cnw * Kw;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int z = 0;
@@ -1832,10 +1849,35 @@ extern "C" int srx_conv2d_bwd_weight_multi(const srx_conv2d_t* d, int nprob, int
   return srx_conv2d_bwd_weight_multi_scaled(d, nprob, per_out, xs, dys, dws, accumulate, dbs, nullptr, ws, ws_floats, stream);
 }
 
+static int wgrad_multi_impl(const srx_conv2d_t* d, int nprob, int per_out, const float* const* xs, const float* const* dys,
+                            float* const* dws, int accumulate, float* const* dbs, const float* out_scales,
+                            float* const* dws_hi, float* const* dbs_hi, int cin_lo, float* ws, size_t ws_floats,
+                            void* stream);
+
 extern "C" int srx_conv2d_bwd_weight_multi_scaled(const srx_conv2d_t* d, int nprob, int per_out, const float* const* xs,
                                                   const float* const* dys, float* const* dws, int accumulate,
                                                   float* const* dbs, const float* out_scales, float* ws, size_t ws_floats,
                                                   void* stream) {
+  return wgrad_multi_impl(d, nprob, per_out, xs, dys, dws, accumulate, dbs, out_scales, nullptr, nullptr, 0, ws, ws_floats,
+                          stream);
+}
+
+extern "C" int srx_conv2d_bwd_weight_multi_pair(const srx_conv2d_t* d, int nprob, const float* const* xs,
+                                                const float* const* dys, float* const* dws_lo, float* const* dws_hi,
+                                                int cin_lo, int accumulate, float* const* dbs_lo, float* const* dbs_hi,
+                                                float* ws, size_t ws_floats, void* stream) {
+  SRX_REQUIRE(d && dws_hi, "conv2d_bwd_weight_multi_pair: null pointer");
+  SRX_REQUIRE(d->Cout % 8 == 0 && !d->shuffle && d->up != 2 && cin_lo > 0 && cin_lo <= d->Cin && !srx_thin_wgrad_applicable(d),
+              "conv2d_bwd_weight_multi_pair: two convs of Cout / 2 output channels each (a multiple of 4), no PixelShuffle, "
+              "no fused upsample, 0 < cin_lo <= Cin");
+  SRX_REQUIRE((dbs_lo == nullptr) == (dbs_hi == nullptr), "conv2d_bwd_weight_multi_pair: bias gradients for both convs or neither");
+  return wgrad_multi_impl(d, nprob, 1, xs, dys, dws_lo, accumulate, dbs_lo, nullptr, dws_hi, dbs_hi, cin_lo, ws, ws_floats, stream);
+}
+
+static int wgrad_multi_impl(const srx_conv2d_t* d, int nprob, int per_out, const float* const* xs, const float* const* dys,
+                            float* const* dws, int accumulate, float* const* dbs, const float* out_scales,
+                            float* const* dws_hi, float* const* dbs_hi, int cin_lo, float* ws, size_t ws_floats,
+                            void* stream) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(nprob >= 1 && nprob <= WG_MAXP && per_out >= 1 && nprob % per_out == 0,
               "conv2d_bwd_weight_multi: 1..%d problems, a whole number of outputs", WG_MAXP);
@@ -1850,15 +1892,15 @@ extern "C" int srx_conv2d_bwd_weight_multi_scaled(const srx_conv2d_t* d, int npr
       up_x[i] = ws + (size_t)i * tmp;
       if (int rc = srx_upsample_nearest2x_fwd(xs[i], ws + (size_t)i * tmp, d->N, d->H, d->W, d->Cin_s, stream)) return rc;
     }
-    return srx_conv2d_bwd_weight_multi_scaled(&h, nprob, per_out, up_x, dys, dws, accumulate, dbs, out_scales,
-                                              ws + nprob * tmp, ws_floats - nprob * tmp, stream);
+    return wgrad_multi_impl(&h, nprob, per_out, up_x, dys, dws, accumulate, dbs, out_scales, nullptr, nullptr, 0,
+                            ws + nprob * tmp, ws_floats - nprob * tmp, stream);
   }
   const int nout = nprob / per_out;
   bool any_db = false;
   for (int i = 0; i < nprob; ++i) SRX_REQUIRE(xs[i] && dys[i], "conv2d_bwd_weight: null tensor in problem %d", i);
   for (int o = 0; o < nout; ++o) {
-    SRX_REQUIRE(dws[o], "conv2d_bwd_weight: null gradient pointer for output %d", o);
-    any_db |= dbs && dbs[o];
+    SRX_REQUIRE(dws[o] && (!dws_hi || dws_hi[o]), "conv2d_bwd_weight: null gradient pointer for output %d", o);
+    any_db |= (dbs && dbs[o]) || (dbs_hi && dbs_hi[o]);
   }
   if (any_db && d->shuffle) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_weight: bias gradient of a PixelShuffle layer is not fused");
   hipStream_t st = srx_stream(stream);
@@ -1924,7 +1966,10 @@ extern "C" int srx_conv2d_bwd_weight_multi_scaled(const srx_conv2d_t* d, int npr
   for (int i = 0; i < nprob; ++i) { mp.x[i] = xs[i]; mp.dy[i] = dys[i]; }
   for (int o = 0; o < nout; ++o) {
     outs.dw[o] = dws[o]; outs.db[o] = dbs ? dbs[o] : nullptr; outs.scale[o] = out_scales ? out_scales[o] : 1.f;
+    outs.dw_hi[o] = dws_hi ? dws_hi[o] : nullptr; outs.db_hi[o] = dbs_hi ? dbs_hi[o] : nullptr;
   }
+  outs.rows_lo = dws_hi ? d->Cout / 2 : 0;
+  outs.cin_lo = cin_lo;
   dim3 grid((unsigned)(tiles * nprob * nsplit));
   const double wfl = 2.0 * a.M * d->Cout * a.K * nprob;
   char nm[112];

@@ -63,13 +63,39 @@ class WeightGradQueue:
 
     def __init__(self):
         self.groups = {}
+        self.pairs = {}
 
     def add(self, d: Conv2dDesc, x_ptr: int, dy_ptr: int, sink_ptr: int, bias_ptr, keep, scale: float = 1.0) -> None:
         """``scale``: the tensor at ``dy_ptr`` stands for ``scale * dy`` (one value per sink)."""
         key = tuple(getattr(d, f) for f, _ in Conv2dDesc._fields_)
         self.groups.setdefault(key, [d, []])[1].append((x_ptr, dy_ptr, sink_ptr, bias_ptr or 0, keep, float(scale)))
 
+    def add_pair(self, d: Conv2dDesc, cin_lo: int, x_ptr: int, dy_ptr: int, sinks, bias_sinks, keep) -> None:
+        """Two convs that read the same input buffer and whose output gradients are adjacent channel slices, as ONE
+        problem (``srx_conv2d_bwd_weight_multi_pair``): ``sinks`` / ``bias_sinks`` are (first conv, second conv)."""
+        key = ('pair', cin_lo, bias_sinks is None) + tuple(getattr(d, f) for f, _ in Conv2dDesc._fields_)
+        self.pairs.setdefault(key, [d, cin_lo, []])[2].append((x_ptr, dy_ptr, sinks, bias_sinks, keep))
+
+    def _flush_pairs(self) -> None:
+        pairs, self.pairs = self.pairs, {}
+        L, s = _lib.lib(), _stream()
+        arr = lambda vals: (C.c_void_p * len(vals))(*vals)  # noqa: E731
+        for d, cin_lo, items in pairs.values():
+            dref = C.byref(d)
+            for i in range(0, len(items), self.MAXP):
+                part = items[i:i + self.MAXP]
+                n = len(part)
+                nws = L.srx_conv2d_bwd_weight_multi_ws_floats(dref, n)
+                ws = torch.empty(max(int(nws), 4), dtype=torch.float32, device=part[0][4][0].device)
+                with_bias = part[0][3] is not None
+                call('srx_conv2d_bwd_weight_multi_pair', dref, n, arr([p[0] for p in part]), arr([p[1] for p in part]),
+                     arr([p[2][0] for p in part]), arr([p[2][1] for p in part]), cin_lo, 1,
+                     arr([p[3][0] for p in part]) if with_bias else None, arr([p[3][1] for p in part]) if with_bias else None,
+                     _p(ws), nws, s)
+
     def flush(self) -> None:
+        if self.pairs:
+            self._flush_pairs()
         groups, self.groups = self.groups, {}
         if not groups:
             return
@@ -1406,6 +1432,19 @@ class _RRDBTrunk(Function):
                 skip_scale = 1.0
             dx = torch.empty((n, h, w, c0), dtype=torch.float32, device=dev)
             keep = (buf, gbuf, grad)
+            # conv1 + conv2 and conv3 + conv4 read the same buffer and their output gradients are adjacent slices of gbuf:
+            # queued as two 64-column weight-gradient problems instead of four 32-column ones (half a tile of padding each)
+            wsinks = [_sink(ctx.params[10 * i + 2 * k]) for k in range(4)]
+            bsinks = [_sink(ctx.params[10 * i + 2 * k + 1]) for k in range(4)]
+            paired = (queue is not None and all(v is not None for v in wsinks) and all(v is not None for v in bsinks)
+                      and all(ctx.needs_input_grad[5 + 10 * i + kk] for kk in range(8)))
+            if paired:
+                for lo in (0, 2):
+                    st = ctx.states[i][lo + 1]
+                    dp = Conv2dDesc(n, h, w, c0 + (lo + 1) * g, total, 2 * g, total, st.k, st.k, st.stride, st.pad, 0, st.act,
+                                    st.slope, 0, st.precision)
+                    queue.add_pair(dp, c0 + lo * g, _p(buf), gbuf.data_ptr() + 4 * (c0 + lo * g),
+                                   (_p(wsinks[lo]), _p(wsinks[lo + 1])), (_p(bsinks[lo]), _p(bsinks[lo + 1])), keep)
             for k in (4, 3, 2, 1, 0):
                 st, d = ctx.states[i][k], ctx.descs[i][k]
                 cin = c0 + k * g
@@ -1417,7 +1456,9 @@ class _RRDBTrunk(Function):
                     gk, wscale = gbuf.data_ptr() + 4 * cin, 1.0
                 dref = C.byref(d)
                 wparam, bparam = ctx.params[10 * i + 2 * k], ctx.params[10 * i + 2 * k + 1]
-                if ctx.needs_input_grad[5 + 10 * i + 2 * k]:
+                if paired and k < 4:
+                    pass  # (queued above: the queue runs after the whole backward pass, when every slice of gbuf is complete)
+                elif ctx.needs_input_grad[5 + 10 * i + 2 * k]:
                     sink = _sink(wparam)
                     dw = None if sink is not None else torch.empty((st.cout, st.cin, st.k, st.k), dtype=torch.float32,
                                                                      device=dev)
