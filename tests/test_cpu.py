@@ -100,7 +100,7 @@ def test_library_exports_every_declared_symbol():
     from torchsr_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()
-    handle = ctypes.CDLL(_lib.LIB_PATH)
+    handle = _lib.load_handle(_lib.LIB_PATH)   # (on a GPU box: after torch has initialised HIP)
     header = open(os.path.join(ROOT, 'include', 'srx.h')).read()
     declared = set(re.findall(r'\b(srx_[a-z0-9_]+)\s*\(', header))
     assert declared, 'no declarations found'

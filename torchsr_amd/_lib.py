@@ -146,6 +146,16 @@ EXPORTS = tuple(_SIGS.keys())
 _lib = None
 
 
+def load_handle(path: str) -> C.CDLL:
+    """dlopen the library -- after PyTorch has initialised HIP when there is a GPU.  Loading it first (its fat binary
+    then registers with a runtime torch initialises later) makes every launch from it fail with 'no ROCm-capable device
+    is detected' on this stack (measured: tools/experiments/bisect_smoke.py).  Without a GPU it simply loads."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+    return C.CDLL(path)
+
+
 def lib() -> C.CDLL:
     """Load the shared library (once).  Raises if it has not been built."""
     global _lib
@@ -155,7 +165,7 @@ def lib() -> C.CDLL:
                 f'{LIB_PATH} is missing: the MI355X HIP extension has not been built. '
                 'Run `python -c "import __graft_entry__ as g; g.build()"` (needs hipcc). '
                 'There is no CPU fallback for the product path.')
-        handle = C.CDLL(LIB_PATH)
+        handle = load_handle(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             try:
                 fn = getattr(handle, name)
