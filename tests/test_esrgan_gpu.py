@@ -264,3 +264,25 @@ def test_esrgan_segmented_step_equals_fused(dev):
         assert not tb._cuts.pairs
     assert {'gan.disc.head', 'gan.disc.body', 'gan.content', 'gan.gen.head', 'gan.gen.body', 'gan.gopt'} <= set(tb._graphs)
     assert F.cut_hook[0] is None
+
+
+def test_esrgan_step_is_bitwise_reproducible(dev):
+    """Two ESRGAN trainers (bf16 products, the RRDB trunk node, paired and scaled weight-gradient groups, hipGraph replays
+    from the third step) from the same state: bit-identical losses and parameters after four steps."""
+    gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
+    lr, hr = torch.from_numpy(gold['low_res']).to(dev), torch.from_numpy(gold['high_res']).to(dev)
+    runs = []
+    for _ in range(2):
+        t = make_trainer(dev, disable_amp=False, use_graphs=True)
+        losses = [[v.item() for v in t.gan_step(lr, hr).values()] for _step in range(4)]
+        assert 'gan.all' in t._graphs
+        runs.append((losses, {k: v.clone() for k, v in t.generator.state_dict().items()},
+                     {k: v.clone() for k, v in t.discriminator.state_dict().items()}))
+        del t
+        torch.cuda.empty_cache()
+        junk = torch.full((64 << 20,), float('nan'), device=dev)
+        del junk
+    assert runs[0][0] == runs[1][0]
+    for a, b in ((runs[0][1], runs[1][1]), (runs[0][2], runs[1][2])):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k

@@ -222,6 +222,33 @@ def test_graph_replay_equals_eager(dev):
         assert torch.allclose(tg.generator(lr), te.generator(lr), rtol=1e-4, atol=1e-5)
 
 
+def test_step_is_bitwise_reproducible(dev):
+    """No float atomics, no dependence on stale memory, no ordering races: two trainers built from the same state take
+    the same six BASELINE-size steps (two eager, then hipGraph replays) to bit-identical losses, parameters and
+    BatchNorm buffers -- reductions are two-stage with a fixed order, weight-gradient slabs are summed in order, the
+    grouped launches always see their problems in the same order."""
+    torch.manual_seed(5)
+    lr, hr = torch.rand(16, 3, 24, 24, device=dev), torch.rand(16, 3, 96, 96, device=dev)
+    runs = []
+    for _ in range(2):
+        t = make_trainer(dev, True, batch=16)
+        losses = []
+        for _step in range(6):
+            out = t.gan_step(lr, hr)
+            losses.append([out[k].item() for k in LOSS_KEYS])
+        assert 'gan.all' in t._graphs
+        runs.append((losses, {k: v.clone() for k, v in t.generator.state_dict().items()},
+                     {k: v.clone() for k, v in t.discriminator.state_dict().items()}))
+        del t
+        torch.cuda.empty_cache()   # the second trainer gets other addresses and recycled (dirty) memory
+        junk = torch.full((64 << 20,), float('nan'), device=dev)
+        del junk
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for a, b in ((runs[0][1], runs[1][1]), (runs[0][2], runs[1][2])):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_pack_tables_take_over_after_the_first_step(dev):
     """After the first optimiser step every conv of G / D is repacked by one table launch per model
     (functional.PackTable) and the lazy per-layer pack finds its key current."""
