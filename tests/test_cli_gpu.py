@@ -105,3 +105,12 @@ def test_esrgan_train_cli(dev, tmp_path, monkeypatch):
     ckpt = torch.load('esrgan-gan-latest.pth', map_location='cpu')
     assert ckpt['phase'] == 'esrgan-gan' and len(ckpt['state']) == 702
     assert all(torch.isfinite(v).all() for v in ckpt['state'].values() if v.is_floating_point())
+    # `torchsr test --model esrgan` on the checkpoint just written (the RRDB trunk without a backward pass: four
+    # rotating buffers), then the same training run with the device data pipeline at ESRGAN's 128-pixel crops
+    from PIL import Image
+    Image.fromarray((np.random.RandomState(1).rand(36, 44, 3) * 255).astype('uint8')).save('lr.png')
+    main(['test', 'lr.png', '--model', 'esrgan'])
+    out = np.asarray(Image.open('upres-lr.png'))
+    assert out.shape == (144, 176, 3) and out.std() > 0
+    main(['train', '--model', 'esrgan', '--train-dir', 'synthetic:8', '--batch-size', '2', '--epochs', '1',
+          '--pretrain-epochs', '1', '--seed', '8', '--vgg-weights', 'random', '--skip-image-save', '--device-data'])
