@@ -1507,6 +1507,8 @@ class _RRDBTrunk(Function):
 def rrdb_trunk(x: Tensor, rrdbs) -> Tensor:
     """``rrdbs``: the generator's ``ResidualInResidualDenseBlock`` modules, in order (``nn.Sequential(*blocks)(x)``)."""
     from .layers import _w
+    if not rrdbs:
+        return x
     states, masters, wb, scales = [], [], [], []
     for rr in rrdbs:
         for rdb in (rr.RDB1, rr.RDB2, rr.RDB3):
