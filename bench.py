@@ -137,6 +137,39 @@ def north_star_in_graph(device, reps=66, replays=20):
             'note': 'includes the ~1.5 us kernel boundary between dependent launches'}
 
 
+def dominant_shape_in_graph(device, reps=20, replays=10):
+    """The dominant kernel's top layer shape (VGG19 block 3, 3x3 256->256 + bias + ReLU on source and target as one batch of
+    32 at 24x24: M 18432, N 256, K 2304) as `reps` back-to-back launches inside a replayed hipGraph -- the per-launch time
+    without the dispatch gaps that the eager event pairs of `roofline_pass` include."""
+    from torchsr_amd.layers import ACT_RELU, Conv2d
+    torch.manual_seed(4)
+    conv = Conv2d(256, 256, 3, 1, 1, act=ACT_RELU).to(device)
+    x = torch.rand(32, 24, 24, 256, device=device)
+    with torch.no_grad():
+        conv(x)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                conv(x)
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(replays):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e3 / reps)
+    times.sort()
+    us = times[len(times) // 2]
+    gf = 2.0 * 18432 * 256 * 2304 / 1e9
+    return {'MxNxK': '18432x256x2304', 'launches_per_replay': reps, 'us_per_launch_in_graph': round(us, 2),
+            'gflop_per_launch': round(gf, 3), 'tflops': round(gf / us * 1e3, 2), 'frac': round(gf / us * 1e3 / PEAK_TFLOPS, 4)}
+
+
 def roofline_pass(trainer, lr, hr, reps=2):
     """Eager pass with the library's launch profiler on: every conv kernel launch is bracketed by two
     HIP events recorded on its own stream inside libsrx_hip.so (srx_prof_*), around that one kernel."""
@@ -357,6 +390,8 @@ def main():
                 try:
                     out['roofline'] = roofline_pass(trainer, lr, hr)
                     out['roofline']['north_star'] = north_star_in_graph(device)
+                    if out['roofline'].get('traffic_shape_MxNxK') == '18432x256x2304':
+                        out['roofline']['dominant_shape_in_graph'] = dominant_shape_in_graph(device)
                 except Exception as exc:  # noqa: BLE001
                     print(f'bench.py: roofline pass failed: {type(exc).__name__}: {exc}', file=sys.stderr)
                     out.setdefault('roofline', None)
