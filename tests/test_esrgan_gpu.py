@@ -286,3 +286,50 @@ def test_esrgan_step_is_bitwise_reproducible(dev):
     for a, b in ((runs[0][1], runs[1][1]), (runs[0][2], runs[1][2])):
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize('bf16', [False, True])
+def test_rrdb_modules_alone_equal_the_trunk_node(dev, bf16):
+    """`ResidualInResidualDenseBlock` / `ResidualDenseBlock` called directly (esrgan/residual.py:65-86,110-129: one
+    autograd node per dense block, `out * 0.2 + x` as an elementwise pass) against the generator's one-node chain
+    (`functional.rrdb_trunk`, which the goldens pin): outputs, input gradient and every parameter gradient."""
+    from torchsr_amd import functional as F
+    from torchsr_amd.esrgan.residual import ResidualInResidualDenseBlock
+    from torchsr_amd.layers import set_conv_precision
+    torch.manual_seed(9)
+    blocks = torch.nn.Sequential(*[ResidualInResidualDenseBlock() for _ in range(2)]).to(dev)
+    with torch.no_grad():
+        for p in blocks.parameters():   # (the reference's x0.1 init makes the residual branches tiny: scale them up)
+            p.mul_(4.0)
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    if bf16:
+        set_conv_precision(blocks, 'bf16')
+    x = torch.randn(2, 16, 16, 64, device=dev)
+    gy = torch.randn(2, 16, 16, 64, device=dev)
+    def run(how):
+        blocks.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = blocks(xi) if how == 'modules' else F.rrdb_trunk(xi, list(blocks))
+        y.backward(gy)
+        return y.detach(), xi.grad.clone(), [p.grad.clone() for p in blocks.parameters()]
+
+    (ya, dxa, ga), (yb, dxb, gb) = run('modules'), run('trunk')
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()  # noqa: E731
+    # fp32: the same arithmetic in another order.  bf16 products: the modules round conv5's output gradient AFTER the
+    # block's 0.2 (bf16(0.2 dy), what autograd hands the conv), the trunk rounds dy and applies 0.2 to the fp32 result
+    # (0.2 W^T bf16(dy)) -- 0.2 is not a power of two, so the two differ by bf16 rounding noise on the way back
+    # -- and every later operand that differs in its last fp32 bits may round to the other bf16 neighbour (2^-9 of that
+    # product).  The parameter gradients are sums over only 512 pixels here: compared in the L2 norm, loosely element-wise.
+    rel2 = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-12)).item()  # noqa: E731
+    assert rel(ya, yb) < 1e-5 and rel(dxa, dxb) < (5e-4 if bf16 else 2e-5), (rel(ya, yb), rel(dxa, dxb))
+    if bf16:  # yardstick: the exact-fp32 gradients.  Two bf16 evaluation orders must be closer to each other than to those
+        set_conv_precision(blocks, 'fp32')
+        _, dxe, ge = run('modules')
+        assert rel2(dxa, dxb) < rel2(dxa, dxe) and rel2(dxb, dxe) < 2e-2, (rel2(dxa, dxb), rel2(dxa, dxe), rel2(dxb, dxe))
+    for i, ((name, _), a, b) in enumerate(zip(blocks.named_parameters(), ga, gb)):
+        if bf16:
+            far_a, far_b = rel2(a, ge[i]), rel2(b, ge[i])
+            assert rel2(a, b) < max(far_a, far_b) and far_b < max(2 * far_a, 1e-2), (name, rel2(a, b), far_a, far_b)
+        else:
+            assert rel(a, b) < 2e-5, (name, rel(a, b))

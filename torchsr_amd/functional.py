@@ -1344,6 +1344,11 @@ class _RRDBTrunk(Function):
     weight gradient takes ``scale`` in the slab reduction (``srx_conv2d_bwd_weight_multi_scaled``), and conv1's data
     gradient writes the block's input gradient as a dense tensor, adding what conv2..5 left in the shared gradient
     buffer.  Per RRDB one elementwise pass is left in each direction (before: four and ten).
+
+    With bf16 products the scale meets the rounding in the other order than in autograd's graph: conv5's data and weight
+    gradient multiply bf16(dy) and apply ``scale`` to the fp32 result, where the chain of separate nodes rounds
+    ``scale * dy`` -- two evaluation orders of the same product, both within bf16 rounding of the exact gradient and
+    closer to each other than either is to it (``tests/test_esrgan_gpu.py::test_rrdb_modules_alone_equal_the_trunk_node``).
     """
 
     @staticmethod
