@@ -170,23 +170,21 @@ def dominant_shape_in_graph(device, reps=20, replays=10):
             'gflop_per_launch': round(gf, 3), 'tflops': round(gf / us * 1e3, 2), 'frac': round(gf / us * 1e3 / PEAK_TFLOPS, 4)}
 
 
-def roofline_pass(trainer, lr, hr, reps=2):
-    """Eager pass with the library's launch profiler on: every conv kernel launch is bracketed by two
-    HIP events recorded on its own stream inside libsrx_hip.so (srx_prof_*), around that one kernel."""
+def prof_tables(step_fn, reps=2, slots=4096):
+    """Run ``step_fn`` eagerly ``reps`` times with the library's launch profiler on: every conv kernel launch is
+    bracketed by two HIP events recorded on its own stream inside libsrx_hip.so (srx_prof_*), around that one kernel.
+    Returns ({'kernel MxNxK=..': [ms, flops, launches]}, {'kernel': [ms, flops, launches]}) summed over the reps."""
     from torchsr_amd import _lib
-    was = trainer.use_graphs
-    trainer.use_graphs = False
-    trainer.gan_step(lr, hr)  # eager warm-up (repacks, allocator)
+    step_fn()  # eager warm-up (repacks, allocator)
     torch.cuda.synchronize()
-    _lib.call('srx_prof_start', 4096 * reps)
+    _lib.call('srx_prof_start', slots * reps)
     try:
         for _ in range(reps):
             torch.cuda._sleep(int(2.0e8))  # let the host run ahead so that launches queue back to back
-            trainer.gan_step(lr, hr)
+            step_fn()
         torch.cuda.synchronize()
     finally:
         n = _lib.lib().srx_prof_stop()
-        trainer.use_graphs = was
     pairs, kernels = {}, {}
     name = C.create_string_buffer(112)
     ms, fl = C.c_float(), C.c_double()
@@ -198,6 +196,30 @@ def roofline_pass(trainer, lr, hr, reps=2):
             gsum[0] += ms.value
             gsum[1] += fl.value
             gsum[2] += 1
+    return pairs, kernels
+
+
+def dominant_of(step_fn, peak_tflops, reps=2, slots=4096):
+    """The conv kernel with the most device time per call of ``step_fn`` (other_configs legs)."""
+    _pairs, kernels = prof_tables(step_fn, reps, slots)
+    if not kernels:
+        return None
+    kname, (ms, fl, cnt) = max(kernels.items(), key=lambda kv: kv[1][0])
+    tf = fl / (ms * 1e-3) / 1e12
+    return {'kernel': kname, 'ms': round(ms / reps, 3), 'launches': cnt // reps, 'avg_launch_us': round(ms / cnt * 1e3, 2),
+            'tflops': round(tf, 2), 'frac': round(tf / peak_tflops, 4),
+            'conv_kernel_ms': round(sum(v[0] for v in kernels.values()) / reps, 3),
+            'conv_launches': sum(v[2] for v in kernels.values()) // reps}
+
+
+def roofline_pass(trainer, lr, hr, reps=2):
+    """The headline step's dominant kernel (see ``prof_tables``)."""
+    was = trainer.use_graphs
+    trainer.use_graphs = False
+    try:
+        pairs, kernels = prof_tables(lambda: trainer.gan_step(lr, hr), reps)
+    finally:
+        trainer.use_graphs = was
     total_ms = sum(v[0] for v in kernels.values())
     if os.environ.get('SRX_BENCH_SHAPES'):  # developer aid: the full (kernel, shape) table
         with open(os.environ['SRX_BENCH_SHAPES'], 'w') as f:
@@ -234,6 +256,123 @@ def roofline_pass(trainer, lr, hr, reps=2):
         'gflop_per_launch': round(fl / cnt / 1e9, 4),
         'conv_ms_per_step': round(total_ms / reps, 3), 'by_shape': shapes, 'by_kernel': table,
     }
+
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+ESRGAN_EXECUTED_GF = 3034.6  # per batch-16 step: SURVEY.md 8d's 3622 GF minus the second generator forward (587.43),
+#                              which recomputes the first bit for bit and is not run (torchsr_amd/esrgan/trainer.py)
+INFER_GF = 9199.0  # SRGAN generator forward, 1080x1920 -> 4320x7680
+
+
+def _targs(batch, amp, **extra):
+    return Namespace(disable_amp=not amp, batch_size=batch, epochs=8, gan_checkpoint=None, local_rank=0, pretrain_epochs=1,
+                     psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1, use_graphs=True, vgg_weights='random',
+                     **extra)
+
+
+def _timed(fn, steps, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def _crops(device, n, crop, seed):
+    g = torch.Generator().manual_seed(seed)
+    hr = torch.rand(n, 3, crop, crop, generator=g)
+    lr = torch.nn.functional.interpolate(hr, scale_factor=0.25, mode='bicubic', align_corners=False, antialias=True).clamp(0, 1)
+    return lr.to(device), hr.to(device)
+
+
+def other_configs(device):
+    """BASELINE.json's other configurations, each timed on this GPU after the headline region (N = 1 only): wall time
+    per step over hipGraph replays with a synchronize on both sides, inputs resident in HBM, the EXECUTED algorithmic
+    GFLOP (2 x MACs of conv + linear), the fraction of the MFMA peak of the arithmetic the configuration asks for, and
+    the dominant conv kernel from an eager ``srx_prof_*`` pass.  A leg that fails reports its error instead."""
+    from torchsr_amd.esrgan.trainer import ESRGANTrainer
+    from torchsr_amd.srgan.generator import Generator
+    from torchsr_amd.srgan.trainer import SRGANTrainer
+    from torchsr_amd.test import upscale
+    out = {}
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as exc:  # noqa: BLE001
+            print(f'bench.py: other_configs[{name}] failed: {type(exc).__name__}: {exc}', file=sys.stderr)
+            out[name] = {'error': f'{type(exc).__name__}: {exc}'}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    def pretrain(b):
+        torch.manual_seed(0)
+        t = SRGANTrainer(device, _targs(b, False), [], [], b, b)
+        lr, hr = _crops(device, b, 96, 77)
+        dt = _timed(lambda: t.pretrain_step(lr, hr), 50, 6)
+        gf = 7.648 * b
+        t.use_graphs = False
+        dom = dominant_of(lambda: t.pretrain_step(lr, hr), PEAK_TFLOPS)
+        return {'workload': f'SRGAN SRResNet pre-training step (BASELINE configs[0] shape), 96x96 crops, batch {b}, fp32',
+                'ms': round(dt * 1e3, 3), 'crops_per_s': round(b / dt, 1), 'executed_gflop': round(gf, 2),
+                'tflops': round(gf / dt / 1e3, 2), 'peak_tflops': PEAK_TFLOPS, 'frac': round(gf / dt / 1e3 / PEAK_TFLOPS, 4),
+                'dtype': 'f32', 'dominant_kernel': dom}
+
+    def esrgan():
+        torch.manual_seed(0)
+        t = ESRGANTrainer(device, _targs(16, True), [], [], 16, 16)
+        lr, hr = _crops(device, 16, 128, 78)
+        dt = _timed(lambda: t.gan_step(lr, hr), 15, 5)
+        gf = ESRGAN_EXECUTED_GF
+        t.use_graphs = False
+        dom = dominant_of(lambda: t.gan_step(lr, hr), PEAK_BF16_TFLOPS, reps=1, slots=8192)
+        return {'workload': 'ESRGAN full GAN step (23-RRDB generator + relativistic discriminator + VGG19), 128x128 crops, '
+                            'batch 16, bf16 products / fp32 accumulate (BASELINE configs[3])',
+                'ms': round(dt * 1e3, 3), 'crops_per_s': round(16 / dt, 1), 'executed_gflop': gf,
+                'reference_executes_gflop': 3622.0, 'tflops': round(gf / dt / 1e3, 2), 'peak_tflops': PEAK_BF16_TFLOPS,
+                'frac': round(gf / dt / 1e3 / PEAK_BF16_TFLOPS, 4), 'dtype': 'bf16 products, f32 accumulate',
+                'dominant_kernel': dom}
+
+    def infer(precision):
+        torch.manual_seed(0)
+        gen = Generator().to(device).eval()
+        lr = torch.rand(1, 3, 1080, 1920, device=device)
+        kw = {} if precision == 'fp32' else {'precision': precision}
+        dt = _timed(lambda: upscale(gen, lr, **kw), 5, 2)
+        peak = PEAK_TFLOPS if precision == 'fp32' else PEAK_BF16_TFLOPS
+        dom = dominant_of(lambda: upscale(gen, lr, **kw), peak, reps=1, slots=8192)
+        return {'workload': f'SRGAN generator 1920x1080 -> 7680x4320, batch 1, eval mode, tiled, {precision} '
+                            '(BASELINE configs[4])',
+                'ms_per_image': round(dt * 1e3, 2), 'executed_gflop': INFER_GF, 'tflops': round(INFER_GF / dt / 1e3, 2),
+                'peak_tflops': peak, 'frac': round(INFER_GF / dt / 1e3 / peak, 4),
+                'dtype': 'f32' if precision == 'fp32' else 'bf16 products, f32 accumulate', 'dominant_kernel': dom}
+
+    leg('srgan_pretrain_b2', lambda: pretrain(2))
+    leg('srgan_pretrain_b16', lambda: pretrain(16))
+    leg('esrgan_gan_b16_bf16', esrgan)
+    leg('infer_1080p_fp32', lambda: infer('fp32'))
+    leg('infer_1080p_bf16', lambda: infer('bf16'))
+    return out
+
+
+def dp_rehearsal(timeout_s=240):
+    """The data-parallel form of the step on RCCL at world size 1, in a child process (its own process group; a hang
+    in there cannot take the headline with it): ``SRX_BENCH_FORCE_DIST=1 python bench.py``.  Returns the child's
+    ``dp`` object: backend, buckets, segmented vs fused ms per step on the same GPU."""
+    import subprocess
+    env = dict(os.environ, SRX_BENCH_FORCE_DIST='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', '40', '--warmup', '5', '--no-parity', '--no-roofline',
+           '--no-cpu-baseline', '--no-other-configs']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+    if res.returncode != 0:
+        raise RuntimeError(f'child exited {res.returncode}: {res.stderr[-400:]}')
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
+    return json.loads(line)['dp']
 
 
 def cpu_baseline(states, lr, hr, warmup=3, steps=10, budget_s=60.0):
@@ -282,6 +421,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true')
+    ap.add_argument('--no-dp-rehearsal', action='store_true')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -295,7 +436,19 @@ def main():
     dev_index = 0 if os.environ.get('SRX_BENCH_ONE_GPU') == '1' else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-    distributed = world > 1
+    # SRX_BENCH_FORCE_DIST=1: take the data-parallel (segmented, bucketed) path at world size 1 too, on a real RCCL
+    # process group, with the all-reduces issued -- `torchrun --nproc-per-node 1 bench.py` or a plain `python bench.py`
+    forced = world == 1 and os.environ.get('SRX_BENCH_FORCE_DIST') == '1'
+    distributed = world > 1 or forced
+    if forced:
+        import socket
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        if 'MASTER_PORT' not in os.environ:
+            sock = socket.socket()
+            sock.bind(('127.0.0.1', 0))
+            os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
+            sock.close()
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('SRX_BENCH_BACKEND', 'nccl')  # 'nccl' is RCCL on ROCm
@@ -310,14 +463,16 @@ def main():
     torch.manual_seed(0)  # identical init on every rank (and an explicit broadcast in the trainer)
     targs = Namespace(disable_amp=True, batch_size=BATCH, epochs=8, gan_checkpoint=None, local_rank=local_rank,
                       pretrain_epochs=1, psnr_checkpoint=None, skip_image_save=True, world_size=world,
-                      rank=rank if distributed else -1, use_graphs=not args.no_graphs, vgg_weights='random')
+                      rank=rank if distributed else -1, use_graphs=not args.no_graphs, vgg_weights='random',
+                      force_collectives=forced)
     trainer = SRGANTrainer(device, targs, [], [], BATCH, BATCH, distributed=distributed)
     trainer.generator.train()
     trainer.discriminator.train()
     lr, hr = synth_batch(device, rank)
 
-    want_parity = world == 1 and not args.no_parity
-    states0 = cpu_states(trainer) if (world == 1 and not (args.no_parity and args.no_cpu_baseline)) else None
+    single = world == 1 and not forced  # the side measurements of the default one-GPU run
+    want_parity = single and not args.no_parity
+    states0 = cpu_states(trainer) if (single and not (args.no_parity and args.no_cpu_baseline)) else None
     first = trainer.gan_step(lr, hr)  # set-up step 1 of 3 (eager); its losses feed the parity check
     first = {k: float(v) for k, v in first.items()} if want_parity else None
     for _ in range(2):  # set-up: second eager pass + hipGraph capture (not warm-up, not timed)
@@ -345,7 +500,35 @@ def main():
 
     # spread of the step time (outside the timed region): per-step HIP events on the step's stream
     spread = None
-    if rank == 0 and not distributed:
+    dp = None
+    if forced:
+        # the same step as ONE hipGraph without cuts, buckets or collectives, same process, same GPU: what the
+        # segmentation itself costs on one GPU (the ceiling on multi-GPU efficiency before any wire time)
+        torch.manual_seed(0)
+        fargs = Namespace(**{**vars(targs), 'rank': -1, 'force_collectives': False})
+        fused = SRGANTrainer(device, fargs, [], [], BATCH, BATCH, distributed=False)
+        fused.generator.train()
+        fused.discriminator.train()
+        for _ in range(3 + args.warmup):
+            fused.gan_step(lr, hr)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            fused.gan_step(lr, hr)
+        torch.cuda.synchronize()
+        fused_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        seg_ms = elapsed / args.steps * 1e3
+        dp = {'process_group': describe_group(), 'collectives_issued_per_step': 4,
+              'collectives_issued_total': trainer.gen_sync.issued + trainer.disc_sync.issued,
+              'grad_buckets': {'generator': len(trainer.gen_sync), 'discriminator': len(trainer.disc_sync)},
+              'bucket_bytes': {'generator': [int(x.numel()) * 4 for x in trainer.gen_sync.slices],
+                               'discriminator': [int(x.numel()) * 4 for x in trainer.disc_sync.slices]},
+              'graph_segments': sorted(k for k in trainer._graphs), 'hip_graph': trainer.use_graphs,
+              'segmented_ms_per_step': round(seg_ms, 3), 'fused_ms_per_step': round(fused_ms, 3),
+              'segmentation_overhead': round(seg_ms / fused_ms - 1.0, 4), 'steps': args.steps,
+              'what': 'SRGAN GAN step, batch 16, world size 1 on RCCL: 7 hipGraph segments + 4 async all-reduces '
+                      '(no-op sums) vs the single-graph step; unmeasured at N > 1'}
+    if rank == 0 and single:
         evs = []
         for _ in range(min(args.steps, 50)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -378,7 +561,9 @@ def main():
             'step_ms_spread': spread,
             'final_gen_loss': round(gen_loss, 6),
         }
-        if world == 1:
+        if dp is not None:
+            out['dp'] = dp
+        if single:
             # the headline line must survive a failure of any side measurement
             if want_parity:
                 try:
@@ -401,6 +586,16 @@ def main():
                 except Exception as exc:  # noqa: BLE001
                     print(f'bench.py: cpu baseline failed: {type(exc).__name__}: {exc}', file=sys.stderr)
                     out['cpu_baseline'] = None
+            if not args.no_other_configs:
+                del trainer
+                torch.cuda.empty_cache()
+                out['other_configs'] = other_configs(device)
+            if not args.no_dp_rehearsal:
+                try:
+                    out['dp_rehearsal'] = dp_rehearsal()
+                except Exception as exc:  # noqa: BLE001
+                    print(f'bench.py: dp rehearsal failed: {type(exc).__name__}: {exc}', file=sys.stderr)
+                    out['dp_rehearsal'] = {'error': f'{type(exc).__name__}: {str(exc)[-300:]}'}
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

@@ -238,6 +238,13 @@ int srx_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx
 int srx_lrelu_fwd(const float* x, float* y, int64_t n, float slope, void* stream);
 /* y = a*x + b*z  (residual scaling of esrgan/residual.py:86,128; torch.add of srgan/generator.py:78) */
 int srx_axpby(const float* x, const float* z, float* y, int64_t n, float a, float b, void* stream);
+/* Per-step scalars without a per-step device->host sync: append n <= 4 device scalars (*a, *b, *c, *d) as one
+ * 4-float record to ring[(*counter % cap) * 4 ...] and increment *counter (device int32).  The launch is the same every
+ * step, so it sits inside the replayed hipGraph; the host reads `cap` records back in one copy.  Replaces the
+ * reference's `wandb.log({... 'train-loss': loss}, step)` tensor -> host read on every step
+ * (srgan/trainer.py:393-399,459-466; esrgan/trainer.py:393-399,471-478) */
+int srx_ring_push(const float* a, const float* b, const float* c, const float* d, int n, float* ring, int* counter,
+                  int cap, void* stream);
 /* y[m][y_off+c] = a*x[m][x_off+c] + b*z[m][z_off+c], c < C: the same on channel slices of tensors with their own
  * channel strides (`out * 0.2 + x` of an RRDB, esrgan/residual.py:128, between two dense-block buffers) */
 int srx_axpby_channels(const float* x, int x_cs, int x_off, const float* z, int z_cs, int z_off, float* y, int y_cs,

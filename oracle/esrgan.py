@@ -115,3 +115,58 @@ class ESRGANStepOracle:
         gen_loss.backward()                                           # :480
         self.gen_optimizer.step()                                     # :481
         return tuple(float(v.detach()) for v in (disc_loss, pixel, content, adversarial, gen_loss))
+
+
+class ESRGANDataParallelOracle:
+    """``world`` data-parallel replicas of ``ESRGANTrainer``'s loop bodies in ONE process: what
+    ``DistributedDataParallel`` does to them (torchsr/esrgan/trainer.py:142-157, same wrapping as SRGAN's): every rank runs
+    the body on its own shard with identical weights, gradients are averaged over the ranks before each optimiser step,
+    the discriminator's BatchNorm is NOT synchronised (per-rank batch statistics and running buffers; the generator has
+    none).  One set of weight leaves is shared, so the mean of the per-rank losses back-propagates the averaged gradient.
+    The relativistic means (:451-452,468) are per rank, as each rank computes them from its own logits."""
+
+    def __init__(self, g_sd: State, d_sd: State, vgg_sd: State, world: int):
+        self.world = world
+        self.g = {k: v.clone() for k, v in g_sd.items()}
+        self.d = {k: v.clone() for k, v in d_sd.items()}
+        self.vgg = {k: v.clone() for k, v in vgg_sd.items()}
+        g_params, d_params = _leaves(self.g), _leaves(self.d)
+        self.psnr_optimizer, self.disc_optimizer, self.gen_optimizer = Adam(g_params), Adam(d_params), Adam(g_params)
+        self.d_ranks = [self.d] + [{k: (v if v.requires_grad else v.clone()) for k, v in self.d.items()}
+                                   for _ in range(1, world)]
+
+    def pretrain_step(self, low_res, high_res):
+        self.psnr_optimizer.zero_grad()
+        losses = [F.l1_loss(generator_forward(self.g, low_res[r]), high_res[r]) for r in range(self.world)]
+        (sum(losses) / self.world).backward()
+        self.psnr_optimizer.step()
+        return [float(v.detach()) for v in losses]
+
+    def gan_step(self, low_res, high_res):
+        bce, W = F.binary_cross_entropy_with_logits, self.world
+        ones = [torch.full((low_res[r].size(0), 1), 1.0) for r in range(W)]
+        zeros = [torch.full((low_res[r].size(0), 1), 0.0) for r in range(W)]
+        self.disc_optimizer.zero_grad()
+        sr = [generator_forward(self.g, low_res[r]) for r in range(W)]
+        disc = []
+        for r in range(W):
+            real_output = discriminator_forward(self.d_ranks[r], high_res[r], True)
+            fake_output = discriminator_forward(self.d_ranks[r], sr[r].detach(), True)
+            d_real = bce(real_output - torch.mean(fake_output), ones[r])
+            d_fake = bce(fake_output - torch.mean(real_output), zeros[r])
+            disc.append((d_real + d_fake) / 2)
+        (sum(disc) / W).backward()
+        self.disc_optimizer.step()
+        self.gen_optimizer.zero_grad()
+        gen, parts = [], []
+        for r in range(W):
+            real_output = discriminator_forward(self.d_ranks[r], high_res[r].detach(), True)
+            fake_output = discriminator_forward(self.d_ranks[r], sr[r], True)
+            pixel = F.l1_loss(sr[r], high_res[r].detach())
+            content = vgg_loss(self.vgg, sr[r], high_res[r].detach())
+            adversarial = bce(fake_output - torch.mean(real_output), ones[r])
+            gen.append(0.01 * pixel + 1 * content + 0.005 * adversarial)
+            parts.append(tuple(float(v.detach()) for v in (disc[r], pixel, content, adversarial, gen[-1])))
+        (sum(gen) / W).backward()
+        self.gen_optimizer.step()
+        return parts

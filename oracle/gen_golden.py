@@ -498,15 +498,51 @@ def gen_pil():
     print('  PIL', Image.__version__, 'BICUBIC x1/4:', np.stack(lows).shape)
 
 
+def gen_checkpoint():
+    """What the reference WRITES as a checkpoint (srgan/trainer.py:233-258, esrgan/trainer.py:233-258): the dict of
+    ``_model_state(epoch, phase)`` of its own trainers, single-process and wrapped the way a distributed run wraps the
+    generator (``module.`` key prefix, srgan/trainer.py:142-149; test.py:44-52 strips it).  The fixture holds the key
+    lists and a digest per entry -- the loaders of this package are tested against a file rebuilt from them."""
+    os.chdir(REF)
+    out = {}
+    t = _reference_srgan_trainer(2)
+    ck = t._model_state(3, 'srgan-gan')
+    out['srgan_top_keys'] = np.array(list(ck.keys()))
+    out['srgan_epoch'], out['srgan_phase'] = np.int64(ck['epoch']), np.array(ck['phase'])
+    out['srgan_state_keys'] = np.array(list(ck['state'].keys()))
+    out['srgan_state_digest'] = np.stack([tensor_digest(v.float()) for v in ck['state'].values()])
+    out['srgan_state_dtypes'] = np.array([str(v.dtype) for v in ck['state'].values()])
+    wrapped = nn.DataParallel(t.generator)  # same key prefix as DistributedDataParallel; needs no process group
+    t.generator = wrapped
+    ckw = t._model_state(7, 'srgan-psnr')
+    out['srgan_wrapped_state_keys'] = np.array(list(ckw['state'].keys()))
+    assert all(k.startswith('module.') for k in ckw['state'])
+    from torchsr.esrgan.trainer import ESRGANTrainer
+    args = Namespace(disable_amp=True, batch_size=2, epochs=8, gan_checkpoint=None, local_rank=0, pretrain_epochs=1,
+                     psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1)
+    te = ESRGANTrainer('cpu', args, [], [], 2, 2, distributed=False)
+    te.generator.load_state_dict(step_state(te.generator.state_dict(), 'esrgan.G'))
+    cke = te._model_state(2, 'esrgan-gan')
+    out['esrgan_top_keys'] = np.array(list(cke.keys()))
+    out['esrgan_state_keys'] = np.array(list(cke['state'].keys()))
+    out['esrgan_state_digest'] = np.stack([tensor_digest(v.float()) for v in cke['state'].values()])
+    np.savez_compressed(os.path.join(OUT, 'checkpoint.npz'), **out)
+    print('  checkpoint: srgan', len(ck['state']), 'entries, esrgan', len(cke['state']), 'entries; top-level keys', list(ck.keys()))
+
+
 if __name__ == '__main__':
     import warnings
     warnings.simplefilter('ignore')
     install_torchvision_stub()
+    if sys.argv[1:] == ['checkpoint']:
+        gen_checkpoint()
+        sys.exit(0)
     print('generator'); gen_generator()
     print('discriminator'); gen_discriminator()
     print('vgg19'); gen_vgg()
     print('train steps'); gen_steps()
     print('esrgan'); gen_esrgan()
     print('pil'); gen_pil()
+    print('checkpoint'); gen_checkpoint()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

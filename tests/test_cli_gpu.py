@@ -73,6 +73,60 @@ def test_1080p_inference_windows_vs_oracle(dev):
         assert err <= 1e-4 * max(ref.abs().max().item(), 1e-3), (y0, x0, err)
 
 
+def _bn_folded_state(sd, eps=1e-5):
+    """The same eval-mode generator with every BatchNorm folded into the conv before it -- ``w * g / sqrt(var + eps)``, the
+    shift moved to the BatchNorm's bias, identity statistics left behind -- which is the operand the product rounds to
+    bf16 (``functional.FoldedConv``); in exact arithmetic the two state dicts describe the same function."""
+    out = {k: v.clone() for k, v in sd.items()}
+    pairs = [(f'blocks.{i}.conv{j}', f'blocks.{i}.bn{j}') for i in range(16) for j in (1, 2)] + [('conv2.0', 'conv2.1')]
+    for conv, bn in pairs:
+        scale = sd[bn + '.weight'] * torch.rsqrt(sd[bn + '.running_var'] + eps)
+        out[conv + '.weight'] = sd[conv + '.weight'] * scale.view(-1, 1, 1, 1)
+        out[bn + '.bias'] = sd[bn + '.bias'] - sd[bn + '.running_mean'] * scale
+        out[bn + '.weight'] = torch.ones_like(scale)
+        out[bn + '.running_mean'] = torch.zeros_like(scale)
+        out[bn + '.running_var'] = torch.full_like(scale, 1.0 - eps)
+    return out
+
+
+def test_1080p_inference_bf16_products_vs_oracle(dev):
+    """BASELINE config 5 with ``precision='bf16'`` ("fp32 and bf16"): the full 1080p frame,
+    windows against (a) the fp32 oracle -- the reference-anchored statement: within 2e-2 of the exact result, relative to
+    the window's largest value -- and (b) the bf16-products oracle on the BatchNorm-folded weights, i.e. the arithmetic
+    the product states it performs, at 2e-3.  The fp32 call afterwards must be exact again (precision is restored)."""
+    from oracle import srgan as O
+    from oracle.weights import closed_form_state
+    from torchsr_amd.srgan.generator import Generator
+    from torchsr_amd.test import upscale
+    gen = Generator().to(dev)
+    sd = closed_form_state(gen.state_dict())
+    gen.load_state_dict(sd)
+    folded = _bn_folded_state(sd)
+    g = torch.Generator().manual_seed(12)
+    frame = torch.rand(1, 3, 1080, 1920, generator=g)
+    out = upscale(gen, frame.to(dev), precision='bf16')
+    assert out.shape == (1, 3, 4320, 7680) and torch.isfinite(out).all()
+    win, ctx = 40, 48
+    for y0, x0 in ((0, 0), (1080 - win, 1920 - win), (530, 850)):
+        ya, xa, yb, xb = max(0, y0 - ctx), max(0, x0 - ctx), min(1080, y0 + win + ctx), min(1920, x0 + win + ctx)
+        cut = frame[:, :, ya:yb, xa:xb].contiguous()
+        crop = lambda t: t[:, :, 4 * (y0 - ya):4 * (y0 - ya + win), 4 * (x0 - xa):4 * (x0 - xa + win)]  # noqa: E731
+        with torch.no_grad():
+            exact = crop(O.generator_forward(sd, cut, training=False))
+            same = crop(O.generator_forward(folded, cut, training=False))
+            with O.bf16_products():
+                ref = crop(O.generator_forward(folded, cut, training=False))
+        assert (exact - same).abs().max().item() <= 2e-5 * exact.abs().max().item()  # the folding itself changes nothing
+        got = out[:, :, 4 * y0:4 * (y0 + win), 4 * x0:4 * (x0 + win)].cpu()
+        top = max(exact.abs().max().item(), 1e-3)
+        assert (got - exact).abs().max().item() <= 2e-2 * top, (y0, x0, (got - exact).abs().max().item() / top)
+        assert (got - ref).abs().max().item() <= 2e-3 * top, (y0, x0, (got - ref).abs().max().item() / top)
+    again = upscale(gen, frame[:, :, :200, :300].to(dev))
+    with torch.no_grad():
+        want = O.generator_forward(sd, frame[:, :, :200, :300].contiguous(), training=False)
+    assert (again.cpu() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
 def test_device_data_pipeline_cli(dev, tmp_path, monkeypatch):
     """--device-data: images decoded once, crop / flips / bicubic x1/4 on the GPU."""
     from PIL import Image

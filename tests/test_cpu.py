@@ -317,3 +317,163 @@ def test_descriptor_validation_without_a_gpu():
     assert lib.srx_conv2d_packed_fwd_floats(C.byref(d)) == 64 * 576
     assert lib.srx_conv2d_packed_bwd_floats(C.byref(d)) == 64 * 576
     assert lib.srx_conv2d_stat_rows(C.byref(d)) == 256
+
+
+def test_abi_refuses_out_of_range_addends_slices_and_scales_without_a_gpu():
+    """The three entry points added for the RRDB trunk (round 2) address tensors through caller-supplied strides, channel
+    ranges and a host array; every combination that would read or write outside a row is refused with a status code
+    BEFORE anything is launched ('the esr17 fault') -- so the checks run here, with fake pointers, on CPU."""
+    import ctypes as C
+    from torchsr_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip('fake pointers: argument validation is exercised where a missed check cannot reach a device')
+    lib = _lib.lib()
+    fake = 0x10000  # never dereferenced: the calls below must fail in argument validation
+
+    def err():
+        buf = C.create_string_buffer(256)
+        lib.srx_last_error(buf, 256)
+        return buf.value.decode()
+
+    # conv5 of a dense block: 192 input channels (row stride 192), dy dense 64 channels
+    d = _lib.Conv2dDesc(2, 8, 8, 192, 192, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
+    e = _lib.DgradEpilogue()
+    e.addend, e.addend_ld, e.addend_channels, e.addend_scale, e.out_scale = fake, 64, 0, 1.0, 0.2  # 192 channels from 64-float rows
+    rc = lib.srx_conv2d_bwd_data_ex(C.byref(d), fake, fake, fake + 4096, C.byref(e), None, 0, None)
+    assert rc != 0 and 'row stride' in err()
+    e.addend_channels = 128                                                                       # still wider than the row
+    assert lib.srx_conv2d_bwd_data_ex(C.byref(d), fake, fake, fake + 4096, C.byref(e), None, 0, None) != 0 and 'row stride' in err()
+    e.addend_ld, e.addend_channels = 62, 60                                                       # not whole quads
+    assert lib.srx_conv2d_bwd_data_ex(C.byref(d), fake, fake, fake + 4096, C.byref(e), None, 0, None) != 0 and 'quads' in err()
+    e = _lib.DgradEpilogue()
+    e.addend, e.addend_scale = fake + 4096, 0.5                                                   # the addend IS the output
+    assert lib.srx_conv2d_bwd_data_ex(C.byref(d), fake, fake, fake + 4096, C.byref(e), None, 0, None) != 0 and 'of its own' in err()
+    e = _lib.DgradEpilogue()
+    e.accumulate, e.out_scale = 1, 0.2                                                            # scaled output + accumulate
+    assert lib.srx_conv2d_bwd_data_ex(C.byref(d), fake, fake, fake + 4096, C.byref(e), None, 0, None) != 0
+    e = _lib.DgradEpilogue()
+    e.act_out, e.act_slope, e.c_lo, e.c_hi = fake, 0.2, 192, 224                                  # mask beyond the row
+    assert lib.srx_conv2d_bwd_data_ex(C.byref(d), fake, fake, fake + 4096, C.byref(e), None, 0, None) != 0 and 'masked' in err()
+    e.c_lo, e.c_hi = 160, 150                                                                     # empty / unaligned range
+    assert lib.srx_conv2d_bwd_data_ex(C.byref(d), fake, fake, fake + 4096, C.byref(e), None, 0, None) != 0 and 'masked' in err()
+
+    # channel slices of srx_axpby_channels / srx_copy_channels
+    assert lib.srx_axpby_channels(fake, 192, 160, fake, 192, 0, fake, 64, 0, 64, 128, 0.2, 1.0, None) != 0 and 'out of range' in err()
+    assert lib.srx_axpby_channels(fake, 192, 0, fake, 192, 0, fake, 64, 32, 64, 128, 0.2, 1.0, None) != 0 and 'out of range' in err()
+    assert lib.srx_axpby_channels(fake, 192, -4, fake, 192, 0, fake, 64, 0, 64, 128, 0.2, 1.0, None) != 0 and 'out of range' in err()
+    assert lib.srx_axpby_channels(fake, 192, 2, fake, 192, 0, fake, 64, 0, 64, 128, 0.2, 1.0, None) != 0 and 'multiples of 4' in err()
+    assert lib.srx_copy_channels(fake, 64, 0, fake, 192, 160, 64, 128, 0, None) != 0 and 'out of range' in err()
+
+    # grouped / scaled / paired weight gradients
+    arr = lambda *v: (C.c_void_p * len(v))(*v)  # noqa: E731
+    nws = lib.srx_conv2d_bwd_weight_multi_ws_floats(C.byref(d), 2)
+    assert nws > 0
+    bad = (C.c_float * 2)(1.0, float('nan'))
+    rc = lib.srx_conv2d_bwd_weight_multi_scaled(C.byref(d), 2, 1, arr(fake, fake), arr(fake, fake), arr(fake, fake), 1, None, bad,
+                                                fake, nws, None)
+    assert rc != 0 and 'not finite' in err()
+    ok = (C.c_float * 2)(1.0, 0.2)
+    rc = lib.srx_conv2d_bwd_weight_multi_scaled(C.byref(d), 2, 1, arr(fake, fake), arr(fake, fake), arr(fake, fake), 1, None, ok,
+                                                fake, 4, None)
+    assert rc != 0 and 'workspace' in err()                                                      # short workspace
+    rc = lib.srx_conv2d_bwd_weight_multi_scaled(C.byref(d), 3, 2, arr(fake, fake, fake), arr(fake, fake, fake), arr(fake, fake), 1,
+                                                None, ok, fake, 1 << 40, None)
+    assert rc != 0 and 'whole number of outputs' in err()
+    rc = lib.srx_conv2d_bwd_weight_multi_scaled(C.byref(d), 2, 1, arr(fake, None), arr(fake, fake), arr(fake, fake), 1, None, ok,
+                                                fake, nws, None)
+    assert rc != 0 and 'null tensor' in err()
+    dp = _lib.Conv2dDesc(2, 8, 8, 96, 192, 64, 192, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)                  # conv1 + conv2 of a dense block
+    rc = lib.srx_conv2d_bwd_weight_multi_pair(C.byref(dp), 1, arr(fake), arr(fake), arr(fake), arr(fake), 128, 1, None, None,
+                                              fake, 1 << 40, None)
+    assert rc != 0 and 'cin_lo' in err()                                                         # first conv wider than the second
+    rc = lib.srx_conv2d_bwd_weight_multi_pair(C.byref(dp), 1, arr(fake), arr(fake), arr(fake), arr(fake), 62, 1, None, None,
+                                              fake, 1 << 40, None)
+    assert rc != 0 and 'quads' in err()
+    rc = lib.srx_conv2d_bwd_weight_multi_pair(C.byref(dp), 1, arr(fake), arr(fake), arr(fake), arr(fake), 64, 1, arr(fake), None,
+                                              fake, 1 << 40, None)
+    assert rc != 0 and 'both convs or neither' in err()
+
+
+def test_vgg_loss_loads_a_torchvision_shaped_state_dict(tmp_path):
+    """The pretrained branch of ``VGGLoss.__init__`` (torchsr/srgan/loss.py:30: ``vgg19(pretrained=True)``): the file
+    torchvision downloads is a full VGG19 state dict -- ``features.N.{weight,bias}`` for the 16 convs plus the three
+    ``classifier`` layers -- of which ``features[:36]`` is kept.  The real values are not available offline, so the file is
+    written here with the closed-form fill (and token-sized classifier tensors: they are dropped unread)."""
+    from torchsr_amd.srgan.loss import VGGLoss, make_vgg19_features
+    own = make_vgg19_features(36).state_dict()
+    full = {f'features.{k}': v for k, v in closed_form_state(own, prefix='features.').items()}
+    for i in (0, 3, 6):
+        full[f'classifier.{i}.weight'], full[f'classifier.{i}.bias'] = torch.ones(4, 4), torch.ones(4)
+    path = tmp_path / 'vgg19-dcbb9e9d.pth'
+    torch.save(full, path)
+    v = VGGLoss(weights=str(path))
+    assert v.pretrained and not v.features.training and not any(p.requires_grad for p in v.parameters())
+    got = v.features.state_dict()
+    assert list(got) == list(own)
+    for k, t in got.items():
+        assert torch.equal(t, full['features.' + k]), k
+    # found through the environment variable too; a file without the feature tensors is an error, not a silent random init
+    import os
+    os.environ['TORCHSR_VGG19_WEIGHTS'] = str(path)
+    try:
+        assert VGGLoss().pretrained
+    finally:
+        del os.environ['TORCHSR_VGG19_WEIGHTS']
+    torch.save({k: v for k, v in full.items() if not k.startswith('features.34')}, tmp_path / 'short.pth')
+    with pytest.raises(RuntimeError, match='Missing key'):
+        VGGLoss(weights=str(tmp_path / 'short.pth'))
+
+
+@pytest.mark.parametrize('model', ['srgan', 'esrgan'])
+def test_loaders_read_what_the_reference_trainer_writes(tmp_path, model):
+    """tests/golden/checkpoint.npz: the keys and per-entry digests of ``_model_state`` of the reference's own trainers
+    (srgan/trainer.py:233-258), plain and with the ``module.`` prefix a wrapped generator gives.  A file rebuilt from
+    them must load through the trainer's ``_load_checkpoint`` and through ``test.load_generator_state`` into this
+    package's generator, entry for entry."""
+    import importlib
+    from torchsr_amd.srgan.trainer import SRGANTrainer
+    from torchsr_amd.test import load_generator_state
+    gold = np.load(os.path.join(GOLDEN, 'checkpoint.npz'))
+    assert list(gold[f'{model}_top_keys']) == ['epoch', 'phase', 'state']
+    gen = importlib.import_module(f'torchsr_amd.{model}.generator').Generator()
+    keys = [str(k) for k in gold[f'{model}_state_keys']]
+    assert keys == list(gen.state_dict().keys())  # the checkpoint ABI: same names, same order
+    values = step_state(gen.state_dict(), f'{model}.G')
+    for k, dg in zip(keys, gold[f'{model}_state_digest']):
+        assert np.allclose(tensor_digest(values[k].float()), dg, rtol=1e-12, atol=1e-12), k  # what the reference held
+    prefixes = ['', 'module.'] if model == 'srgan' else ['']
+    if model == 'srgan':
+        assert [str(k) for k in gold['srgan_wrapped_state_keys']] == ['module.' + k for k in keys]
+    for prefix in prefixes:
+        path = str(tmp_path / f'{model}-gan-best{len(prefix)}.pth')
+        torch.save({'epoch': 3, 'phase': f'{model}-gan', 'state': {prefix + k: values[k] for k in keys}}, path)
+        ck = SRGANTrainer._load_checkpoint(None, path)
+        assert ck['epoch'] == 3 and ck['phase'] == f'{model}-gan' and list(ck['state']) == keys
+        for state in (ck['state'], load_generator_state(path)):
+            fresh = importlib.import_module(f'torchsr_amd.{model}.generator').Generator()
+            fresh.load_state_dict(state, strict=True)
+            for k, v in fresh.state_dict().items():
+                assert torch.equal(v, values[k]), (prefix, k)
+    # a bare state dict (no wrapper) is accepted as well
+    bare = str(tmp_path / 'bare.pth')
+    torch.save({k: values[k] for k in keys}, bare)
+    assert list(load_generator_state(bare)) == keys and list(SRGANTrainer._load_checkpoint(None, bare)['state']) == keys
+
+
+def test_device_loader_shards_have_equal_length_on_every_rank():
+    """Uneven shards would leave one rank in a collective alone: every rank must see the same number of
+    train batches and a non-empty test shard, like the reference's DistributedSampler (torchsr/dataset.py:279,343-360)."""
+    from torchsr_amd.dataset import DeviceLoader
+    images = [torch.zeros(8, 8, 3, dtype=torch.uint8) for _ in range(127)]
+    for world, batch, n in ((8, 16, 127), (8, 4, 33), (3, 2, 7), (2, 5, 11), (8, 16, 1)):
+        for test in (False, True):
+            loaders = [DeviceLoader(images[:n], 'cpu', batch, 8, 4, test, 0, 1, rank, world) for rank in range(world)]
+            lens = [len(ld) for ld in loaders]
+            assert len(set(lens)) == 1, (world, batch, n, test, lens)
+            shards = [ld._shard(list(ld.order)) for ld in loaders]
+            assert len({len(s) for s in shards}) == 1 and all(len(s) >= 1 for s in shards)
+            assert set(i for s in shards for i in s) == set(range(n))  # every sample is somewhere
+            if test:
+                assert lens[0] >= 1
+            # what __iter__ slices must exist on every rank
+            assert all(lens[0] * batch - len(s) < batch for s in shards) if test else all(lens[0] * batch <= len(s) for s in shards)

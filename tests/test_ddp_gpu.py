@@ -131,3 +131,133 @@ def test_two_rank_trainer_step_matches_data_parallel_oracle(dev):
         assert rep['loss_gap'] < 1e-4 and rep['pre_gap'] < 1e-4 and rep['param_gap'] < 1e-3, (rank, rep)
         assert {'gan.disc.head', 'gan.disc.body', 'gan.content', 'gan.gen.head', 'gan.gen.body', 'gan.gopt'} <= \
             set(rep['graphs']), rep['graphs']
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ESRGAN: gen_tail_bucket = 'upsample1.weight', the relativistic losses, D(real) + D(fake) as one paired call in the
+# discriminator update ('d.head' hit ONCE) and two separate calls in the generator update
+ESR_RRDBS = 3  # a three-RRDB generator: same code paths as the 23 of BASELINE config 4, a CPU oracle that takes seconds
+
+
+def _esr_shard(rank):
+    from oracle.weights import seeded_input
+    return seeded_input((2, 3, 32, 32), 270 + rank), seeded_input((2, 3, 128, 128), 280 + rank)
+
+
+def _esr_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import functools
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import esrgan as OE
+        from oracle.weights import closed_form_state, step_state
+        from torchsr_amd.esrgan.generator import Generator
+        from torchsr_amd.esrgan.trainer import ESRGANTrainer
+        dev = torch.device('cuda', 0)
+        torch.cuda.set_device(dev)
+
+        class SmallESRGANTrainer(ESRGANTrainer):
+            generator_cls = functools.partial(Generator, ESR_RRDBS)
+
+        def make(use_graphs):
+            args = Namespace(disable_amp=True, batch_size=2, epochs=8, gan_checkpoint=None, local_rank=0,
+                             pretrain_epochs=1, psnr_checkpoint=None, skip_image_save=True, world_size=world, rank=rank,
+                             use_graphs=use_graphs, vgg_weights='random')
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                t = SmallESRGANTrainer(dev, args, [], [], 2, 2, distributed=True)
+            t.generator.load_state_dict(step_state(t.generator.state_dict(), 'esrgan.G'))
+            t.discriminator.load_state_dict(step_state(t.discriminator.state_dict(), 'esrgan.D'))
+            t.vgg_loss.features.load_state_dict(closed_form_state(t.vgg_loss.features.state_dict(), prefix='features.'))
+            t.generator.train()
+            t.discriminator.train()
+            return t
+
+        te, tg = make(False), make(True)
+        tail = 3 * (64 * 64 * 9 + 64) + 3 * 64 * 9 + 3  # upsample1/2, conv3.0, conv4 (+ alignment padding of the flat buffer)
+        report = {'buckets': (len(te.gen_sync), len(te.disc_sync)), 'tail_ok': tail <= te.gen_sync.slices[1].numel() < tail + 4,
+                  'head_ok': te.disc_sync.slices[1].numel() >= 100 * 8192, 'world': te.disc_sync.world_size, 'loss_gap': 0.0}
+        hits = []
+        cut = te._cuts.__class__.__call__
+
+        def counting(self, name, t):  # how often each cut is armed AND hit per step (eager trainer only)
+            r = cut(self, name, t)
+            if r is not t and self is te._cuts:
+                hits.append(name)
+            return r
+        te._cuts.__class__.__call__ = counting
+        lr, hr = (t.to(dev) for t in _esr_shard(rank))
+        for step in range(STEPS):
+            hits.clear()
+            le, lg = te.gan_step(lr, hr), tg.gan_step(lr, hr)
+            for k in le:
+                a, b = le[k].item(), lg[k].item()
+                report['loss_gap'] = max(report['loss_gap'], abs(a - b) / max(abs(a), 1e-3))
+            if step == 0:
+                report['hits'] = sorted(hits)
+                first = {'G': {k: v.detach().cpu().clone() for k, v in te.generator.state_dict().items()},
+                         'D': {k: v.detach().cpu().clone() for k, v in te.discriminator.state_dict().items()},
+                         'losses': [le[k].item() for k in ('gan/disc-loss', 'gan/pixel-loss', 'gan/content-loss',
+                                                            'gan/adversarial-loss', 'gan/train-loss')]}
+        te._cuts.__class__.__call__ = cut
+        report['graphs'] = sorted(tg._graphs)
+        report['pending'] = (dict(te._cuts.pairs), dict(tg._cuts.pairs))
+        gap = 0.0
+        for ma, mb in ((te.generator, tg.generator), (te.discriminator, tg.discriminator)):
+            for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
+                if a.is_floating_point():
+                    gap = max(gap, ((a - b).abs().max() / a.abs().max().clamp_min(1e-6)).item())
+        report['param_gap'] = gap
+
+        vgg_sd = {k: v.detach().cpu().clone() for k, v in te.vgg_loss.features.state_dict().items()}
+        orc = OE.ESRGANDataParallelOracle(step_state(te.generator.state_dict(), 'esrgan.G'),
+                                          step_state(te.discriminator.state_dict(), 'esrgan.D'), vgg_sd, world)
+        shards = [_esr_shard(r) for r in range(world)]
+        want = orc.gan_step([s[0] for s in shards], [s[1] for s in shards])[rank]
+        report['loss_err'] = max(abs(g - w) / max(abs(w), 1e-3) for g, w in zip(first['losses'], want))
+        bad = []
+        for name, got, ref in (('G', first['G'], orc.g), ('D', first['D'], orc.d_ranks[rank])):
+            for k, v in got.items():
+                r = ref[k].detach()
+                if not v.is_floating_point():
+                    if int(v) != int(r):
+                        bad.append((name, k, 'counter'))
+                    continue
+                if (name, k) == ('D', 'classifier.2.bias'):
+                    continue  # exact gradient 0 (tests/test_esrgan_gpu.py::assert_digests)
+                diff = (v - r).abs()
+                if 'running_' in k:
+                    if (diff.max() / r.abs().max().clamp_min(1e-6)).item() > 1e-3:
+                        bad.append((name, k, 'running'))
+                else:
+                    n_bad = int((diff > 2e-6).sum())
+                    if n_bad > max(2, int(5e-3 * diff.numel())) or diff.max().item() > 2.1e-4:
+                        bad.append((name, k, n_bad, diff.max().item()))
+        report['bad'] = bad
+        out[rank] = report
+        torch.cuda.synchronize()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_esrgan_step_matches_data_parallel_oracle(dev):
+    world, port = 2, _free_port()
+    mgr = mp.get_context('spawn').Manager()
+    out = mgr.dict()
+    mp.spawn(_esr_worker, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    for rank in range(world):
+        rep = out[rank]
+        assert rep['buckets'] == (2, 2) and rep['tail_ok'] and rep['head_ok'] and rep['world'] == world, (rank, rep)
+        # discriminator update: real + fake as one paired call -> 'd.head' once (or twice when the pair falls back to two
+        # calls); generator: 'g.tail' once; the discriminator passes of the generator update are not cut
+        assert rep['hits'] in (['d.head', 'g.tail'], ['d.head', 'd.head', 'g.tail']), (rank, rep['hits'])
+        assert rep['pending'] == ({}, {}), (rank, rep['pending'])
+        assert rep['bad'] == [], (rank, rep['bad'][:5])
+        assert rep['loss_err'] < 1e-3, (rank, rep)
+        assert rep['loss_gap'] < 1e-4 and rep['param_gap'] < 1e-3, (rank, rep)
+        assert {'gan.disc.head', 'gan.disc.body', 'gan.content', 'gan.gen.head', 'gan.gen.body', 'gan.gopt'} <= \
+            set(rep['graphs']), rep['graphs']

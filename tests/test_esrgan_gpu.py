@@ -91,7 +91,8 @@ def assert_digests(keys, sd, digests, what):
         # gradient sits at the fp32 noise floor move in a direction that differs between any two fp32
         # implementations (the elementwise test below allows 0.2 % of a tensor to do so): each costs 2e-4 of a sum
         slack = 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6 + max(2, 2e-3 * sd[str(k)].numel()) * 2.1e-4
-        assert abs(d[0] - dg[0]) <= slack and abs(d[1] - dg[1]) <= slack, (what, k, d[:2], dg[:2])
+        # [0] sum, [1] abs-sum, [2] cos(index)-weighted sum: the order-sensitive entry (|weight| <= 1: same slack)
+        assert all(abs(d[i] - dg[i]) <= slack for i in range(3)), (what, k, d[:3], dg[:3])
 
 
 def test_esrgan_gan_steps_vs_reference_trainer(dev):
@@ -117,6 +118,30 @@ def test_esrgan_gan_steps_vs_reference_trainer(dev):
         if step == 0:
             assert_digests(gold['gs_keys'], t.generator.state_dict(), gold['gan_g_digest'][step], f'G step {step}')
             assert_digests(gold['ds_keys'], t.discriminator.state_dict(), gold['gan_d_digest'][step], f'D step {step}')
+
+
+def assert_elementwise(got_sd, ref_sd, name, skip=()):
+    """Every parameter within 2e-6 absolute of ``ref_sd`` after ONE Adam step (updates are ~1e-4: pins the update
+    direction of every element whose gradient is above the noise floor; 0.5 % of a tensor, at least 2 elements, may sit
+    at that floor -- tools/experiments/esrgan_noise_floor.py).  Returns the worst tensor for the record."""
+    worst = ('', 0.0)
+    for k, v in got_sd.items():
+        r = ref_sd[k].detach()
+        if not v.is_floating_point():
+            assert int(v) == int(r), (name, k)
+            continue
+        if k in skip:
+            continue
+        diff = (v.detach().cpu() - r.cpu()).abs()
+        if 'running_' in k:
+            assert (diff.max() / r.abs().max().clamp_min(1e-6)).item() < 1e-3, (name, k)
+        else:
+            n_bad = int((diff > 2e-6).sum())
+            assert n_bad <= max(2, int(5e-3 * diff.numel())), (name, k, n_bad, diff.max().item())
+            assert diff.max().item() <= 2.1e-4, (name, k, diff.max().item())
+            if n_bad / diff.numel() > worst[1]:
+                worst = (k, n_bad / diff.numel())
+    return worst
 
 
 def test_esrgan_first_step_matches_oracle_elementwise(dev):
@@ -163,6 +188,14 @@ def test_esrgan_config4_geometry_step_vs_reference_trainer(dev):
     assert abs(got[4] - float(gold['b4_gan_ref_gen_loss'])) <= TOL * float(gold['b4_gan_ref_gen_loss'])
     assert_digests(gold['gs_keys'], t.generator.state_dict(), gold['b4_gan_g_digest'], 'G b4')
     assert_digests(gold['ds_keys'], t.discriminator.state_dict(), gold['b4_gan_d_digest'], 'D b4')
+    # ... and every element against the CPU oracle at this size (the digests above are sums over up to 8e5 elements)
+    from oracle import esrgan as OE
+    vgg_sd = {k: v.detach().cpu().clone() for k, v in t.vgg_loss.features.state_dict().items()}
+    orc = OE.ESRGANStepOracle(step_state(t.generator.state_dict(), 'esrgan.G'), step_state(t.discriminator.state_dict(), 'esrgan.D'),
+                              vgg_sd)
+    orc.gan_step(lr.cpu(), hr.cpu())
+    assert_elementwise(t.generator.state_dict(), orc.g, 'G b4')
+    assert_elementwise(t.discriminator.state_dict(), orc.d, 'D b4', skip=('classifier.2.bias',))
 
 
 def test_esrgan_config4_full_batch_step_vs_reference_trainer(dev):
@@ -183,6 +216,15 @@ def test_esrgan_config4_full_batch_step_vs_reference_trainer(dev):
     assert_digests(gold['gs_keys'], t.generator.state_dict(), gold['b4_gan_g_digest'], 'G b16')
     keep = [i for i, k in enumerate(gold['ds_keys']) if 'running_var' not in str(k)]
     assert_digests(gold['ds_keys'][keep], t.discriminator.state_dict(), gold['b4_gan_d_digest'][keep], 'D b16')
+    # element by element: the batch-16 step of the replicated crops against the batch-4 step of the crops themselves
+    # (which test_esrgan_config4_geometry_step_vs_reference_trainer ties to the oracle elementwise)
+    t4 = make_trainer(dev, batch=4)
+    t4.gan_step(lr[:4].contiguous(), hr[:4].contiguous())
+    assert_elementwise(t.generator.state_dict(), t4.generator.state_dict(), 'G b16 vs b4')
+    ref_d = {k: v for k, v in t4.discriminator.state_dict().items()}
+    got_d = {k: v for k, v in t.discriminator.state_dict().items() if 'running_var' not in k}
+    assert_elementwise(got_d, ref_d, 'D b16 vs b4', skip=('classifier.2.bias',))
+    del t4
     # the same step in the precision config 4 is quoted at (autocast in both phases): within bf16 rounding of it
     tb = make_trainer(dev, batch=16, disable_amp=False)
     lb = tb.gan_step(lr, hr)

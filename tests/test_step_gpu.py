@@ -48,7 +48,8 @@ def assert_digests(keys, sd, digests, what):
         # gradient sits at the fp32 noise floor move in a direction that differs between any two fp32
         # implementations (assert_elementwise allows 0.2 % of a tensor to do so): each costs 2e-4 of a sum
         slack = 2e-4 * max(abs(dg[1]), 1e-6) + 1e-6 + max(2, 2e-3 * sd[k].numel()) * 2.1e-4
-        assert abs(d[0] - dg[0]) <= slack and abs(d[1] - dg[1]) <= slack, (what, k, d[:2], dg[:2])
+        # [0] sum, [1] abs-sum, [2] cos(index)-weighted sum: the order-sensitive entry (|weight| <= 1: same slack)
+        assert all(abs(d[i] - dg[i]) <= slack for i in range(3)), (what, k, d[:3], dg[:3])
 
 
 def assert_elementwise(mod, ref, name):

@@ -102,6 +102,7 @@ _SIGS = {
     'srx_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _I, _L, _P, _P]),
     'srx_lrelu_fwd': (_I, [_P, _P, _L, _F, _P]),
     'srx_axpby': (_I, [_P, _P, _P, _L, _F, _F, _P]),
+    'srx_ring_push': (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _P]),
     'srx_axpby_channels': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _L, _F, _F, _P]),
     'srx_copy_channels': (_I, [_P, _I, _I, _P, _I, _I, _I, _L, _I, _P]),
     'srx_upsample_nearest2x_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -532,3 +532,29 @@ extern "C" int srx_maxpool2x2_relu_bwd(const float* dy, const float* x, float* d
   SRX_CHECK_LAUNCH("maxpool_bwd_kernel");
   return SRX_OK;
 }
+
+// ------------------------------------------------------------------ loss ring
+// One record per train step: up to four device scalars appended to a ring, the slot taken from a device-side
+// counter, so that the launch is identical every step and can sit inside a replayed hipGraph.
+namespace {
+__global__ void ring_push_kernel(const float* a, const float* b, const float* c, const float* d, int n, float* ring,
+                                 int* counter, int cap) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int i = *counter;
+  float* slot = ring + (size_t)(i % cap) * 4;
+  slot[0] = *a;
+  if (n > 1) slot[1] = *b;
+  if (n > 2) slot[2] = *c;
+  if (n > 3) slot[3] = *d;
+  *counter = i + 1;
+}
+}  // namespace
+
+extern "C" int srx_ring_push(const float* a, const float* b, const float* c, const float* d, int n, float* ring,
+                             int* counter, int cap, void* stream) {
+  SRX_REQUIRE(n >= 1 && n <= 4 && a && (n < 2 || b) && (n < 3 || c) && (n < 4 || d) && ring && counter && cap > 0,
+              "ring_push: bad argument");
+  hipLaunchKernelGGL(ring_push_kernel, dim3(1), dim3(64), 0, srx_stream(stream), a, b, c, d, n, ring, counter, cap);
+  SRX_CHECK_LAUNCH("ring_push_kernel");
+  return SRX_OK;
+}

@@ -1729,6 +1729,11 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
     SRX_REQUIRE(addend && !accumulate, "conv2d_bwd_data_ex: addend stride / channels / scales without an addend");
     SRX_REQUIRE(addend_ld >= 4 && addend_ld % 4 == 0 && (addend_channels % 4 == 0 || addend_channels >= d->Cin),
                 "conv2d_bwd_data_ex: the addend's stride and channel count must be made of whole quads");
+    // the epilogue reads min(addend_channels, Cin rounded up to a quad) floats of every addend row: more than the
+    // row stride would walk into the next pixel and, on the last rows, past the end of the addend tensor
+    SRX_REQUIRE(addend_channels > 0 && (addend_channels < d->Cin ? addend_channels : (int)srx_roundup(d->Cin, 4)) <= addend_ld,
+                "conv2d_bwd_data_ex: the addend has %d channels per row but a row stride of %d floats",
+                addend_channels < d->Cin ? addend_channels : (int)srx_roundup(d->Cin, 4), addend_ld);
   }
   if (d->up == 2) {
     if (accumulate || act_out || addend)
@@ -1747,8 +1752,8 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
     SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: accumulate is implemented for stride-1 layers on the generic kernel only");
   if (act_out && (d->stride != 1 || srx_thin_dgrad_applicable(d)))
     SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data_act: stride-1 layers on the generic kernel only");
-  if (act_out) SRX_REQUIRE(c_lo >= 0 && c_lo < c_hi && c_lo % 4 == 0 && (c_hi % 4 == 0 || c_hi >= d->Cin),
-                           "conv2d_bwd_data_act: the masked channel range must be made of whole quads");
+  if (act_out) SRX_REQUIRE(c_lo >= 0 && c_lo < c_hi && c_lo % 4 == 0 && (c_hi % 4 == 0 || c_hi >= d->Cin) && c_lo < d->Cin_s,
+                           "conv2d_bwd_data_act: the masked channel range must be made of whole quads inside the row");
   hipStream_t st = srx_stream(stream);
   if (srx_thin_dgrad_applicable(d)) return srx_thin_fwd(d, dy, wpk_bwd, nullptr, dx, d->Cin, st);
   const Geo g = fwd_geo(d);
@@ -1871,6 +1876,7 @@ extern "C" int srx_conv2d_bwd_weight_multi_pair(const srx_conv2d_t* d, int nprob
               "conv2d_bwd_weight_multi_pair: two convs of Cout / 2 output channels each (a multiple of 4), no PixelShuffle, "
               "no fused upsample, 0 < cin_lo <= Cin");
   SRX_REQUIRE((dbs_lo == nullptr) == (dbs_hi == nullptr), "conv2d_bwd_weight_multi_pair: bias gradients for both convs or neither");
+  SRX_REQUIRE(cin_lo % 4 == 0 || cin_lo == d->Cin, "conv2d_bwd_weight_multi_pair: cin_lo must be a whole number of quads");
   return wgrad_multi_impl(d, nprob, 1, xs, dys, dws_lo, accumulate, dbs_lo, nullptr, dws_hi, dbs_hi, cin_lo, ws, ws_floats, stream);
 }
 
@@ -1966,6 +1972,8 @@ static int wgrad_multi_impl(const srx_conv2d_t* d, int nprob, int per_out, const
   for (int i = 0; i < nprob; ++i) { mp.x[i] = xs[i]; mp.dy[i] = dys[i]; }
   for (int o = 0; o < nout; ++o) {
     outs.dw[o] = dws[o]; outs.db[o] = dbs ? dbs[o] : nullptr; outs.scale[o] = out_scales ? out_scales[o] : 1.f;
+    SRX_REQUIRE(outs.scale[o] == outs.scale[o] && outs.scale[o] - outs.scale[o] == 0.f,
+                "conv2d_bwd_weight_multi_scaled: output scale %d is not finite (out_scales is a HOST array of nprob / per_out floats)", o);
     outs.dw_hi[o] = dws_hi ? dws_hi[o] : nullptr; outs.db_hi[o] = dbs_hi ? dbs_hi[o] : nullptr;
   }
   outs.rows_lo = dws_hi ? d->Cout / 2 : 0;

@@ -107,8 +107,17 @@ class DeviceLoader:
                                             mode='bicubic', align_corners=False)
         return f[0].permute(1, 2, 0).clamp(0, 255).round().to(torch.uint8).contiguous()
 
+    def _shard(self, order):
+        """This rank's samples: what ``DistributedSampler`` hands out (dataset.py:279,343-360) -- the order padded to a
+        multiple of the world size by wrapping around, then every world-th sample -- so that every rank holds the
+        same number of samples (none is empty, none runs an extra batch and waits in a collective alone)."""
+        if self.world > 1 and len(order) % self.world:
+            pad = self.world - len(order) % self.world
+            order = order + (order * (-(-pad // len(order))))[:pad]
+        return order[self.rank::self.world]
+
     def __len__(self) -> int:
-        n = len(self.order[self.rank::self.world])
+        n = -(-len(self.order) // self.world)  # the same on every rank
         # the reference's train loader drops nothing either (dataset.py:280-293), but a replayed hipGraph needs
         # one batch shape, so the last partial TRAIN batch is dropped; the eager test pass keeps it (:345-360)
         return -(-n // self.batch) if self.test else n // self.batch
@@ -118,7 +127,7 @@ class DeviceLoader:
         if not self.test:
             random.Random(self.epoch * 104729 + 17).shuffle(order)  # same permutation on every rank
         self.epoch += 1
-        order = order[self.rank::self.world]
+        order = self._shard(order)
         call, dev = self._lib.call, self.device
         for b in range(len(self)):
             idx = order[b * self.batch:(b + 1) * self.batch]

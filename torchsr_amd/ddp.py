@@ -78,10 +78,13 @@ class GradBuckets:
     """
 
     def __init__(self, flat, boundaries: Sequence[str] = (), module: Optional[torch.nn.Module] = None,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, force: bool = False):
         self.flat = flat
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        # ``force``: hand the buckets to the process group at world size 1 too (a no-op sum, but the real RCCL call on
+        # RCCL's stream): how the exchange is exercised on a one-GPU box (tests/test_rccl_gpu.py, bench.py)
+        self.force = bool(force) and dist.is_initialized()
         cuts = [0]
         if boundaries:
             if module is None:
@@ -96,6 +99,7 @@ class GradBuckets:
             raise RuntimeError(f'GradBuckets: boundaries must be distinct and in parameter order, got offsets {cuts}')
         self.slices = [flat.grad[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
         self._work = []
+        self.issued = 0  # collectives handed to the process group so far
 
     def __len__(self) -> int:
         return len(self.slices)
@@ -107,10 +111,11 @@ class GradBuckets:
 
     def launch(self, i: Optional[int] = None) -> None:
         """All-reduce bucket ``i`` (all buckets when ``None``) without blocking the host."""
-        if self.world_size <= 1:
+        if self.world_size <= 1 and not self.force:
             return
         for s in (self.slices if i is None else [self.slices[i]]):
             self._work.append(dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.issued += 1
 
     def wait(self) -> None:
         for w in self._work:

@@ -54,6 +54,43 @@ def save_image(tensor: Tensor, path: str) -> None:
     Image.fromarray(img.numpy()).save(path)
 
 
+class LossRing:
+    """Every step's train loss for wandb without a device -> host sync per step.
+
+    The reference hands the loss TENSOR to ``wandb.log`` on every step (trainer.py:393-399,459-466), which reads it
+    back -- a sync per step, ~10 % of a 9 ms step.  Here the step itself appends the scalar to a device ring
+    (``srx_ring_push``, the last kernel of the replayed hipGraph), the host only notes the step id and the host-side
+    values that go with it, and ``flush`` reads the ring back in ONE copy per ``cap`` steps and emits the same
+    ``wandb.log`` calls -- same keys, same step axis, every sample.
+    """
+
+    def __init__(self, device, cap: int = 50):
+        self.cap = cap
+        self.ring = torch.zeros(cap * 4, dtype=torch.float32, device=device)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self.read = 0        # records already flushed
+        self.pending = []    # [(key, step, other contents)] in push order
+
+    def push(self, loss: Tensor) -> None:
+        """Device side (captured into the step's hipGraph)."""
+        F.call('srx_ring_push', loss.data_ptr(), None, None, None, 1, self.ring.data_ptr(), self.counter.data_ptr(),
+               self.cap, torch.cuda.current_stream().cuda_stream)
+
+    def note(self, key: str, step: int, contents: dict) -> bool:
+        """Host side, once per pushed record; True when the ring is full and must be flushed."""
+        self.pending.append((key, step, contents))
+        return len(self.pending) >= self.cap
+
+    def flush(self, log) -> None:
+        if not self.pending:
+            return
+        values = self.ring.view(self.cap, 4)[:, 0].cpu()  # the one sync
+        for i, (key, step, contents) in enumerate(self.pending):
+            log({**contents, key: float(values[(self.read + i) % self.cap])}, step=step)
+        self.read += len(self.pending)
+        self.pending = []
+
+
 class SRGANTrainer:
     """``SRGANTrainer(device, args, train_loader, test_loader, train_len, test_len, distributed)``.
 
@@ -69,7 +106,7 @@ class SRGANTrainer:
     # data parallel: first parameter of the gradient bucket that autograd completes FIRST (see ddp.py)
     gen_tail_bucket = 'conv_layers.0.conv.weight'
     disc_head_bucket = 'classifier.0.weight'
-    wandb_log_every = 50  # steps between train-loss samples sent to wandb (each one is a device -> host sync)
+    wandb_flush_every = 50  # steps between read-backs of the per-step train losses (LossRing): one sync per flush
 
     def __init__(self, device, args: Namespace, train_loader, test_loader, train_len: int, test_len: int,
                  distributed: bool = False) -> None:
@@ -92,6 +129,8 @@ class SRGANTrainer:
         self.main_process = args.rank in [-1, 0]
         self.use_graphs = bool(getattr(args, 'use_graphs', True))
         self.vgg_weights = getattr(args, 'vgg_weights', None)
+        # issue the gradient all-reduces even at world size 1 (a one-GPU rehearsal of the RCCL path)
+        self.force_collectives = bool(getattr(args, 'force_collectives', False))
         if self.device.type != 'cuda':
             raise RuntimeError('torchsr_amd trains on an MI355X (device "cuda"); there is no CPU path')
         if self.device.index is None:
@@ -106,6 +145,9 @@ class SRGANTrainer:
         self._static: Dict[str, Tensor] = {}
         self._phase = None
         self._cuts = BackwardCuts(('g.tail', 'd.head')) if distributed else None
+        # per-step train losses for wandb: only when a run is active on this process (decided before graph capture)
+        self._ring = LossRing(self.device, self.wandb_flush_every) \
+            if (wandb and self.main_process and getattr(wandb, 'run', None) is not None) else None
         F.direct_grads[0] = True  # parameter gradients accumulate straight into the flat .grad views
         self._initialize_trainer()
         self._create_test_image()
@@ -140,8 +182,10 @@ class SRGANTrainer:
         self.disc_flat = FlatParams(self.discriminator)
         # gradient buckets in parameter order: [0] = the body (complete LAST in the backward pass), [1] = the slice
         # autograd completes first (the generator's sub-pixel tail, the discriminator's classifier)
-        self.gen_sync = GradBuckets(self.gen_flat, (self.gen_tail_bucket,), self.generator) if self.distributed else None
-        self.disc_sync = GradBuckets(self.disc_flat, (self.disc_head_bucket,), self.discriminator) \
+        force = self.force_collectives
+        self.gen_sync = GradBuckets(self.gen_flat, (self.gen_tail_bucket,), self.generator, force=force) \
+            if self.distributed else None
+        self.disc_sync = GradBuckets(self.disc_flat, (self.disc_head_bucket,), self.discriminator, force=force) \
             if self.distributed else None
 
     def _initialize_loss(self) -> None:
@@ -296,6 +340,20 @@ class SRGANTrainer:
         with F.deferred_weight_grads():
             self._cuts.resume(cut)
 
+    def _push_loss(self, key: str) -> None:
+        """Last kernel of a step: append the step's train loss to the wandb ring (no-op without a wandb run)."""
+        if self._ring is not None:
+            self._ring.push(self._losses[key])
+
+    def _note_loss(self, key: str, step: int, contents: dict) -> None:
+        """trainer.py:393-399 / :459-466: one wandb sample per step, delivered at the next flush."""
+        if self._ring is not None and self._ring.note(key, step, contents):
+            self._ring.flush(self._log_wandb)
+
+    def _flush_losses(self) -> None:
+        if self._ring is not None:
+            self._ring.flush(self._log_wandb)
+
     # ------------------------------------------------------------------ pre-training
     def _pretrain_body(self) -> None:
         """Loop body of ``_pretrain``, trainer.py:380-386.  The autocast region is the generator forward + MSE
@@ -322,11 +380,13 @@ class SRGANTrainer:
                 self._exec('psnr.body', lambda: self._resume('g.tail'))       # residual tower backward
                 self.gen_sync.launch(0)
                 self.gen_sync.wait()
-                self._exec('psnr.opt', self.psnr_optimizer.step)
+                self._exec('psnr.opt', lambda: (self.psnr_optimizer.step(), self._push_loss('psnr/train-loss')))
             finally:
                 F.cut_hook[0] = None
+                self._cuts.clear()
         else:
-            self._exec('psnr.all', lambda: (self._pretrain_body(), self.psnr_optimizer.step()))
+            self._exec('psnr.all', lambda: (self._pretrain_body(), self.psnr_optimizer.step(),
+                                            self._push_loss('psnr/train-loss')))
         return self._losses['psnr/train-loss']
 
     def _pretrain(self) -> None:
@@ -353,9 +413,9 @@ class SRGANTrainer:
             for sub_step, (low_res, high_res) in enumerate(self.train_loader):
                 loss = self.pretrain_step(low_res, high_res)
                 step = (sub_step * self.batch_size * self.world_size) + ((epoch - 1) * self.train_len)
-                if sub_step % self.wandb_log_every == 0:  # trainer.py:393-399 logs every step (a sync each)
-                    self._log_wandb({'psnr/train-loss': loss, 'psnr/epoch': epoch}, step=step)
+                self._note_loss('psnr/train-loss', step, {'psnr/epoch': epoch})   # trainer.py:393-399, every step
             torch.cuda.synchronize()
+            self._flush_losses()
             time_taken = time.time() - start_time
             throughput = len(self.train_loader) * self.batch_size * self.world_size / time_taken
             self._log(f'Throughput: {round(throughput, 3)} images/sec')
@@ -409,6 +469,7 @@ class SRGANTrainer:
         self._phase_content()
         self._phase_gen()
         self.gen_optimizer.step()                                            # :469
+        self._push_loss('gan/train-loss')
 
     def gan_step(self, low_res: Tensor, high_res: Tensor) -> Dict[str, Tensor]:
         """One full GAN step (``_gan_loop`` without the logging); returns device loss tensors."""
@@ -426,7 +487,7 @@ class SRGANTrainer:
                 self.disc_sync.launch(1)           # classifier.*: 75.5 MB, under D's conv backward + the VGG forward
                 self._exec('gan.disc.body', self._phase_disc_body)
                 self.disc_sync.launch(0)           # features.*: 19 MB, under the VGG forward
-                self._cuts.names = {'g.tail'}      # (ESRGAN runs its second generator forward in this segment)
+                self._cuts.names = {'g.tail'}
                 self._exec('gan.content', self._phase_content)
                 self.disc_sync.wait()
                 self._cuts.names = set()           # the discriminator pass below is differentiated in ONE piece
@@ -435,21 +496,19 @@ class SRGANTrainer:
                 self._exec('gan.gen.body', self._phase_gen_body)
                 self.gen_sync.launch(0)
                 self.gen_sync.wait()
-                self._exec('gan.gopt', self.gen_optimizer.step)
+                self._exec('gan.gopt', lambda: (self.gen_optimizer.step(), self._push_loss('gan/train-loss')))
             finally:
                 F.cut_hook[0] = None
+                self._cuts.clear()  # a segment that raised between a cut and its resume must not leak into the next step
         else:
             self._exec('gan.all', self._gan_all)
         return self._losses
 
     def _gan_loop(self, low_res: Tensor, high_res: Tensor, step: int) -> None:
         """trainer.py:416-469."""
-        losses = self.gan_step(low_res, high_res)
-        self._gan_calls = getattr(self, '_gan_calls', 0) + 1
-        if (self._gan_calls - 1) % self.wandb_log_every == 0:  # :459-466 logs every step (a sync each)
-            self._log_wandb({'gan/disc-lr': self.disc_scheduler.get_last_lr()[0],
-                             'gan/gen-lr': self.gen_scheduler.get_last_lr()[0],
-                             'gan/train-loss': losses['gan/train-loss']}, step=step)
+        self.gan_step(low_res, high_res)
+        self._note_loss('gan/train-loss', step, {'gan/disc-lr': self.disc_scheduler.get_last_lr()[0],   # :459-466,
+                                                 'gan/gen-lr': self.gen_scheduler.get_last_lr()[0]})     # every step
 
     def _gan_train(self) -> None:
         """trainer.py:471-531."""
@@ -481,6 +540,7 @@ class SRGANTrainer:
                        ((self.pre_epochs + epoch - 1) * self.train_len)
                 self._gan_loop(low_res, high_res, step)
             torch.cuda.synchronize()
+            self._flush_losses()
             time_taken = time.time() - start_time
             throughput = len(self.train_loader) * self.batch_size * self.world_size / time_taken
             self._log(f'Throughput: {round(throughput, 3)} images/sec')

@@ -34,9 +34,24 @@ def load_generator_state(path: str) -> OrderedDict:
 
 @torch.no_grad()
 def upscale(generator: torch.nn.Module, low_res: Tensor, halo: int = None,
-            max_tile_pixels: int = MAX_TILE_PIXELS, scale: int = 4) -> Tensor:
-    """``generator(low_res)`` in eval mode, tiled when the image is large.  ``low_res``: [N,3,h,w]."""
+            max_tile_pixels: int = MAX_TILE_PIXELS, scale: int = 4, precision: str = None) -> Tensor:
+    """``generator(low_res)`` in eval mode, tiled when the image is large.  ``low_res``: [N,3,h,w].
+
+    ``precision``: ``'fp32'`` (exact; the reference's ``test`` runs no autocast, test.py:57-62) or ``'bf16'`` (bf16
+    products with fp32 accumulation in every conv but the 3-channel ones); ``None`` keeps
+    whatever the generator's convs are set to.  The setting is restored afterwards."""
+    from .layers import Conv2d, set_conv_precision
     generator.eval()
+    if precision is not None:
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError(f"upscale: precision must be 'fp32' or 'bf16', got {precision!r}")
+        saved = [(m, m._st.precision) for m in generator.modules() if isinstance(m, Conv2d)]
+        set_conv_precision(generator, precision)
+        try:
+            return upscale(generator, low_res, halo, max_tile_pixels, scale, None)
+        finally:
+            for m, p in saved:
+                m._st.precision = p
     if halo is None:
         halo = int(getattr(generator, 'halo', HALO))
     n, c, h, w = low_res.shape
@@ -67,6 +82,6 @@ def test(args: Namespace, model: object, device) -> None:
     generator.load_state_dict(load_generator_state(f'{args.model.lower()}-gan-best.pth'))
     image = np.asarray(Image.open(args.image).convert('RGB'), dtype='float32') / 255.0
     low_res = torch.from_numpy(image).permute(2, 0, 1).unsqueeze(0).contiguous().to(device)
-    super_res = upscale(generator, low_res)
+    super_res = upscale(generator, low_res, precision=getattr(args, 'precision', None) or 'fp32')
     head, tail = os.path.split(args.image)
     save_image(super_res, os.path.join(head, f'upres-{tail}'))

@@ -104,6 +104,9 @@ def parse_args(argv=None) -> Namespace:
     test = commands.add_parser('test', help='Generate a super resolution image from a trained model.')
     test.add_argument('image', type=str)
     test.add_argument('--model', type=str, default=MODEL, choices=MODELS.keys())
+    test.add_argument('--precision', type=str, default='fp32', choices=('fp32', 'bf16'),
+                      help='conv arithmetic of the generator forward: exact fp32 (the reference runs no autocast here) or '
+                           'bf16 products with fp32 accumulation')
     return parser.parse_args(argv)
 
 
@@ -111,6 +114,18 @@ def main(argv=None) -> None:
     """torchsr.py:239-270."""
     args = parse_args(argv)
     args, distributed = distributed_params(args)
+    model_class = crop_size = None
+    if args.function == 'train':
+        model_class, crop_size = select_trainer_model(args)
+    # checked before wandb.init so that a refused start leaves no open run; a run that never enters the GAN phase
+    # (--epochs 0: pre-training only) never evaluates the perceptual loss
+    if args.function == 'train' and args.vgg_weights != 'random' and args.epochs > 0:
+        # the reference always trains against the pretrained VGG19 (srgan/loss.py:30); a perceptual loss on random
+        # features is not that objective, so it has to be asked for
+        from torchsr_amd.srgan.loss import VGG19_FILE, _find_weights
+        if _find_weights(args.vgg_weights) is None:
+            sys.exit(f'torchsr train: {VGG19_FILE} not found (--vgg-weights PATH, $TORCHSR_VGG19_WEIGHTS or the torch hub '
+                     'cache); pass "--vgg-weights random" to train against seeded random VGG19 features instead')
     if wandb and args.rank in [-1, 0]:                      # torchsr.py:242-243
         wandb.init(config=args, name='TorchSR', project='torchsr')
     device = get_device(args)
@@ -118,14 +133,6 @@ def main(argv=None) -> None:
         from torchsr_amd.test import test
         test(args, select_test_model(args), device)
         return
-    model_class, crop_size = select_trainer_model(args)
-    if args.vgg_weights != 'random':
-        # the reference always trains against the pretrained VGG19 (srgan/loss.py:30); a perceptual loss on random
-        # features is not that objective, so it has to be asked for
-        from torchsr_amd.srgan.loss import VGG19_FILE, _find_weights
-        if _find_weights(args.vgg_weights) is None:
-            sys.exit(f'torchsr train: {VGG19_FILE} not found (--vgg-weights PATH, $TORCHSR_VGG19_WEIGHTS or the torch hub '
-                     'cache); pass "--vgg-weights random" to train against seeded random VGG19 features instead')
     if args.seed:
         random.seed(args.seed)
         np.random.seed(args.seed)
