@@ -92,8 +92,14 @@ def _bn_folded_state(sd, eps=1e-5):
 def test_1080p_inference_bf16_products_vs_oracle(dev):
     """BASELINE config 5 with ``precision='bf16'`` ("fp32 and bf16"): the full 1080p frame,
     windows against (a) the fp32 oracle -- the reference-anchored statement: within 2e-2 of the exact result, relative to
-    the window's largest value -- and (b) the bf16-products oracle on the BatchNorm-folded weights, i.e. the arithmetic
-    the product states it performs, at 2e-3.  The fp32 call afterwards must be exact again (precision is restored)."""
+    the window's largest value -- and (b) the bf16-products oracle on the BatchNorm-folded weights: the product must be
+    as close to the exact result as that restatement of its arithmetic is (rms error within 1.5x).  Two evaluations of
+    the SAME bf16-product arithmetic cannot be compared more tightly end to end: they differ in the order of the fp32
+    sums, an activation in 1e4 then rounds to the other bf16 neighbour, and with these weights (outputs are sums of
+    hundreds of cancelling terms) one such flip moves a conv output by 1e-4 of the tensor's maximum -- 1e-2 after the
+    generator's 37 convs, as far as either is from the exact result (tools/experiments/diag_infer_bf16.py).  The
+    arithmetic itself is pinned layer by layer in test_bf16_inference_layers_vs_rounded_operands.
+    The fp32 call afterwards must be exact again (precision is restored)."""
     from oracle import srgan as O
     from oracle.weights import closed_form_state
     from torchsr_amd.srgan.generator import Generator
@@ -120,11 +126,66 @@ def test_1080p_inference_bf16_products_vs_oracle(dev):
         got = out[:, :, 4 * y0:4 * (y0 + win), 4 * x0:4 * (x0 + win)].cpu()
         top = max(exact.abs().max().item(), 1e-3)
         assert (got - exact).abs().max().item() <= 2e-2 * top, (y0, x0, (got - exact).abs().max().item() / top)
-        assert (got - ref).abs().max().item() <= 2e-3 * top, (y0, x0, (got - ref).abs().max().item() / top)
+        rms = lambda t: t.double().square().mean().sqrt().item()  # noqa: E731
+        assert rms(got - exact) <= 1.5 * rms(ref - exact), (y0, x0, rms(got - exact), rms(ref - exact))
+        assert rms(got - ref) <= 2.0 * rms(ref - exact), (y0, x0, rms(got - ref), rms(ref - exact))
     again = upscale(gen, frame[:, :, :200, :300].to(dev))
     with torch.no_grad():
         want = O.generator_forward(sd, frame[:, :, :200, :300].contiguous(), training=False)
     assert (again.cpu() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
+def test_bf16_inference_layers_vs_rounded_operands(dev):
+    """The arithmetic of ``precision='bf16'`` inference, one fused layer at a time on the layer's OWN input (so that nothing
+    compounds): conv [+ folded BatchNorm] [+ PReLU] [+ PixelShuffle] [+ skip] = fp64 evaluation of
+    ``act(conv(bf16(x), bf16(w_folded)) + b_folded) + skip`` to 2e-5; the 64 -> 3 output conv is exact fp32."""
+    import torch.nn.functional as TF
+    from oracle.weights import closed_form_state
+    from torchsr_amd import functional as F
+    from torchsr_amd.layers import set_conv_precision
+    from torchsr_amd.srgan.generator import Generator
+    gen = Generator().to(dev)
+    gen.load_state_dict(closed_form_state(gen.state_dict()))
+    gen.eval()
+    set_conv_precision(gen, 'bf16')
+    r16 = lambda t: t.to(torch.bfloat16).double()  # noqa: E731
+    nchw = lambda t, c=None: F.to_nchw(t, c).cpu()  # noqa: E731
+
+    def rel(a, b):
+        return ((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-9)).item()
+
+    def check(name, layer, x4, skip4=None, shuffle=False, exact=False, cout=None):
+        y = layer(x4) if skip4 is None else layer(x4, residual=skip4)
+        fc = layer if isinstance(layer, F.FoldedConv) else None
+        w, b = (fc.w, fc.b) if fc else (layer.weight.detach(), layer.bias.detach())
+        st = fc.st if fc else layer._st
+        xin = nchw(x4, st.cin)
+        z = TF.conv2d(xin.double() if exact else r16(xin), w.cpu().double() if exact else r16(w.cpu()),
+                      None if b is None else b.cpu().double(), st.stride, st.pad)
+        if shuffle:
+            z = TF.pixel_shuffle(z, 2)
+        if st.act:
+            z = torch.where(z > 0, z, z * st.slope)
+        if skip4 is not None:
+            z = z + nchw(skip4).double()
+        assert rel(nchw(y, cout), z) < 2e-5, (name, rel(nchw(y, cout), z))
+        return y
+
+    with torch.no_grad():
+        x4 = F.to_nhwc(torch.rand(1, 3, 56, 72, generator=torch.Generator().manual_seed(5)).to(dev), 4)
+        gen.forward_nhwc(x4)  # builds the folded layers
+        f = gen.__dict__['_folded']
+        c1 = check('conv1 + PReLU', f[0], x4)
+        t = c1
+        for i, blk in enumerate(gen.blocks):
+            fa, fb = blk.__dict__['_folded']
+            a = check(f'blocks.{i}.conv1 + bn1 + PReLU', fa, t)
+            t = check(f'blocks.{i}.conv2 + bn2 + x', fb, a, skip4=t)
+        out = check('conv2 + bn + conv1', f[1], t, skip4=c1)
+        for i, layer in enumerate(gen.conv_layers):
+            layer(out)
+            out = check(f'conv_layers.{i} + PixelShuffle + PReLU', layer.__dict__['_folded'], out, shuffle=True)
+        check('conv3 (exact fp32)', gen.conv3, out, exact=True, cout=3)
 
 
 def test_device_data_pipeline_cli(dev, tmp_path, monkeypatch):

@@ -232,8 +232,10 @@ def _esr_worker(rank, world, port, out):
                     if (diff.max() / r.abs().max().clamp_min(1e-6)).item() > 1e-3:
                         bad.append((name, k, 'running'))
                 else:
+                    # (elements whose averaged gradient sits at the fp32 noise floor step differently in any two fp32
+                    # evaluations: 0.2-0.6 % of a dense-block weight here, tools/experiments/esrgan_noise_floor.py)
                     n_bad = int((diff > 2e-6).sum())
-                    if n_bad > max(2, int(5e-3 * diff.numel())) or diff.max().item() > 2.1e-4:
+                    if n_bad > max(2, int(1e-2 * diff.numel())) or diff.max().item() > 2.1e-4:
                         bad.append((name, k, n_bad, diff.max().item()))
         report['bad'] = bad
         out[rank] = report
