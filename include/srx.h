@@ -238,6 +238,18 @@ int srx_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx
 int srx_lrelu_fwd(const float* x, float* y, int64_t n, float slope, void* stream);
 /* y = a*x + b*z  (residual scaling of esrgan/residual.py:86,128; torch.add of srgan/generator.py:78) */
 int srx_axpby(const float* x, const float* z, float* y, int64_t n, float a, float b, void* stream);
+/* ESRGAN ResidualDenseBlock.forward (esrgan/residual.py:65-86) as ONE launch, bf16 products / fp32 accumulate:
+ *   c_k = LeakyReLU(conv_k(cat(x, c_1..c_{k-1})) + b_k, slope), k = 1..4;  out = (conv_5(cat(x, c_1..c_4)) + b_5) * scale + x
+ * buf: NHWC [N][H][W][ld], ld >= 192: x in channels 0..63 on entry; c_1..c_4 (fp32, what the backward pass reads) are
+ * written to channels 64..191.  out: [N][H][W][out_ld], channels 0..63 (the next block's buffer in an RRDB chain).
+ * wpk: this block's stream of srx_rdb_packed_bytes() bytes written by srx_rdb_pack; bias5: HOST array of the five
+ * device bias pointers (32, 32, 32, 32, 64 floats).  One workgroup per 8x8 pixel tile; any H, W. */
+size_t srx_rdb_packed_bytes(void);
+/* w_table_dev: DEVICE array of 5 * nblk pointers to the OIHW fp32 weights (conv1..conv5 of block 0, of block 1, ...);
+ * dst: nblk * srx_rdb_packed_bytes() bytes.  One launch for all blocks (after an optimiser step). */
+int srx_rdb_pack(const float* const* w_table_dev, int nblk, void* dst, void* stream);
+int srx_rdb_fwd(int N, int H, int W, float* buf, int ld, const void* wpk, const float* const* bias5, float scale,
+                float slope, float* out, int out_ld, void* stream);
 /* Per-step scalars without a per-step device->host sync: append n <= 4 device scalars (*a, *b, *c, *d) as one
  * 4-float record to ring[(*counter % cap) * 4 ...] and increment *counter (device int32).  The launch is the same every
  * step, so it sits inside the replayed hipGraph; the host reads `cap` records back in one copy.  Replaces the

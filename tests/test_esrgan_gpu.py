@@ -364,7 +364,10 @@ def test_rrdb_modules_alone_equal_the_trunk_node(dev, bf16):
     # -- and every later operand that differs in its last fp32 bits may round to the other bf16 neighbour (2^-9 of that
     # product).  The parameter gradients are sums over only 512 pixels here: compared in the L2 norm, loosely element-wise.
     rel2 = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-12)).item()  # noqa: E731
-    assert rel(ya, yb) < 1e-5 and rel(dxa, dxb) < (5e-4 if bf16 else 2e-5), (rel(ya, yb), rel(dxa, dxb))
+    # (forward, bf16: the trunk runs a dense block as one launch -- srx_rdb_fwd -- which sums the same products in another
+    # order than the modules' five launches; an intermediate that then differs in its last fp32 bit can round to the other
+    # bf16 neighbour, 2^-9 of one product)
+    assert rel(ya, yb) < (1e-4 if bf16 else 1e-5) and rel(dxa, dxb) < (5e-4 if bf16 else 2e-5), (rel(ya, yb), rel(dxa, dxb))
     if bf16:  # yardstick: the exact-fp32 gradients.  Two bf16 evaluation orders must be closer to each other than to those
         set_conv_precision(blocks, 'fp32')
         _, dxe, ge = run('modules')

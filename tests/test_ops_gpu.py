@@ -816,3 +816,50 @@ def test_conv2d_random_shapes(dev, case):
     whatever tile / split plan the library picks, forward, data gradient, weight and bias gradients must agree
     with the CPU convolution."""
     test_conv2d_fwd_bwd(dev, case)
+
+
+@pytest.mark.parametrize('n,h,w', [(2, 16, 16), (1, 13, 21), (3, 8, 8), (1, 5, 40)])
+def test_fused_dense_block_forward(dev, n, h, w):
+    """``srx_rdb_fwd`` (one launch: five convs, intermediates in LDS, bf16 products) against an fp64 evaluation of the same
+    arithmetic -- every conv multiplies bf16-rounded inputs and weights, sums exactly, adds the fp32 bias; c1..c4 are kept
+    in fp32 and rounded again where the next conv reads them (torchsr/esrgan/residual.py:81-86) -- on tiles that are whole,
+    ragged (H, W not multiples of 8) and narrower than the halo, through the C ABI."""
+    import ctypes as C
+    import torch.nn.functional as TF
+    from torchsr_amd import _lib
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(100 * h + w)
+    r16 = lambda t: t.to(torch.bfloat16).double()  # noqa: E731
+    ws = [torch.randn(32 if k < 4 else 64, 64 + 32 * k, 3, 3, generator=g) * (2.0 / (9 * (64 + 32 * k))) ** 0.5 for k in range(5)]
+    bs = [torch.randn(32 if k < 4 else 64, generator=g) * 0.1 for k in range(5)]
+    x = torch.randn(n, 64, h, w, generator=g)
+    # device
+    wd = [t.to(dev).contiguous() for t in ws]
+    bd = [t.to(dev).contiguous() for t in bs]
+    table = torch.tensor([t.data_ptr() for t in wd], dtype=torch.int64).to(dev)
+    per = L.srx_rdb_packed_bytes()
+    assert per == 479232
+    pk = torch.empty(per, dtype=torch.uint8, device=dev)
+    _lib.call('srx_rdb_pack', table.data_ptr(), 1, pk.data_ptr(), s)
+    buf = torch.full((n, h, w, 192), float('nan'), device=dev)
+    buf[..., :64] = x.permute(0, 2, 3, 1).to(dev)
+    out = torch.full((n, h, w, 192), float('nan'), device=dev)
+    biases = (C.c_void_p * 5)(*[t.data_ptr() for t in bd])
+    _lib.call('srx_rdb_fwd', n, h, w, buf.data_ptr(), 192, pk.data_ptr(), biases, 0.2, 0.2, out.data_ptr(), 192, s)
+    torch.cuda.synchronize()
+    got_c = buf[..., 64:].permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got_c).all()
+    # reference, conv by conv ON THE DEVICE'S OWN intermediates (an intermediate one fp32 ulp away from its fp64 value may
+    # round to the other bf16 neighbour in the next conv: 2^-9 of a product, not an error of this kernel)
+    feats = [x]
+    for k in range(4):
+        z = TF.conv2d(r16(torch.cat(feats, 1)), r16(ws[k]), bs[k].double(), 1, 1)
+        want = torch.where(z > 0, z, z * 0.2)
+        got = got_c[:, 32 * k:32 * k + 32]
+        assert ((got.double() - want).abs().max() / want.abs().max()).item() < 2e-5, (k, ((got - want).abs().max() / want.abs().max()).item())
+        feats.append(got)
+    y = TF.conv2d(r16(torch.cat(feats, 1)), r16(ws[4]), bs[4].double(), 1, 1) * 0.2 + x.double()
+    got_y = out[..., :64].permute(0, 3, 1, 2).cpu().double()
+    assert ((got_y - y).abs().max() / y.abs().max()).item() < 2e-5
+    assert torch.isnan(out[..., 64:]).all() and torch.equal(buf[..., :64].cpu(), x.permute(0, 2, 3, 1))  # nothing else touched

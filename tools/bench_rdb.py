@@ -1,0 +1,48 @@
+"""srx_rdb_fwd alone: 69 dependent launches (one generator forward's dense blocks) at batch 16, 32x32 (developer tool)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torchsr_amd import _lib  # noqa: E402
+
+dev = torch.device('cuda:0')
+L = _lib.lib()
+n, h, w, nb = 16, 32, 32, 69
+ws = [torch.randn(32 if k < 4 else 64, 64 + 32 * k, 3, 3, device=dev) * 0.02 for k in range(5)]
+bs = [torch.zeros(32 if k < 4 else 64, device=dev) for k in range(5)]
+table = torch.tensor([t.data_ptr() for t in ws] * nb, dtype=torch.int64).to(dev)
+per = L.srx_rdb_packed_bytes()
+pk = torch.empty(per * nb, dtype=torch.uint8, device=dev)
+s = torch.cuda.current_stream().cuda_stream
+_lib.call('srx_rdb_pack', table.data_ptr(), nb, pk.data_ptr(), s)
+bufs = [torch.randn(n, h, w, 192, device=dev) for _ in range(4)]
+biases = (C.c_void_p * 5)(*[t.data_ptr() for t in bs])
+
+
+def chain():
+    s = torch.cuda.current_stream().cuda_stream  # (the capture stream inside torch.cuda.graph)
+    for i in range(nb):
+        _lib.call('srx_rdb_fwd', n, h, w, bufs[i % 4].data_ptr(), 192, pk.data_ptr() + i * per, biases, 0.2, 0.2,
+                  bufs[(i + 1) % 4].data_ptr(), 192, s)
+
+
+chain()
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    chain()
+for _ in range(3):
+    g.replay()
+torch.cuda.synchronize()
+ts = []
+for _ in range(10):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); g.replay(); e1.record(); e1.synchronize()
+    ts.append(e0.elapsed_time(e1) * 1e3 / nb)
+ts.sort()
+gf = 2.0 * n * h * w * 9 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64) / 1e9
+print(f'rdb_fwd: {ts[len(ts) // 2]:.2f} us per block in-graph (min {ts[0]:.2f}); {gf:.3f} GFLOP -> {gf / ts[len(ts) // 2] * 1e3:.1f} TFLOP/s')
+

@@ -12,7 +12,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('SRX_LIB') or os.path.join(CSRC, 'libsrx_hip.so')  # SRX_LIB: developer A/B builds on one GPU box
-SOURCES = ['api.cpp', 'gconv.hip', 'thin.hip', 'rowtile.hip', 'augment.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'optim.hip']
+SOURCES = ['api.cpp', 'gconv.hip', 'rdb.hip', 'thin.hip', 'rowtile.hip', 'augment.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'optim.hip']
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
 
@@ -92,6 +92,9 @@ _SIGS = {
     'srx_conv2d_bwd_weight_multi': (_I, [_D, _I, _I, _P, _P, _P, _I, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_weight_multi_scaled': (_I, [_D, _I, _I, _P, _P, _P, _I, _P, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_weight_multi_pair': (_I, [_D, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _Z, _P]),
+    'srx_rdb_packed_bytes': (_Z, []),
+    'srx_rdb_pack': (_I, [_P, _I, _P, _P]),
+    'srx_rdb_fwd': (_I, [_I, _I, _I, _P, _I, _P, _P, _F, _F, _P, _I, _P]),
     'srx_colsum_ws_floats': (_Z, [_L, _I]),
     'srx_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     'srx_crop_flip_u8': (_I, [_P, _P, _P, _I, _I, _P]),

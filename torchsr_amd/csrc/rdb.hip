@@ -1,0 +1,399 @@
+// ESRGAN ResidualDenseBlock forward as ONE kernel (torchsr/esrgan/residual.py:65-86), bf16 products / fp32 accumulate.
+//
+//   c_k = LeakyReLU(conv_k(cat(x, c_1..c_{k-1})) + b_k), k = 1..4;   y = (conv_5(cat(x, c_1..c_4)) + b_5) * scale + x
+//
+// As five launches the block is launch- and fill-bound: at batch 16 x 32x32 pixels every conv is 0.6-1.8 GFLOP, one
+// round of <= 256 workgroups that each stream their operands for a few microseconds (11.9-17 us per launch for < 1 us of
+// bf16 matrix work, profiles/r02_other_configs.txt), and every 32-channel slice makes an HBM round trip between convs.
+// Here one workgroup owns an 8x8 pixel tile of one image -- 16 images x 16 tiles = exactly the chip's 256 CUs -- and runs
+// the whole chain on it:
+//   * the input patch with a 5-pixel halo (18x18 x 64 channels) is staged ONCE, rounded to bf16 (what the product
+//     multiplies anyway), and the four intermediates live in LDS as bf16 on shrinking regions (16x16, 14x14, 12x12,
+//     10x10): 84 KB in all.  Halo pixels are recomputed by the neighbouring tiles (1.77x the FLOPs, at a few per cent
+//     of the bf16 MFMA peak that is free); pixels outside the image are stored as the zeros the next conv's padding reads.
+//   * weights come as bf16 tiles pre-swizzled for the LDS image (srx_rdb_pack, once per optimiser step for all blocks):
+//     one unit = one 32-channel source x 9 taps x all output channels (18 / 36 KB).  Waves 4..7 stream them: unit u + 1
+//     goes global -> registers -> the other LDS slot while unit u is multiplied; ONE barrier per unit, 20 units per block.
+//   * waves 0..3 (one per SIMD) multiply: a wave owns up to two 32-pixel x 32-channel output tiles of the current conv and
+//     reads every weight fragment once for both; fragments are requested two taps ahead, reads and address arithmetic
+//     interleaved with the MFMAs (sched_group_barrier).  Operands are (weights as A, pixels as B) so that a lane ends
+//     up with four consecutive channels of one pixel per accumulator quad: packed 8-byte LDS stores for the next conv,
+//     16-byte global stores for the fp32 copies the backward pass needs (tile centre only).
+// Measured (MI355X, batch 16 x 32x32, 69 dependent launches in a hipGraph): 28.6 us per block against 61 us for the five
+// launches it replaces; 1944 MFMAs per workgroup = 7.4 us of matrix time per SIMD, the rest is the patch staging (2.9 us),
+// the four epilogues (4 us), 20 barriers and LDS reads that are 36 % bank-conflict cycles (region rows of 16..8 pixels
+// in images of 18..10 pixels pitch: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r03_pmc_rdb.txt).
+// 64-byte LDS rows (32 bf16 channels); the 16-byte quad j of row r sits at quad j ^ ((r >> 2) & 3): sixteen consecutive
+// rows then cover all 64 banks once per ds_read_b128 lane group.
+#include "srx_common.h"
+#include <mutex>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RT = 8;    // output tile edge
+constexpr int NSRC = 6;  // 32-channel sources: x[0:32], x[32:64], c1, c2, c3, c4
+// source s: edge of its LDS image, origin relative to the tile (region of c_j = tile grown by 5 - j pixels)
+__host__ __device__ constexpr int src_w(int s) { return s < 2 ? RT + 10 : RT + 10 - 2 * (s - 1); }
+__host__ __device__ constexpr int src_org(int s) { return s < 2 ? -5 : -(5 - (s - 1)); }
+__host__ __device__ constexpr int src_off(int s) {  // byte offset of the image in LDS
+  int o = 0;
+  for (int i = 0; i < s; ++i) o += src_w(i) * src_w(i) * 64;
+  return o;
+}
+constexpr int ACT_BYTES = src_off(NSRC);  // 86016
+// conv k (1..5): output region = image of source k + 1 (k < 5) or the tile itself
+__host__ __device__ constexpr int reg_w(int k) { return k < 5 ? src_w(k + 1) : RT; }
+__host__ __device__ constexpr int reg_org(int k) { return k < 5 ? src_org(k + 1) : 0; }
+__host__ __device__ constexpr int conv_n(int k) { return k == 5 ? 64 : 32; }
+__host__ __device__ constexpr int conv_cin(int k) { return 64 + 32 * (k - 1); }
+// weight units in consumption order: conv 1 (2 sources), conv 2 (3), ... conv 5 (6)
+constexpr int NUNITS = 20;
+__host__ __device__ constexpr int unit_first(int k) { return (k - 1) * (k + 2) / 2; }  // 0, 2, 5, 9, 14
+__host__ __device__ constexpr int unit_conv(int u) { return u < 2 ? 1 : (u < 5 ? 2 : (u < 9 ? 3 : (u < 14 ? 4 : 5))); }
+__host__ __device__ constexpr int unit_bytes(int u) { return 9 * conv_n(unit_conv(u)) * 64; }
+__host__ __device__ constexpr int unit_off(int u) {
+  int o = 0;
+  for (int i = 0; i < u; ++i) o += unit_bytes(i);
+  return o;
+}
+constexpr int PACKED_BYTES = unit_off(NUNITS);  // 479232 per block
+constexpr int SLOT_BYTES = 9 * 64 * 64;         // 36864: the largest unit
+constexpr int OFF_W = ACT_BYTES;
+constexpr int OFF_BIAS = OFF_W + 2 * SLOT_BYTES;
+constexpr int LDS_BYTES = OFF_BIAS + 192 * 4;   // 160512
+constexpr int NTHREADS = 512;
+
+struct RdbArgs {
+  float* buf;            // [N][H][W][ld]: x in channels 0..63; c1..c4 are written to channels 64..191
+  const unsigned char* wpk;
+  const float* bias[5];
+  float* out;            // [N][H][W][out_ld], channels 0..63
+  int N, H, W, ld, out_ld, tiles_x, tiles_y;
+  float scale, slope;
+};
+
+// Roles.  Waves 0..3 (one per SIMD) multiply: a wave owns up to two 32-pixel tiles of the current conv's region and reads
+// every weight fragment once for both (LDS traffic is what bounds this kernel: 3 fragment reads per 2 MFMAs instead of 4).
+// Waves 4..7 stream the weights: unit u + 1 goes global -> registers -> the other LDS slot while unit u is multiplied.
+constexpr int NCOMPUTE = 4, NLOAD_THREADS = NTHREADS - NCOMPUTE * 64;
+constexpr int MAX_ROUNDS = (SLOT_BYTES / 16 + NLOAD_THREADS - 1) / NLOAD_THREADS;  // 9
+
+struct Wave {
+  f32x16 acc[2];
+  int lane, h, l31, wave;
+  int n_img, ty0, tx0;
+};
+
+// Every loader thread issues the same number of loads per unit (the last round re-reads the unit's final chunk where
+// a thread has nothing left to fetch): a predicated load would be waited for on the spot.
+template <int U>
+__device__ __forceinline__ void load_unit(const RdbArgs& a, int lt, f32x4 (&wr)[MAX_ROUNDS]) {
+  constexpr int chunks = unit_bytes(U) / 16, rounds = (chunks + NLOAD_THREADS - 1) / NLOAD_THREADS;
+  const f32x4* src = reinterpret_cast<const f32x4*>(a.wpk + unit_off(U));
+#pragma unroll
+  for (int i = 0; i < rounds; ++i) wr[i] = src[min(i * NLOAD_THREADS + lt, chunks - 1)];
+}
+template <int U>
+__device__ __forceinline__ void store_unit(unsigned char* lds, int lt, const f32x4 (&wr)[MAX_ROUNDS]) {
+  constexpr int chunks = unit_bytes(U) / 16, rounds = (chunks + NLOAD_THREADS - 1) / NLOAD_THREADS;
+  f32x4* dst = reinterpret_cast<f32x4*>(lds + OFF_W + (U & 1) * SLOT_BYTES);
+#pragma unroll
+  for (int i = 0; i < rounds; ++i)
+    if ((i + 1) * NLOAD_THREADS <= chunks || i * NLOAD_THREADS + lt < chunks) dst[i * NLOAD_THREADS + lt] = wr[i];
+}
+
+// conv K: pixel tiles of 32, channel tiles of 32; a compute wave takes TPW consecutive pixel tiles of one channel tile
+template <int K> __host__ __device__ constexpr int m_tiles() { return (reg_w(K) * reg_w(K) + 31) / 32; }
+template <int K> __host__ __device__ constexpr int n_tiles() { return conv_n(K) / 32; }
+template <int K> __host__ __device__ constexpr int tpw() { return (m_tiles<K>() * n_tiles<K>() + NCOMPUTE - 1) / NCOMPUTE; }
+// wave -> (first pixel tile, channel tile, number of tiles)
+template <int K>
+__device__ __forceinline__ void job(int wave, int& mt0, int& nt, int& cnt) {
+  constexpr int per_n = (m_tiles<K>() + tpw<K>() - 1) / tpw<K>();  // waves per channel tile
+  nt = wave / per_n;
+  mt0 = (wave - nt * per_n) * tpw<K>();
+  cnt = nt < n_tiles<K>() ? max(0, min(tpw<K>(), m_tiles<K>() - mt0)) : 0;
+}
+
+template <int K, int S, int U>
+__device__ __forceinline__ void mma_unit(const unsigned char* lds, Wave& w) {
+  constexpr int NK = conv_n(K), WS = src_w(S), WK = reg_w(K), RK = WK * WK, TPW = tpw<K>();
+  constexpr int D = reg_org(K) - src_org(S) - 1;  // source coordinate of tap (0,0) = region coordinate + D
+  int mt0, nt, cnt;
+  job<K>(w.wave, mt0, nt, cnt);
+  if (cnt == 0) return;
+  int bp[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int q = min((mt0 + i) * 32 + w.l31, RK - 1);
+    const int qy = q / WK, qx = q - qy * WK;
+    bp[i] = (qy + D) * WS + qx + D;
+  }
+  const int nrow = nt * 32 + w.l31;
+  const unsigned char* wrow = lds + OFF_W + (U & 1) * SLOT_BYTES + nrow * 64;
+  const int wsw = (nrow >> 2) & 3;
+  const unsigned char* act = lds + src_off(S);
+  // fragments of tap t + 2 are requested before tap t is multiplied: the wave is alone on its SIMD and an LDS read
+  // under load (four waves reading, four writing the next weights) returns after ~250 cycles -- two taps of MFMAs
+  // (one tap ahead: 255 cycles per tap measured in-kernel, twice the MFMA time)
+  bf16x8 wf[3][2], xf[3][TPW][2];
+  auto fetch = [&](int t, int set) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      wf[set][kk] = *reinterpret_cast<const bf16x8*>(wrow + t * NK * 64 + (((kk * 2 + w.h) ^ wsw) << 4));
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int p = bp[i] + (t / 3) * WS + (t % 3);
+      const int psw = (p >> 2) & 3;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        xf[set][i][kk] = *reinterpret_cast<const bf16x8*>(act + p * 64 + (((kk * 2 + w.h) ^ psw) << 4));
+    }
+  };
+  fetch(0, 0);
+  fetch(1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (t + 2 < 9) fetch(t + 2, (t + 2) % 3);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < TPW; ++i)
+        w.acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t % 3][kk], xf[t % 3][i][kk], w.acc[i], 0, 0, 0);
+    // issue order inside this tap: one MFMA, then a share of the later tap's address arithmetic and fragment reads, so
+    // that the wave's VALU / LDS issue slots fall into the MFMAs' shadows; the closing barrier keeps hipcc from sinking
+    // the reads towards their use
+#pragma unroll
+    for (int g = 0; g < 2 * TPW; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// conv K < 5: bias + LeakyReLU; bf16 to the LDS image of c_K (zeros outside the image), fp32 to the block's buffer
+// (tile centre only: the halo belongs to the neighbouring workgroups)
+template <int K>
+__device__ __forceinline__ void epilogue_mid(const RdbArgs& a, unsigned char* lds, Wave& w) {
+  constexpr int WK = reg_w(K), RK = WK * WK, ORG = reg_org(K), TPW = tpw<K>();
+  int mt0, nt, cnt;
+  job<K>(w.wave, mt0, nt, cnt);
+  const float* bias = reinterpret_cast<const float*>(lds + OFF_BIAS) + 32 * (K - 1);
+  f32x4 b[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(bias + 8 * g + 4 * w.h);
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int q = (mt0 + i) * 32 + w.l31;
+    if (i >= cnt || q >= RK) continue;
+    const int qy = q / WK, qx = q - qy * WK;
+    const int oy = qy + ORG, ox = qx + ORG;
+    const int iy = w.ty0 + oy, ix = w.tx0 + ox;
+    const bool in_img = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    const bool centre = in_img && (unsigned)oy < (unsigned)RT && (unsigned)ox < (unsigned)RT;
+    float* gp = a.buf + ((size_t)(w.n_img * a.H + iy) * a.W + ix) * a.ld + 64 + 32 * (K - 1) + 4 * w.h;
+    unsigned char* cp = lds + src_off(K + 1) + q * 64 + 8 * w.h;
+    const int psw = (q >> 2) & 3;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = w.acc[i][4 * g + e] + b[g][e];
+        v[e] = z > 0.f ? z : z * a.slope;
+      }
+      bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      if (!in_img) pk = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      *reinterpret_cast<bf16x4*>(cp + ((g ^ psw) << 4)) = pk;
+      if (centre) *reinterpret_cast<f32x4*>(gp + 8 * g) = v;
+    }
+  }
+}
+
+// conv 5: (acc + bias) * scale + x -> out
+__device__ __forceinline__ void epilogue_out(const RdbArgs& a, const unsigned char* lds, Wave& w, const f32x4 (&xs)[4]) {
+  int mt0, nt, cnt;
+  job<5>(w.wave, mt0, nt, cnt);
+  if (cnt == 0) return;
+  const int q = mt0 * 32 + w.l31;  // < 64
+  const int qy = q / RT, qx = q - qy * RT;
+  const int iy = w.ty0 + qy, ix = w.tx0 + qx;
+  if (!((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)) return;
+  const size_t pix = (size_t)(w.n_img * a.H + iy) * a.W + ix;
+  const float* bias = reinterpret_cast<const float*>(lds + OFF_BIAS) + 128 + 32 * nt + 4 * w.h;
+  float* op = a.out + pix * a.out_ld + 32 * nt + 4 * w.h;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 8 * g);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (w.acc[0][4 * g + e] + b[e]) * a.scale + xs[g][e];
+    *reinterpret_cast<f32x4*>(op + 8 * g) = v;
+  }
+}
+
+// the skip connection's fp32 x of this wave's conv-5 tile, requested a few units before it is needed
+__device__ __forceinline__ void load_skip(const RdbArgs& a, const Wave& w, f32x4 (&xs)[4]) {
+  int mt0, nt, cnt;
+  job<5>(w.wave, mt0, nt, cnt);
+  const int q = mt0 * 32 + w.l31;
+  const int qy = q / RT, qx = q - qy * RT;
+  const int iy = min(w.ty0 + qy, a.H - 1), ix = min(w.tx0 + qx, a.W - 1);  // (clamped: stores are masked, loads are not)
+  const float* xp = a.buf + ((size_t)(w.n_img * a.H + iy) * a.W + ix) * a.ld + 32 * min(nt, 1) + 4 * w.h;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) xs[g] = *reinterpret_cast<const f32x4*>(xp + 8 * g);
+}
+
+template <int U>
+__device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, Wave& w, int tid, f32x4 (&xs)[4]) {
+  constexpr int K = unit_conv(U), S = U - unit_first(K);
+  __syncthreads();  // unit U's weights (and, for S == 0, the previous conv's output image) are in LDS; slot (U+1)&1 is free
+  if (w.wave >= NCOMPUTE) {
+    if constexpr (U + 1 < NUNITS) {
+      f32x4 wr[MAX_ROUNDS];
+      load_unit<U + 1>(a, tid - NCOMPUTE * 64, wr);
+      store_unit<U + 1>(lds, tid - NCOMPUTE * 64, wr);
+    }
+  } else {
+    if (S == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w.acc[i][r] = 0.f;
+    }
+    if constexpr (U == unit_first(5)) load_skip(a, w, xs);
+    mma_unit<K, S, U>(lds, w);
+    if constexpr (S == K) {  // last source of conv K
+      if constexpr (K < 5) epilogue_mid<K>(a, lds, w);
+      else epilogue_out(a, lds, w, xs);
+    }
+  }
+  if constexpr (U + 1 < NUNITS) run_units<U + 1>(a, lds, w, tid, xs);
+}
+
+__global__ __launch_bounds__(NTHREADS) void rdb_fwd_kernel(const RdbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  Wave w;
+  w.lane = tid & 63; w.h = w.lane >> 5; w.l31 = w.lane & 31; w.wave = srx_uniform(tid >> 6);
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  w.n_img = b / a.tiles_y; w.ty0 = ty * RT; w.tx0 = tx * RT;
+
+  if (w.wave >= NCOMPUTE) {  // the first weight unit
+    f32x4 wr[MAX_ROUNDS];
+    load_unit<0>(a, tid - NCOMPUTE * 64, wr);
+    store_unit<0>(lds, tid - NCOMPUTE * 64, wr);
+  }
+  // the input patch, rounded to bf16 once: 324 pixels x 8 groups of 8 channels; every load is issued before the first
+  // conversion (out-of-image pixels read a clamped address and are zeroed afterwards)
+  constexpr int PW = RT + 10, ITEMS = PW * PW * 8, ROUNDS = (ITEMS + NTHREADS - 1) / NTHREADS;  // 6
+  {
+    f32x4 v[ROUNDS][2];
+    bool ok[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int i = min(r * NTHREADS + tid, ITEMS - 1);
+      const int p = i >> 3, g = i & 7;
+      const int py = p / PW, px = p - py * PW;
+      const int iy = w.ty0 - 5 + py, ix = w.tx0 - 5 + px;
+      ok[r] = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+      const float* xp = a.buf + ((size_t)(w.n_img * a.H + cy) * a.W + cx) * a.ld + 8 * g;
+      v[r][0] = *reinterpret_cast<const f32x4*>(xp);
+      v[r][1] = *reinterpret_cast<const f32x4*>(xp + 4);
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int i = r * NTHREADS + tid;
+      if (i >= ITEMS) continue;
+      const int p = i >> 3, g = i & 7;
+      f32x4 v0 = v[r][0], v1 = v[r][1];
+      if (!ok[r]) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+      const bf16x8 pk = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3],
+                         (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
+      *reinterpret_cast<bf16x8*>(lds + (g >> 2) * (PW * PW * 64) + p * 64 + (((g & 3) ^ ((p >> 2) & 3)) << 4)) = pk;
+    }
+  }
+  if (tid < 192) {
+    const int k = tid < 128 ? tid >> 5 : 4;
+    reinterpret_cast<float*>(lds + OFF_BIAS)[tid] = a.bias[k][tid < 128 ? (tid & 31) : tid - 128];
+  }
+  f32x4 xs[4];
+  run_units<0>(a, lds, w, tid, xs);
+}
+
+// OIHW fp32 weights of every block's five convs -> the bf16 unit stream rdb_fwd_kernel reads (one thread per 16 bytes)
+__global__ void rdb_pack_kernel(const float* const* __restrict__ wtab, unsigned char* __restrict__ dst, int nblk) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int per_blk = PACKED_BYTES / 16;
+  if (gid >= (int64_t)nblk * per_blk) return;
+  const int blk = (int)(gid / per_blk);
+  int c = (int)(gid - (int64_t)blk * per_blk) * 16;  // byte offset in the block's stream
+  int u = 0;
+#pragma unroll 1
+  while (u + 1 < NUNITS && c >= unit_off(u + 1)) ++u;
+  const int K = unit_conv(u), S = u - unit_first(K), NK = conv_n(K);
+  c -= unit_off(u);
+  const int t = c / (NK * 64);
+  c -= t * NK * 64;
+  const int n = c / 64, js = (c & 63) >> 4;
+  const int j = js ^ ((n >> 2) & 3);  // logical quad stored in this position
+  const int cin0 = (S < 2 ? 32 * S : 64 + 32 * (S - 2)) + 8 * j;
+  const float* wk = wtab[blk * 5 + (K - 1)] + ((size_t)n * conv_cin(K) + cin0) * 9 + t;
+  bf16x8 pk;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pk[e] = (__bf16)wk[e * 9];
+  *reinterpret_cast<bf16x8*>(dst + gid * 16) = pk;
+}
+
+}  // namespace
+
+extern "C" size_t srx_rdb_packed_bytes(void) { return (size_t)PACKED_BYTES; }
+
+extern "C" int srx_rdb_pack(const float* const* w_table_dev, int nblk, void* dst, void* stream) {
+  SRX_REQUIRE(w_table_dev && dst && nblk > 0 && nblk <= 4096, "rdb_pack: bad argument");
+  const int64_t n = (int64_t)nblk * (PACKED_BYTES / 16);
+  hipLaunchKernelGGL(rdb_pack_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, srx_stream(stream), w_table_dev,
+                     reinterpret_cast<unsigned char*>(dst), nblk);
+  SRX_CHECK_LAUNCH("rdb_pack_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_rdb_fwd(int N, int H, int W, float* buf, int ld, const void* wpk, const float* const* bias5, float scale,
+                           float slope, float* out, int out_ld, void* stream) {
+  SRX_REQUIRE(buf && wpk && bias5 && out, "rdb_fwd: null pointer");
+  SRX_REQUIRE(N > 0 && H > 0 && W > 0 && ld >= 192 && ld % 4 == 0 && out_ld >= 64 && out_ld % 4 == 0,
+              "rdb_fwd: the block buffer needs >= 192 channels per pixel (x, c1..c4), the output >= 64, in whole quads");
+  SRX_REQUIRE((int64_t)N * H * W < (1 << 24) && (int64_t)N * H * W * ld < (1LL << 40), "rdb_fwd: more than 2^24 pixels; tile the image");
+  RdbArgs a{};
+  a.buf = buf; a.wpk = reinterpret_cast<const unsigned char*>(wpk); a.out = out;
+  for (int k = 0; k < 5; ++k) {
+    SRX_REQUIRE(bias5[k], "rdb_fwd: null bias %d", k);
+    a.bias[k] = bias5[k];
+  }
+  a.N = N; a.H = H; a.W = W; a.ld = ld; a.out_ld = out_ld;
+  a.tiles_x = (int)srx_cdiv(W, RT); a.tiles_y = (int)srx_cdiv(H, RT);
+  a.scale = scale; a.slope = slope;
+  const int64_t grid = (int64_t)N * a.tiles_x * a.tiles_y;
+  SRX_REQUIRE(grid < (1LL << 31), "rdb_fwd: grid too large");
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rdb_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+  });
+  // algorithmic FLOPs: the five convs on the tile pixels (the halo recompute is not counted)
+  const double fl = 2.0 * N * H * W * 9.0 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64);
+  char nm[112];
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "rdb_fwd_kernel MxNxK=%dx192x(576..1728)", N * H * W);
+  SRX_LAUNCH_PROF(nm, fl, rdb_fwd_kernel, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES, srx_stream(stream), a);
+  SRX_CHECK_LAUNCH("rdb_fwd_kernel");
+  return SRX_OK;
+}

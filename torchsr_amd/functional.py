@@ -1331,6 +1331,51 @@ def dense_block(x: Tensor, scale: float, convs) -> Tensor:
     return _DenseBlock.apply(x, scale, [c._st for c in convs], [c.weight for c in convs], *wb)
 
 
+class RDBPack:
+    """The bf16 weight streams of a chain of dense blocks for the one-launch forward (``srx_rdb_fwd``): one
+    ``srx_rdb_pack`` launch for all blocks, re-run when any weight changed (the same staleness key as ``ConvState.pack``)."""
+
+    def __init__(self):
+        self.buf = self.table = None
+        self._key = None
+        self.per_block = 0
+
+    def ensure(self, states, masters) -> None:
+        ws = [w for row in masters for w in row]
+        key = (ws[0].data_ptr(), len(ws), _pack_epoch[0], states[0][0].model_epoch[0], sum(w._version for w in ws))
+        if key == self._key:
+            return
+        dev = ws[0].device
+        if self.table is None or self.table.numel() != len(ws) or self.table.device != dev:
+            self.per_block = int(_lib.lib().srx_rdb_packed_bytes())
+            self.table = torch.tensor([w.data_ptr() for w in ws], dtype=torch.int64).to(dev)
+            self.buf = torch.empty(len(states) * self.per_block, dtype=torch.uint8, device=dev)
+            self._ptrs = [w.data_ptr() for w in ws]
+        elif self._ptrs != [w.data_ptr() for w in ws]:
+            self.table.copy_(torch.tensor([w.data_ptr() for w in ws], dtype=torch.int64))
+            self._ptrs = [w.data_ptr() for w in ws]
+        call('srx_rdb_pack', _p(self.table), len(states), _p(self.buf), _stream())
+        self._key = key
+
+    def block_ptr(self, i: int) -> int:
+        return self.buf.data_ptr() + i * self.per_block
+
+
+def rdb_fused_ok(states, wb_row, c0: int) -> bool:
+    """The one-launch dense block applies to the reference's geometry (64 + 4 x 32 channels, 3x3 / stride 1 / pad 1,
+    LeakyReLU on conv1..4, biases) with bf16 products; ``SRX_NO_RDB_FUSED=1`` keeps the per-conv launches (A/B runs)."""
+    import os
+    if os.environ.get('SRX_NO_RDB_FUSED') == '1' or c0 != 64 or len(states) != 5:
+        return False
+    for k, st in enumerate(states):
+        if (st.precision != 1 or st.k != 3 or st.stride != 1 or st.pad != 1 or st.shuffle or st.up or st.cin != 64 + 32 * k
+                or st.cout != (64 if k == 4 else 32) or st.act != (ACT_NONE if k == 4 else ACT_LRELU)):
+            return False
+        if k < 4 and st.slope != states[0].slope:
+            return False
+    return all(wb_row[2 * k + 1] is not None for k in range(5))
+
+
 class _RRDBTrunk(Function):
     """ESRGAN's chain of residual-in-residual dense blocks (esrgan/generator.py:54-56,70; esrgan/residual.py:81-86,
     125-128) as ONE autograd node, so that nothing but convolutions touches the activations.
@@ -1352,7 +1397,7 @@ class _RRDBTrunk(Function):
     """
 
     @staticmethod
-    def forward(ctx, x: Tensor, rdb_scales, rrdb_scale: float, states, masters, *wb):
+    def forward(ctx, x: Tensor, rdb_scales, rrdb_scale: float, states, masters, pack, *wb):
         ctx.set_materialize_grads(False)
         x = _chk(x, 'rrdb_trunk.input')
         n, h, w, c0 = x.shape
@@ -1369,6 +1414,11 @@ class _RRDBTrunk(Function):
         call('srx_copy_channels', _p(x), c0, 0, _p(bufs[0]), total, 0, c0, m, 0, s)
         descs = []
         y = None
+        # bf16 products: a whole dense block is ONE launch (srx_rdb_fwd: the five convs on 8x8 pixel tiles with the
+        # intermediates resident in LDS); exact fp32 keeps one launch per conv
+        fused = pack is not None and all(rdb_fused_ok(states[i], wb[10 * i:10 * i + 10], c0) for i in range(nb))
+        if fused:
+            pack.ensure(states, masters)
         for i in range(nb):
             buf, nxt = bufs[i], bufs[i + 1]
             row = []
@@ -1379,7 +1429,9 @@ class _RRDBTrunk(Function):
                                st.precision)
                 row.append(d)
                 dref = C.byref(d)
-                st.pack(masters[i][k], d)
+                st.pack(masters[i][k], d)  # (the backward pass reads the packed data-gradient copy either way)
+                if fused:
+                    continue
                 bias = wb[10 * i + 2 * k + 1]
                 bp = None if bias is None else _p(_chk(bias.detach(), 'rrdb_trunk.bias'))
                 nws = L.srx_conv2d_fwd_ws_floats(dref)
@@ -1389,6 +1441,10 @@ class _RRDBTrunk(Function):
                          _p(ws), nws, s)
                 else:
                     call('srx_conv2d_fwd', dref, _p(buf), _p(st.wpk_fwd), bp, buf.data_ptr() + 4 * cin, None, _p(ws), nws, s)
+            if fused:
+                biases = (C.c_void_p * 5)(*[_p(_chk(wb[10 * i + 2 * k + 1].detach(), 'rrdb_trunk.bias')) for k in range(5)])
+                call('srx_rdb_fwd', n, h, w, _p(buf), total, pack.block_ptr(i), biases, float(rdb_scales[i]),
+                     float(states[i][0].slope), _p(nxt), total, s)
             descs.append(row)
             if i % 3 == 2:  # end of an RRDB: out * 0.2 + x, x = the input of its first dense block (:128)
                 first = bufs[i - 2]
@@ -1442,7 +1498,7 @@ class _RRDBTrunk(Function):
             wsinks = [_sink(ctx.params[10 * i + 2 * k]) for k in range(4)]
             bsinks = [_sink(ctx.params[10 * i + 2 * k + 1]) for k in range(4)]
             paired = (queue is not None and all(v is not None for v in wsinks) and all(v is not None for v in bsinks)
-                      and all(ctx.needs_input_grad[5 + 10 * i + kk] for kk in range(8)))
+                      and all(ctx.needs_input_grad[6 + 10 * i + kk] for kk in range(8)))
             if paired:
                 for lo in (0, 2):
                     st = ctx.states[i][lo + 1]
@@ -1463,12 +1519,12 @@ class _RRDBTrunk(Function):
                 wparam, bparam = ctx.params[10 * i + 2 * k], ctx.params[10 * i + 2 * k + 1]
                 if paired and k < 4:
                     pass  # (queued above: the queue runs after the whole backward pass, when every slice of gbuf is complete)
-                elif ctx.needs_input_grad[5 + 10 * i + 2 * k]:
+                elif ctx.needs_input_grad[6 + 10 * i + 2 * k]:
                     sink = _sink(wparam)
                     dw = None if sink is not None else torch.empty((st.cout, st.cin, st.k, st.k), dtype=torch.float32,
                                                                      device=dev)
                     bptr = None
-                    if bparam is not None and ctx.needs_input_grad[6 + 10 * i + 2 * k]:
+                    if bparam is not None and ctx.needs_input_grad[7 + 10 * i + 2 * k]:
                         bsink = _sink(bparam)
                         if (bsink is None) != (sink is None):
                             raise RuntimeError('rrdb_trunk: weight and bias of a conv must both (or neither) have a gradient sink')
@@ -1484,7 +1540,7 @@ class _RRDBTrunk(Function):
                              one(_p(dw if sink is None else sink)), 0 if sink is None else 1, one(bptr),
                              (C.c_float * 1)(wscale), _p(_ws(nws, grad)), nws, s)
                     grads[10 * i + 2 * k] = dw
-                elif bparam is not None and ctx.needs_input_grad[6 + 10 * i + 2 * k]:
+                elif bparam is not None and ctx.needs_input_grad[7 + 10 * i + 2 * k]:
                     raise RuntimeError('rrdb_trunk: a bias gradient without its weight gradient is not implemented')
                 e = _lib.DgradEpilogue()
                 if k > 0:  # LeakyReLU backward of conv k on the slice this call completes (esrgan/residual.py:81-84)
@@ -1506,7 +1562,7 @@ class _RRDBTrunk(Function):
                 ws = _ws(nws, grad) if nws else None
                 call('srx_conv2d_bwd_data_ex', ddref, gk, _p(st.wpk_bwd), _p(out), C.byref(e), _p(ws), nws, s)
             grad = dx
-        return (grad, None, None, None, None, *grads)
+        return (grad, None, None, None, None, None, *grads)
 
 
 def rrdb_trunk(x: Tensor, rrdbs) -> Tensor:
@@ -1523,7 +1579,10 @@ def rrdb_trunk(x: Tensor, rrdbs) -> Tensor:
             scales.append(rdb.scale_ratio)
             for c in convs:
                 wb += [_w(c.weight), _w(c.bias)]
-    return _RRDBTrunk.apply(x, scales, 0.2, states, masters, *wb)
+    pack = rrdbs[0].__dict__.get('_rdb_pack')
+    if pack is None:
+        pack = rrdbs[0].__dict__.setdefault('_rdb_pack', RDBPack())
+    return _RRDBTrunk.apply(x, scales, 0.2, states, masters, pack, *wb)
 
 
 class _Upsample2x(Function):
