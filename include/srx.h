@@ -250,6 +250,19 @@ size_t srx_rdb_packed_bytes(void);
 int srx_rdb_pack(const float* const* w_table_dev, int nblk, void* dst, void* stream);
 int srx_rdb_fwd(int N, int H, int W, float* buf, int ld, const void* wpk, const float* const* bias5, float scale,
                 float slope, float* out, int out_ld, void* stream);
+/* The block's data-gradient chain (autograd of the five convs and four LeakyReLUs of esrgan/residual.py:81-86 with
+ * respect to their inputs) as ONE launch, the forward's schedule run in reverse:
+ *   g5 = scale * dy;  g_j = LeakyReLU'(c_j) * sum_{k > j} conv_k^T(g_k)[c_j], j = 4..1;  dx = sum_k conv_k^T(g_k)[x] + skip_scale * skip
+ * dy: [N][H][W][dy_ld] (the gradient of the block's output; `scale` = the block's scale_ratio times whatever factor the
+ * caller's chain rule has collected); buf: the block's saved buffer (x, c1..c4, ld >= 192: read for the masks);
+ * gbuf: [N][H][W][gld >= 192], receives g1..g4 (fp32) at channels 64..191 -- the output gradients the convs' weight
+ * gradients are computed from (srx_conv2d_bwd_weight_multi_pair / _scaled; conv5's is dy); skip: [N][H][W][skip_ld]: the
+ * gradient that reaches x around the convs (`+ x` of :86); dx: [N][H][W][dx_ld] channels 0..63, must not alias dy / skip.
+ * wpk_bwd: this block's stream written by srx_rdb_pack_bwd (transposed, tap-flipped; same size as the forward's). */
+int srx_rdb_pack_bwd(const float* const* w_table_dev, int nblk, void* dst, void* stream);
+int srx_rdb_bwd(int N, int H, int W, const float* dy, int dy_ld, float scale, const float* buf, int ld, const void* wpk_bwd,
+                float slope, float* gbuf, int gld, const float* skip, int skip_ld, float skip_scale, float* dx, int dx_ld,
+                void* stream);
 /* Per-step scalars without a per-step device->host sync: append n <= 4 device scalars (*a, *b, *c, *d) as one
  * 4-float record to ring[(*counter % cap) * 4 ...] and increment *counter (device int32).  The launch is the same every
  * step, so it sits inside the replayed hipGraph; the host reads `cap` records back in one copy.  Replaces the

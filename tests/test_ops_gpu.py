@@ -863,3 +863,51 @@ def test_fused_dense_block_forward(dev, n, h, w):
     got_y = out[..., :64].permute(0, 3, 1, 2).cpu().double()
     assert ((got_y - y).abs().max() / y.abs().max()).item() < 2e-5
     assert torch.isnan(out[..., 64:]).all() and torch.equal(buf[..., :64].cpu(), x.permute(0, 2, 3, 1))  # nothing else touched
+
+
+@pytest.mark.parametrize('n,h,w', [(2, 16, 16), (1, 13, 21), (1, 5, 40)])
+def test_fused_dense_block_backward(dev, n, h, w):
+    """``srx_rdb_bwd`` (the data-gradient chain of a dense block in one launch, bf16 products) against fp64: the slice
+    gradients g4..g1 and the input gradient, stage by stage on the device's own earlier stages (see
+    test_fused_dense_block_forward for why), whole / ragged / narrow tiles, through the C ABI."""
+    import torch.nn.functional as TF
+    from torchsr_amd import _lib
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(77 * h + w)
+    r16 = lambda t: t.to(torch.bfloat16).double()  # noqa: E731
+    ws = [torch.randn(32 if k < 4 else 64, 64 + 32 * k, 3, 3, generator=g) * (2.0 / (9 * (64 + 32 * k))) ** 0.5 for k in range(5)]
+    acts = torch.randn(n, 192, h, w, generator=g)          # x, c1..c4 as the forward left them (only the signs of c matter)
+    dy = torch.randn(n, 64, h, w, generator=g)
+    skip = torch.randn(n, 64, h, w, generator=g)
+    scale, slope, skip_scale = 0.2 * 0.7, 0.2, 0.9
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)  # noqa: E731
+    wd = [t.to(dev).contiguous() for t in ws]
+    table = torch.tensor([t.data_ptr() for t in wd], dtype=torch.int64).to(dev)
+    pk = torch.empty(L.srx_rdb_packed_bytes(), dtype=torch.uint8, device=dev)
+    _lib.call('srx_rdb_pack_bwd', table.data_ptr(), 1, pk.data_ptr(), s)
+    buf, dyd, skd = nhwc(acts), nhwc(dy), nhwc(skip)
+    gbuf = torch.full((n, h, w, 192), float('nan'), device=dev)
+    dx = torch.full((n, h, w, 64), float('nan'), device=dev)
+    _lib.call('srx_rdb_bwd', n, h, w, dyd.data_ptr(), 64, scale, buf.data_ptr(), 192, pk.data_ptr(), slope, gbuf.data_ptr(), 192,
+              skd.data_ptr(), 64, skip_scale, dx.data_ptr(), 64, s)
+    torch.cuda.synchronize()
+    assert torch.isnan(gbuf[..., :64]).all() and torch.isfinite(gbuf[..., 64:]).all() and torch.isfinite(dx).all()
+    got_g = gbuf[..., 64:].permute(0, 3, 1, 2).cpu()       # g1..g4
+    gs = {5: (dy * scale)}                                  # conv k's output gradient, fp32 as stored
+    rel = lambda a, b: ((a.double() - b).abs().max() / b.abs().max()).item()  # noqa: E731
+
+    def share(k, lo, hi):  # conv_k^T(bf16(g_k))[input channels lo:hi] with bf16 weights
+        full = torch.nn.grad.conv2d_input((n, 64 + 32 * (k - 1), h, w), r16(ws[k - 1]), r16(gs[k]), padding=1)
+        return full[:, lo:hi]
+
+    for j in (4, 3, 2, 1):
+        lo = 64 + 32 * (j - 1)
+        a = sum(share(k, lo, lo + 32) for k in range(j + 1, 6))
+        c = acts[:, lo:lo + 32].double()
+        want = torch.where(c > 0, a, a * slope)
+        got = got_g[:, 32 * (j - 1):32 * j]
+        assert rel(got, want) < 2e-5, (j, rel(got, want))
+        gs[j] = got
+    want_dx = sum(share(k, 0, 64) for k in range(1, 6)) + skip_scale * skip.double()
+    assert rel(dx.permute(0, 3, 1, 2).cpu(), want_dx) < 2e-5

@@ -66,13 +66,25 @@ constexpr int OFF_BIAS = OFF_W + 2 * SLOT_BYTES;
 constexpr int LDS_BYTES = OFF_BIAS + 192 * 4;   // 160512
 constexpr int NTHREADS = 512;
 
+// Forward (BWD = false): src = buf (x in channels 0..63, row stride ld), the stage outputs c1..c4 go to buf channels 64..191,
+// the last stage writes (conv5 + b5) * scale + x to out.
+// Backward (BWD = true), the data-gradient chain of the same block -- structurally the same computation run in reverse:
+//   g5 = scale * dy (64 channels: the "input patch"),  g_j = LeakyReLU'(c_j) * sum_{k > j} conv_k^T(g_k)[c_j]  (j = 4..1, 32 channels,
+//   regions 16x16 .. 10x10),  dx = sum_k conv_k^T(g_k)[x] + skip_scale * skip  (64 channels, the tile).
+// Stage K (1..5) has the K + 1 sources g5[0:32], g5[32:64], g4, .., g_{6-K} and produces the slice of c_{5-K} (K < 5) or of
+// x (K = 5): the forward's schedule with transposed, tap-flipped weights (srx_rdb_pack, bwd stream).  src = dy (row stride
+// ld), buf = the block's saved activations (the masks read c_j > 0), the stage outputs g4..g1 go to gout channels
+// 64+32(j-1).. (fp32: the weight gradients read them), the last stage writes dx to out.
 struct RdbArgs {
-  float* buf;            // [N][H][W][ld]: x in channels 0..63; c1..c4 are written to channels 64..191
+  const float* src;      // forward: the block buffer (x); backward: dy
+  float* buf;            // [N][H][W][bld]: forward: c1..c4 are written to channels 64..191; backward: read for the masks
+  float* gout;           // backward: [N][H][W][gld], g1..g4 at channels 64..191
+  const float* skip;     // backward: [N][H][W][skip_ld], added to dx with skip_scale
   const unsigned char* wpk;
-  const float* bias[5];
+  const float* bias[5];  // forward only
   float* out;            // [N][H][W][out_ld], channels 0..63
-  int N, H, W, ld, out_ld, tiles_x, tiles_y;
-  float scale, slope;
+  int N, H, W, ld, bld, gld, skip_ld, out_ld, tiles_x, tiles_y;
+  float scale, slope, skip_scale;
 };
 
 // Roles.  Waves 0..3 (one per SIMD) multiply: a wave owns up to two 32-pixel tiles of the current conv's region and reads
@@ -177,17 +189,21 @@ __device__ __forceinline__ void mma_unit(const unsigned char* lds, Wave& w) {
   }
 }
 
-// conv K < 5: bias + LeakyReLU; bf16 to the LDS image of c_K (zeros outside the image), fp32 to the block's buffer
+// stage K < 5.  Forward: bias + LeakyReLU; backward: the LeakyReLU mask of c_{5-K} (read from the saved buffer, halo pixels
+// included).  bf16 to the LDS image of source K + 1 (zeros outside the image), fp32 to the block's buffer / gradient buffer
 // (tile centre only: the halo belongs to the neighbouring workgroups)
-template <int K>
+template <int K, bool BWD>
 __device__ __forceinline__ void epilogue_mid(const RdbArgs& a, unsigned char* lds, Wave& w) {
   constexpr int WK = reg_w(K), RK = WK * WK, ORG = reg_org(K), TPW = tpw<K>();
+  constexpr int CH = BWD ? 64 + 32 * (4 - K) : 64 + 32 * (K - 1);  // channel slot of this stage's tensor in buf / gout
   int mt0, nt, cnt;
   job<K>(w.wave, mt0, nt, cnt);
-  const float* bias = reinterpret_cast<const float*>(lds + OFF_BIAS) + 32 * (K - 1);
   f32x4 b[4];
+  if constexpr (!BWD) {
+    const float* bias = reinterpret_cast<const float*>(lds + OFF_BIAS) + 32 * (K - 1);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(bias + 8 * g + 4 * w.h);
+    for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(bias + 8 * g + 4 * w.h);
+  }
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
     const int q = (mt0 + i) * 32 + w.l31;
@@ -197,16 +213,27 @@ __device__ __forceinline__ void epilogue_mid(const RdbArgs& a, unsigned char* ld
     const int iy = w.ty0 + oy, ix = w.tx0 + ox;
     const bool in_img = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     const bool centre = in_img && (unsigned)oy < (unsigned)RT && (unsigned)ox < (unsigned)RT;
-    float* gp = a.buf + ((size_t)(w.n_img * a.H + iy) * a.W + ix) * a.ld + 64 + 32 * (K - 1) + 4 * w.h;
+    const size_t pix = (size_t)(w.n_img * a.H + min(max(iy, 0), a.H - 1)) * a.W + min(max(ix, 0), a.W - 1);
+    float* gp = (BWD ? a.gout + pix * a.gld : a.buf + pix * a.bld) + CH + 4 * w.h;
     unsigned char* cp = lds + src_off(K + 1) + q * 64 + 8 * w.h;
     const int psw = (q >> 2) & 3;
+    f32x4 m[4];
+    if constexpr (BWD) {  // (clamped address: every lane loads, out-of-image lanes discard)
+      const float* mp = a.buf + pix * a.bld + CH + 4 * w.h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) m[g] = *reinterpret_cast<const f32x4*>(mp + 8 * g);
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float z = w.acc[i][4 * g + e] + b[g][e];
-        v[e] = z > 0.f ? z : z * a.slope;
+        if constexpr (BWD) {
+          v[e] = m[g][e] > 0.f ? w.acc[i][4 * g + e] : w.acc[i][4 * g + e] * a.slope;
+        } else {
+          const float z = w.acc[i][4 * g + e] + b[g][e];
+          v[e] = z > 0.f ? z : z * a.slope;
+        }
       }
       bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
       if (!in_img) pk = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
@@ -216,7 +243,8 @@ __device__ __forceinline__ void epilogue_mid(const RdbArgs& a, unsigned char* ld
   }
 }
 
-// conv 5: (acc + bias) * scale + x -> out
+// last stage.  Forward: (acc + bias) * scale + x -> out; backward: acc + skip_scale * skip -> out
+template <bool BWD>
 __device__ __forceinline__ void epilogue_out(const RdbArgs& a, const unsigned char* lds, Wave& w, const f32x4 (&xs)[4]) {
   int mt0, nt, cnt;
   job<5>(w.wave, mt0, nt, cnt);
@@ -230,27 +258,35 @@ __device__ __forceinline__ void epilogue_out(const RdbArgs& a, const unsigned ch
   float* op = a.out + pix * a.out_ld + 32 * nt + 4 * w.h;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 8 * g);
     f32x4 v;
+    if constexpr (BWD) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (w.acc[0][4 * g + e] + b[e]) * a.scale + xs[g][e];
+      for (int e = 0; e < 4; ++e) v[e] = w.acc[0][4 * g + e] + a.skip_scale * xs[g][e];
+    } else {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 8 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (w.acc[0][4 * g + e] + b[e]) * a.scale + xs[g][e];
+    }
     *reinterpret_cast<f32x4*>(op + 8 * g) = v;
   }
 }
 
-// the skip connection's fp32 x of this wave's conv-5 tile, requested a few units before it is needed
+// the last stage's fp32 addend (forward: the skip connection's x; backward: the gradient that bypasses the block) for
+// this wave's tile, requested a few units before it is needed
+template <bool BWD>
 __device__ __forceinline__ void load_skip(const RdbArgs& a, const Wave& w, f32x4 (&xs)[4]) {
   int mt0, nt, cnt;
   job<5>(w.wave, mt0, nt, cnt);
   const int q = mt0 * 32 + w.l31;
   const int qy = q / RT, qx = q - qy * RT;
   const int iy = min(w.ty0 + qy, a.H - 1), ix = min(w.tx0 + qx, a.W - 1);  // (clamped: stores are masked, loads are not)
-  const float* xp = a.buf + ((size_t)(w.n_img * a.H + iy) * a.W + ix) * a.ld + 32 * min(nt, 1) + 4 * w.h;
+  const size_t pix = (size_t)(w.n_img * a.H + iy) * a.W + ix;
+  const float* xp = (BWD ? a.skip + pix * a.skip_ld : a.src + pix * a.ld) + 32 * min(nt, 1) + 4 * w.h;
 #pragma unroll
   for (int g = 0; g < 4; ++g) xs[g] = *reinterpret_cast<const f32x4*>(xp + 8 * g);
 }
 
-template <int U>
+template <int U, bool BWD>
 __device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, Wave& w, int tid, f32x4 (&xs)[4]) {
   constexpr int K = unit_conv(U), S = U - unit_first(K);
   __syncthreads();  // unit U's weights (and, for S == 0, the previous conv's output image) are in LDS; slot (U+1)&1 is free
@@ -267,17 +303,18 @@ __device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) w.acc[i][r] = 0.f;
     }
-    if constexpr (U == unit_first(5)) load_skip(a, w, xs);
+    if constexpr (U == unit_first(5)) load_skip<BWD>(a, w, xs);
     mma_unit<K, S, U>(lds, w);
-    if constexpr (S == K) {  // last source of conv K
-      if constexpr (K < 5) epilogue_mid<K>(a, lds, w);
-      else epilogue_out(a, lds, w, xs);
+    if constexpr (S == K) {  // last source of stage K
+      if constexpr (K < 5) epilogue_mid<K, BWD>(a, lds, w);
+      else epilogue_out<BWD>(a, lds, w, xs);
     }
   }
-  if constexpr (U + 1 < NUNITS) run_units<U + 1>(a, lds, w, tid, xs);
+  if constexpr (U + 1 < NUNITS) run_units<U + 1, BWD>(a, lds, w, tid, xs);
 }
 
-__global__ __launch_bounds__(NTHREADS) void rdb_fwd_kernel(const RdbArgs a) {
+template <bool BWD>
+__global__ __launch_bounds__(NTHREADS) void rdb_kernel(const RdbArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   Wave w;
@@ -306,7 +343,7 @@ __global__ __launch_bounds__(NTHREADS) void rdb_fwd_kernel(const RdbArgs a) {
       const int iy = w.ty0 - 5 + py, ix = w.tx0 - 5 + px;
       ok[r] = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-      const float* xp = a.buf + ((size_t)(w.n_img * a.H + cy) * a.W + cx) * a.ld + 8 * g;
+      const float* xp = a.src + ((size_t)(w.n_img * a.H + cy) * a.W + cx) * a.ld + 8 * g;
       v[r][0] = *reinterpret_cast<const f32x4*>(xp);
       v[r][1] = *reinterpret_cast<const f32x4*>(xp + 4);
     }
@@ -317,21 +354,27 @@ __global__ __launch_bounds__(NTHREADS) void rdb_fwd_kernel(const RdbArgs a) {
       const int p = i >> 3, g = i & 7;
       f32x4 v0 = v[r][0], v1 = v[r][1];
       if (!ok[r]) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+      if constexpr (BWD) { v0 *= a.scale; v1 *= a.scale; }  // g5 = scale * dy, rounded after the product (as autograd hands it on)
       const bf16x8 pk = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3],
                          (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
       *reinterpret_cast<bf16x8*>(lds + (g >> 2) * (PW * PW * 64) + p * 64 + (((g & 3) ^ ((p >> 2) & 3)) << 4)) = pk;
     }
   }
-  if (tid < 192) {
-    const int k = tid < 128 ? tid >> 5 : 4;
-    reinterpret_cast<float*>(lds + OFF_BIAS)[tid] = a.bias[k][tid < 128 ? (tid & 31) : tid - 128];
+  if constexpr (!BWD) {
+    if (tid < 192) {
+      const int k = tid < 128 ? tid >> 5 : 4;
+      reinterpret_cast<float*>(lds + OFF_BIAS)[tid] = a.bias[k][tid < 128 ? (tid & 31) : tid - 128];
+    }
   }
   f32x4 xs[4];
-  run_units<0>(a, lds, w, tid, xs);
+  run_units<0, BWD>(a, lds, w, tid, xs);
 }
 
-// OIHW fp32 weights of every block's five convs -> the bf16 unit stream rdb_fwd_kernel reads (one thread per 16 bytes)
-__global__ void rdb_pack_kernel(const float* const* __restrict__ wtab, unsigned char* __restrict__ dst, int nblk) {
+// OIHW fp32 weights of every block's five convs -> the bf16 unit streams rdb_kernel reads (one thread per 16 bytes).
+// bwd = 0: stage K = conv K, rows = its output channels, k = the source's 32 input channels, taps as stored.
+// bwd = 1: stage K, source S: the conv is k = 5 (S < 2: its output channels 32 S ..) or 6 - S; rows = the INPUT channels of
+// that conv that make up the stage's slice (c_{5-K}, or x for K = 5), k = 32 of its output channels, taps flipped.
+__global__ void rdb_pack_kernel(const float* const* __restrict__ wtab, unsigned char* __restrict__ dst, int nblk, int bwd) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   constexpr int per_blk = PACKED_BYTES / 16;
   if (gid >= (int64_t)nblk * per_blk) return;
@@ -346,11 +389,20 @@ __global__ void rdb_pack_kernel(const float* const* __restrict__ wtab, unsigned 
   c -= t * NK * 64;
   const int n = c / 64, js = (c & 63) >> 4;
   const int j = js ^ ((n >> 2) & 3);  // logical quad stored in this position
-  const int cin0 = (S < 2 ? 32 * S : 64 + 32 * (S - 2)) + 8 * j;
-  const float* wk = wtab[blk * 5 + (K - 1)] + ((size_t)n * conv_cin(K) + cin0) * 9 + t;
   bf16x8 pk;
+  if (!bwd) {
+    const int cin0 = (S < 2 ? 32 * S : 64 + 32 * (S - 2)) + 8 * j;
+    const float* wk = wtab[blk * 5 + (K - 1)] + ((size_t)n * conv_cin(K) + cin0) * 9 + t;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) pk[e] = (__bf16)wk[e * 9];
+    for (int e = 0; e < 8; ++e) pk[e] = (__bf16)wk[e * 9];
+  } else {
+    const int k = S < 2 ? 5 : 6 - S;
+    const int co0 = (S < 2 ? 32 * S : 0) + 8 * j;
+    const int ci = (K < 5 ? 64 + 32 * (4 - K) : 0) + n;
+    const float* wk = wtab[blk * 5 + (k - 1)] + ((size_t)co0 * conv_cin(k) + ci) * 9 + (8 - t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pk[e] = (__bf16)wk[(size_t)e * conv_cin(k) * 9];
+  }
   *reinterpret_cast<bf16x8*>(dst + gid * 16) = pk;
 }
 
@@ -358,12 +410,37 @@ __global__ void rdb_pack_kernel(const float* const* __restrict__ wtab, unsigned 
 
 extern "C" size_t srx_rdb_packed_bytes(void) { return (size_t)PACKED_BYTES; }
 
-extern "C" int srx_rdb_pack(const float* const* w_table_dev, int nblk, void* dst, void* stream) {
+static int rdb_pack_impl(const float* const* w_table_dev, int nblk, void* dst, int bwd, void* stream) {
   SRX_REQUIRE(w_table_dev && dst && nblk > 0 && nblk <= 4096, "rdb_pack: bad argument");
   const int64_t n = (int64_t)nblk * (PACKED_BYTES / 16);
   hipLaunchKernelGGL(rdb_pack_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, srx_stream(stream), w_table_dev,
-                     reinterpret_cast<unsigned char*>(dst), nblk);
+                     reinterpret_cast<unsigned char*>(dst), nblk, bwd);
   SRX_CHECK_LAUNCH("rdb_pack_kernel");
+  return SRX_OK;
+}
+extern "C" int srx_rdb_pack(const float* const* w_table_dev, int nblk, void* dst, void* stream) {
+  return rdb_pack_impl(w_table_dev, nblk, dst, 0, stream);
+}
+extern "C" int srx_rdb_pack_bwd(const float* const* w_table_dev, int nblk, void* dst, void* stream) {
+  return rdb_pack_impl(w_table_dev, nblk, dst, 1, stream);
+}
+
+template <bool BWD>
+static int rdb_launch(RdbArgs& a, const char* what, void* stream) {
+  a.tiles_x = (int)srx_cdiv(a.W, RT); a.tiles_y = (int)srx_cdiv(a.H, RT);
+  const int64_t grid = (int64_t)a.N * a.tiles_x * a.tiles_y;
+  SRX_REQUIRE(grid < (1LL << 31), "%s: grid too large", what);
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rdb_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+  });
+  // algorithmic FLOPs: the five convs (or their data gradients) on the tile pixels; the halo recompute is not counted
+  const double fl = 2.0 * a.N * a.H * a.W * 9.0 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64);
+  char nm[112];
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "rdb_kernel<%d> MxNxK=%dx192x(576..1728)", BWD ? 1 : 0, a.N * a.H * a.W);
+  SRX_LAUNCH_PROF(nm, fl, rdb_kernel<BWD>, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES, srx_stream(stream), a);
+  SRX_CHECK_LAUNCH(what);
   return SRX_OK;
 }
 
@@ -374,26 +451,29 @@ extern "C" int srx_rdb_fwd(int N, int H, int W, float* buf, int ld, const void* 
               "rdb_fwd: the block buffer needs >= 192 channels per pixel (x, c1..c4), the output >= 64, in whole quads");
   SRX_REQUIRE((int64_t)N * H * W < (1 << 24) && (int64_t)N * H * W * ld < (1LL << 40), "rdb_fwd: more than 2^24 pixels; tile the image");
   RdbArgs a{};
-  a.buf = buf; a.wpk = reinterpret_cast<const unsigned char*>(wpk); a.out = out;
+  a.src = buf; a.buf = buf; a.wpk = reinterpret_cast<const unsigned char*>(wpk); a.out = out;
   for (int k = 0; k < 5; ++k) {
     SRX_REQUIRE(bias5[k], "rdb_fwd: null bias %d", k);
     a.bias[k] = bias5[k];
   }
-  a.N = N; a.H = H; a.W = W; a.ld = ld; a.out_ld = out_ld;
-  a.tiles_x = (int)srx_cdiv(W, RT); a.tiles_y = (int)srx_cdiv(H, RT);
+  a.N = N; a.H = H; a.W = W; a.ld = ld; a.bld = ld; a.out_ld = out_ld;
   a.scale = scale; a.slope = slope;
-  const int64_t grid = (int64_t)N * a.tiles_x * a.tiles_y;
-  SRX_REQUIRE(grid < (1LL << 31), "rdb_fwd: grid too large");
-  static std::once_flag once;
-  std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rdb_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-  });
-  // algorithmic FLOPs: the five convs on the tile pixels (the halo recompute is not counted)
-  const double fl = 2.0 * N * H * W * 9.0 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64);
-  char nm[112];
-  if (srx_prof_on()) snprintf(nm, sizeof(nm), "rdb_fwd_kernel MxNxK=%dx192x(576..1728)", N * H * W);
-  SRX_LAUNCH_PROF(nm, fl, rdb_fwd_kernel, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES, srx_stream(stream), a);
-  SRX_CHECK_LAUNCH("rdb_fwd_kernel");
-  return SRX_OK;
+  return rdb_launch<false>(a, "rdb_fwd", stream);
+}
+
+extern "C" int srx_rdb_bwd(int N, int H, int W, const float* dy, int dy_ld, float scale, const float* buf, int ld,
+                           const void* wpk_bwd, float slope, float* gbuf, int gld, const float* skip, int skip_ld,
+                           float skip_scale, float* dx, int dx_ld, void* stream) {
+  SRX_REQUIRE(dy && buf && wpk_bwd && gbuf && skip && dx, "rdb_bwd: null pointer");
+  SRX_REQUIRE(N > 0 && H > 0 && W > 0 && dy_ld >= 64 && dy_ld % 4 == 0 && ld >= 192 && ld % 4 == 0 && gld >= 192 && gld % 4 == 0 &&
+                  skip_ld >= 64 && skip_ld % 4 == 0 && dx_ld >= 64 && dx_ld % 4 == 0,
+              "rdb_bwd: dy / skip / dx need >= 64 channels per pixel, the activation and gradient buffers >= 192, in whole quads");
+  SRX_REQUIRE(dx != dy && dx != skip && (const float*)gbuf != buf, "rdb_bwd: dx must not alias dy or skip (neighbouring tiles read their halo)");
+  SRX_REQUIRE((int64_t)N * H * W < (1 << 24), "rdb_bwd: more than 2^24 pixels; tile the image");
+  RdbArgs a{};
+  a.src = dy; a.buf = const_cast<float*>(buf); a.gout = gbuf; a.skip = skip; a.out = dx;
+  a.wpk = reinterpret_cast<const unsigned char*>(wpk_bwd);
+  a.N = N; a.H = H; a.W = W; a.ld = dy_ld; a.bld = ld; a.gld = gld; a.skip_ld = skip_ld; a.out_ld = dx_ld;
+  a.scale = scale; a.slope = slope; a.skip_scale = skip_scale;
+  return rdb_launch<true>(a, "rdb_bwd", stream);
 }

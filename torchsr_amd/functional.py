@@ -1336,14 +1336,15 @@ class RDBPack:
     ``srx_rdb_pack`` launch for all blocks, re-run when any weight changed (the same staleness key as ``ConvState.pack``)."""
 
     def __init__(self):
-        self.buf = self.table = None
+        self.buf = self.buf_bwd = self.table = None
         self._key = None
+        self._has_bwd = False
         self.per_block = 0
 
-    def ensure(self, states, masters) -> None:
+    def ensure(self, states, masters, need_bwd: bool = False) -> None:
         ws = [w for row in masters for w in row]
         key = (ws[0].data_ptr(), len(ws), _pack_epoch[0], states[0][0].model_epoch[0], sum(w._version for w in ws))
-        if key == self._key:
+        if key == self._key and (self._has_bwd or not need_bwd):
             return
         dev = ws[0].device
         if self.table is None or self.table.numel() != len(ws) or self.table.device != dev:
@@ -1355,10 +1356,18 @@ class RDBPack:
             self.table.copy_(torch.tensor([w.data_ptr() for w in ws], dtype=torch.int64))
             self._ptrs = [w.data_ptr() for w in ws]
         call('srx_rdb_pack', _p(self.table), len(states), _p(self.buf), _stream())
+        self._has_bwd = bool(need_bwd)
+        if need_bwd:  # the transposed, tap-flipped streams of the data-gradient chain (srx_rdb_bwd)
+            if self.buf_bwd is None or self.buf_bwd.numel() != self.buf.numel() or self.buf_bwd.device != dev:
+                self.buf_bwd = torch.empty_like(self.buf)
+            call('srx_rdb_pack_bwd', _p(self.table), len(states), _p(self.buf_bwd), _stream())
         self._key = key
 
     def block_ptr(self, i: int) -> int:
         return self.buf.data_ptr() + i * self.per_block
+
+    def bwd_ptr(self, i: int) -> int:
+        return self.buf_bwd.data_ptr() + i * self.per_block
 
 
 def rdb_fused_ok(states, wb_row, c0: int) -> bool:
@@ -1418,7 +1427,7 @@ class _RRDBTrunk(Function):
         # intermediates resident in LDS); exact fp32 keeps one launch per conv
         fused = pack is not None and all(rdb_fused_ok(states[i], wb[10 * i:10 * i + 10], c0) for i in range(nb))
         if fused:
-            pack.ensure(states, masters)
+            pack.ensure(states, masters, need_bwd)
         for i in range(nb):
             buf, nxt = bufs[i], bufs[i + 1]
             row = []
@@ -1456,6 +1465,7 @@ class _RRDBTrunk(Function):
                     call('srx_axpby_channels', _p(nxt), total, 0, _p(first), total, 0, _p(nxt), total, 0, c0, m,
                          float(rrdb_scale), 1.0, s)
         ctx.states, ctx.descs = states, descs
+        ctx.pack = pack if fused else None
         ctx.scales = ([float(v) for v in rdb_scales], float(rrdb_scale))
         ctx.dims = (n, h, w, c0, g, total, m, nb)
         ctx.params = wb
@@ -1492,6 +1502,11 @@ class _RRDBTrunk(Function):
                 call('srx_axpby', _p(grad), _p(rrdb_grad), _p(skip), grad.numel(), eff, 1.0, s)
                 skip_scale = 1.0
             dx = torch.empty((n, h, w, c0), dtype=torch.float32, device=dev)
+            if ctx.pack is not None:
+                # bf16 products: the whole data-gradient chain of the block in one launch (srx_rdb_bwd): g5 = eff * scale * dy,
+                # the masked slice gradients g4..g1 (what the weight gradients below read) into gbuf, dx = the x share + skip
+                call('srx_rdb_bwd', n, h, w, _p(grad), c0, float(eff * rdb_scales[i]), _p(buf), total, ctx.pack.bwd_ptr(i),
+                     float(ctx.states[i][0].slope), _p(gbuf), total, _p(skip), c0, float(skip_scale), _p(dx), c0, s)
             keep = (buf, gbuf, grad)
             # conv1 + conv2 and conv3 + conv4 read the same buffer and their output gradients are adjacent slices of gbuf:
             # queued as two 64-column weight-gradient problems instead of four 32-column ones (half a tile of padding each)
@@ -1542,6 +1557,8 @@ class _RRDBTrunk(Function):
                     grads[10 * i + 2 * k] = dw
                 elif bparam is not None and ctx.needs_input_grad[7 + 10 * i + 2 * k]:
                     raise RuntimeError('rrdb_trunk: a bias gradient without its weight gradient is not implemented')
+                if ctx.pack is not None:
+                    continue  # (the block's five data gradients are one launch, below)
                 e = _lib.DgradEpilogue()
                 if k > 0:  # LeakyReLU backward of conv k on the slice this call completes (esrgan/residual.py:81-84)
                     e.act_out, e.act_slope, e.c_lo, e.c_hi = _p(buf), ctx.states[i][k - 1].slope, cin - g, cin

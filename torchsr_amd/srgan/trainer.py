@@ -298,9 +298,10 @@ class SRGANTrainer:
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
         g = torch.cuda.CUDAGraph()
-        # with a process group alive, RCCL's watchdog thread may query events while we capture; only
-        # the capturing thread's own calls should be policed then
-        mode = 'thread_local' if self.distributed else 'global'
+        # with a process group alive (whether or not THIS trainer exchanges gradients), RCCL's watchdog thread queries its
+        # events while we capture: under a 'global' capture HIP fails that query ("operation not permitted when stream is
+        # capturing") and the watchdog aborts the process; only the capturing thread's own calls are policed then
+        mode = 'thread_local' if (self.distributed or dist.is_initialized()) else 'global'
         cut_state = {k: list(v) for k, v in self._cuts.pairs.items()} if self._cuts is not None else None
         try:
             with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=mode):
