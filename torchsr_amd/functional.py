@@ -241,6 +241,7 @@ class ConvState:
         self.wpk_fwd = None
         self.wpk_bwd = None
         self._key = None
+        self.fused_only = False  # set while the layer runs inside a fused multi-conv kernel that has its own weight stream
 
     def desc(self, n, h, w) -> Conv2dDesc:
         d = self._descs.get((n, h, w, self.precision))
@@ -308,7 +309,8 @@ class PackTable:
         self.nrec, self.maxn = 0, 0
 
     def _build(self) -> bool:
-        items = [(c._st, c.weight) for c in self.convs if c.weight.requires_grad]
+        # (convs whose packed fp32 copies nothing reads -- dense blocks running as fused bf16 launches, RDBPack -- are left out)
+        items = [(c._st, c.weight) for c in self.convs if c.weight.requires_grad and not c._st.fused_only]
         if not items or any(st.wpk_fwd is None or getattr(st, 'last_desc', None) is None for st, _ in items):
             return False
         n = len(items)
@@ -1438,9 +1440,10 @@ class _RRDBTrunk(Function):
                                st.precision)
                 row.append(d)
                 dref = C.byref(d)
-                st.pack(masters[i][k], d)  # (the backward pass reads the packed data-gradient copy either way)
+                st.fused_only = fused  # fused: forward and data gradients read RDBPack's bf16 streams, nothing reads wpk_*
                 if fused:
                     continue
+                st.pack(masters[i][k], d)
                 bias = wb[10 * i + 2 * k + 1]
                 bp = None if bias is None else _p(_chk(bias.detach(), 'rrdb_trunk.bias'))
                 nws = L.srx_conv2d_fwd_ws_floats(dref)
