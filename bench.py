@@ -19,9 +19,17 @@ Rank 0 prints ONE JSON line.  At N = 1 it also carries
                   instrumented eager pass of the same step: algorithmic FLOPs of its launches / their
                   event-measured duration, against the 157.3 TFLOP/s fp32 MFMA peak of MI355X; ``by_shape``
                   lists the layer shapes it serves, ``traffic`` = HBM bytes per launch of the heaviest one from
-                  the committed rocprofv3 --pmc passes (profiles/r02_traffic.json; null if not profiled);
+                  the committed rocprofv3 --pmc passes (profiles/r03_traffic.json; null if not profiled);
                   ``north_star`` = the 3x3 64->64 residual conv at 16x24x24 timed the way the step runs it,
                   as back-to-back launches inside a replayed hipGraph (HIP events on the replay stream);
+  "other_configs": BASELINE.json's other configurations timed on this GPU after the headline region: the SRResNet
+                  pre-training step (batch 2 = configs[0]'s shape, and batch 16), the ESRGAN GAN step (batch 16, 128x128, bf16
+                  products = configs[3]) and the 1080p -> 8K generator forward in fp32 and with bf16 products (configs[4]);
+                  each with its EXECUTED algorithmic GFLOP, the fraction of the matching MFMA peak and its dominant conv kernel;
+  "dp_rehearsal": the data-parallel form of the headline step (seven hipGraph segments, four gradient buckets all-reduced
+                  asynchronously) on a real RCCL process group at world size 1, in a child process, next to the single-graph
+                  step in the same process: what the segmentation costs on one GPU.  SRX_BENCH_FORCE_DIST=1 takes that path
+                  directly (also under `torchrun --nproc-per-node 1`).  Scaling to N > 1 is not measured by this file's author;
   "cpu_baseline": the CPU oracle (oracle/srgan.py, stock torch ops) running the identical step on the host
                   cores, BASELINE.md section 5 protocol (3 warm-up + 10 timed steps, median), plus the
                   config-1 leg (pre-training step, batch 2) -- a reported baseline, not the target.
@@ -235,7 +243,7 @@ def roofline_pass(trainer, lr, hr, reps=2):
              for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][0])}
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE: tools/pmc_run.sh) of
     # tools/pmc_workloads.py restricted to ONE layer shape; counters cannot be read from inside the process
-    tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r03_traffic.json')
     measured = json.load(open(tpath)) if os.path.exists(tpath) else {}
     shapes = []
     for full, v in sorted(pairs.items(), key=lambda kv: -kv[1][0]):

@@ -6,6 +6,8 @@
   wgrad33  : the grouped weight gradient of the generator's 33 residual convs (one launch per step)
   vgg256   : 3x3 256->256 at 32x24x24 -- the VGG19 block-3 layers with source and target as one batch
   vgg256h  : the same at 16x24x24 (its data gradient: source half only)
+  vgg512   : 3x3 512->512 at 32x12x12 (VGG19 block 4, M 4608 N 512 K 4608);  vgg512h: at 16x12x12 (M 2304)
+  vgg128   : 3x3 64->128 at 32x48x48 (VGG19 block 2's first layer, M 73728 N 128 K 576)
 """
 import ctypes as C
 import os
@@ -21,8 +23,10 @@ dev = torch.device('cuda:0')
 name = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 torch.manual_seed(0)
-if name in ('rt36', 'vgg256', 'vgg256h'):
-    n, h, w, cin, cout = {'rt36': (16, 24, 24, 64, 64), 'vgg256': (32, 24, 24, 256, 256), 'vgg256h': (16, 24, 24, 256, 256)}[name]
+SHAPES = {'rt36': (16, 24, 24, 64, 64), 'vgg256': (32, 24, 24, 256, 256), 'vgg256h': (16, 24, 24, 256, 256),
+          'vgg512': (32, 12, 12, 512, 512), 'vgg512h': (16, 12, 12, 512, 512), 'vgg128': (32, 48, 48, 64, 128)}
+if name in SHAPES:
+    n, h, w, cin, cout = SHAPES[name]
     conv = Conv2d(cin, cout, 3, 1, 1, bias=False).to(dev)
     x = torch.rand(n, h, w, cin, device=dev)
     with torch.no_grad():
