@@ -73,6 +73,34 @@ def test_1080p_inference_windows_vs_oracle(dev):
         assert err <= 1e-4 * max(ref.abs().max().item(), 1e-3), (y0, x0, err)
 
 
+def test_esrgan_tiled_inference_border_error(dev):
+    """ESRGAN's receptive field (69 dense blocks of five 3x3 convs: ~350 low-resolution pixels) is larger than any halo a
+    tile can carry, so tiled ESRGAN inference is an approximation near tile borders (torchsr_amd/test.py).  This measures
+    it where the whole frame still fits one call: a 320x352 frame whole against tiles of ~128x190 pixels with the default
+    64-pixel halo, the full 23-RRDB generator, two weight scalings -- the reference's own initialisation (kaiming x 0.1,
+    esrgan/residual.py:58-63) and 2.5x that on every dense-block conv (a stand-in for trained weights: the blocks' branch
+    gain is then >6x larger).  The error must be confined to the halo's reach and small; the bound asserted here is the one
+    DESIGN.md states.  Exact results: pass ``max_tile_pixels`` large enough for the frame, or a larger ``halo``."""
+    from torchsr_amd.esrgan.generator import Generator
+    from torchsr_amd.test import upscale
+    torch.manual_seed(2)
+    gen = Generator().to(dev)
+    lr = torch.rand(1, 3, 320, 352, device=dev)
+    for boost, bound in ((1.0, 1e-5), (2.5, 1e-5)):  # measured: 1.8e-6 / 1.9e-6 (fp32 rounding of two evaluation orders)
+        with torch.no_grad():
+            for name, p in gen.named_parameters():
+                if 'RDB' in name and p.dim() == 4:
+                    p.mul_(boost if boost == 1.0 else 2.5)
+        whole = upscale(gen, lr, max_tile_pixels=10 ** 9)
+        tiled = upscale(gen, lr, max_tile_pixels=128 * 256)
+        wide = upscale(gen, lr, halo=128, max_tile_pixels=128 * 256)
+        top = whole.abs().max().item()
+        err, err_wide = (whole - tiled).abs().max().item() / top, (whole - wide).abs().max().item() / top
+        print(f'ESRGAN tiled vs whole frame, dense-block weights x{boost}: max error {err:.2e} of the output range with the '
+              f'64-pixel halo, {err_wide:.2e} with 128')
+        assert err <= bound and err_wide <= bound, (boost, err, err_wide)
+
+
 def _bn_folded_state(sd, eps=1e-5):
     """The same eval-mode generator with every BatchNorm folded into the conv before it -- ``w * g / sqrt(var + eps)``, the
     shift moved to the BatchNorm's bias, identity statistics left behind -- which is the operand the product rounds to
