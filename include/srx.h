@@ -248,8 +248,10 @@ size_t srx_rdb_packed_bytes(void);
 /* w_table_dev: DEVICE array of 5 * nblk pointers to the OIHW fp32 weights (conv1..conv5 of block 0, of block 1, ...);
  * dst: nblk * srx_rdb_packed_bytes() bytes.  One launch for all blocks (after an optimiser step). */
 int srx_rdb_pack(const float* const* w_table_dev, int nblk, void* dst, void* stream);
+/* extra (may be NULL): out = (that) * post_scale + extra -- the `out * 0.2 + x` that ends a ResidualInResidualDenseBlock
+ * (esrgan/residual.py:128) in the epilogue of its third dense block; [N][H][W][extra_ld], channels 0..63, not aliasing out */
 int srx_rdb_fwd(int N, int H, int W, float* buf, int ld, const void* wpk, const float* const* bias5, float scale,
-                float slope, float* out, int out_ld, void* stream);
+                float slope, float post_scale, const float* extra, int extra_ld, float* out, int out_ld, void* stream);
 /* The block's data-gradient chain (autograd of the five convs and four LeakyReLUs of esrgan/residual.py:81-86 with
  * respect to their inputs) as ONE launch, the forward's schedule run in reverse:
  *   g5 = scale * dy;  g_j = LeakyReLU'(c_j) * sum_{k > j} conv_k^T(g_k)[c_j], j = 4..1;  dx = sum_k conv_k^T(g_k)[x] + skip_scale * skip
@@ -260,9 +262,10 @@ int srx_rdb_fwd(int N, int H, int W, float* buf, int ld, const void* wpk, const 
  * gradient that reaches x around the convs (`+ x` of :86); dx: [N][H][W][dx_ld] channels 0..63, must not alias dy / skip.
  * wpk_bwd: this block's stream written by srx_rdb_pack_bwd (transposed, tap-flipped; same size as the forward's). */
 int srx_rdb_pack_bwd(const float* const* w_table_dev, int nblk, void* dst, void* stream);
+/* extra (may be NULL): a second gradient added to dx as it is (the RRDB's own skip connection reaching its first block) */
 int srx_rdb_bwd(int N, int H, int W, const float* dy, int dy_ld, float scale, const float* buf, int ld, const void* wpk_bwd,
-                float slope, float* gbuf, int gld, const float* skip, int skip_ld, float skip_scale, float* dx, int dx_ld,
-                void* stream);
+                float slope, float* gbuf, int gld, const float* skip, int skip_ld, float skip_scale, const float* extra,
+                int extra_ld, float* dx, int dx_ld, void* stream);
 /* Per-step scalars without a per-step device->host sync: append n <= 4 device scalars (*a, *b, *c, *d) as one
  * 4-float record to ring[(*counter % cap) * 4 ...] and increment *counter (device int32).  The launch is the same every
  * step, so it sits inside the replayed hipGraph; the host reads `cap` records back in one copy.  Replaces the

@@ -846,7 +846,10 @@ def test_fused_dense_block_forward(dev, n, h, w):
     buf[..., :64] = x.permute(0, 2, 3, 1).to(dev)
     out = torch.full((n, h, w, 192), float('nan'), device=dev)
     biases = (C.c_void_p * 5)(*[t.data_ptr() for t in bd])
-    _lib.call('srx_rdb_fwd', n, h, w, buf.data_ptr(), 192, pk.data_ptr(), biases, 0.2, 0.2, out.data_ptr(), 192, s)
+    extra = torch.randn(n, h, w, 64, generator=g) if h % 2 else None  # (ragged cases: with the RRDB-end addend, esrgan/residual.py:128)
+    exd = None if extra is None else extra.to(dev)
+    _lib.call('srx_rdb_fwd', n, h, w, buf.data_ptr(), 192, pk.data_ptr(), biases, 0.2, 0.2, 0.7, None if exd is None else exd.data_ptr(),
+              64, out.data_ptr(), 192, s)
     torch.cuda.synchronize()
     got_c = buf[..., 64:].permute(0, 3, 1, 2).cpu()
     assert torch.isfinite(got_c).all()
@@ -860,6 +863,8 @@ def test_fused_dense_block_forward(dev, n, h, w):
         assert ((got.double() - want).abs().max() / want.abs().max()).item() < 2e-5, (k, ((got - want).abs().max() / want.abs().max()).item())
         feats.append(got)
     y = TF.conv2d(r16(torch.cat(feats, 1)), r16(ws[4]), bs[4].double(), 1, 1) * 0.2 + x.double()
+    if extra is not None:
+        y = y * 0.7 + extra.permute(0, 3, 1, 2).double()
     got_y = out[..., :64].permute(0, 3, 1, 2).cpu().double()
     assert ((got_y - y).abs().max() / y.abs().max()).item() < 2e-5
     assert torch.isnan(out[..., 64:]).all() and torch.equal(buf[..., :64].cpu(), x.permute(0, 2, 3, 1))  # nothing else touched
@@ -887,10 +892,12 @@ def test_fused_dense_block_backward(dev, n, h, w):
     pk = torch.empty(L.srx_rdb_packed_bytes(), dtype=torch.uint8, device=dev)
     _lib.call('srx_rdb_pack_bwd', table.data_ptr(), 1, pk.data_ptr(), s)
     buf, dyd, skd = nhwc(acts), nhwc(dy), nhwc(skip)
+    extra = torch.randn(n, 64, h, w, generator=g) if h % 2 else None  # (the RRDB's own skip gradient on its first block)
+    exd = None if extra is None else nhwc(extra)
     gbuf = torch.full((n, h, w, 192), float('nan'), device=dev)
     dx = torch.full((n, h, w, 64), float('nan'), device=dev)
     _lib.call('srx_rdb_bwd', n, h, w, dyd.data_ptr(), 64, scale, buf.data_ptr(), 192, pk.data_ptr(), slope, gbuf.data_ptr(), 192,
-              skd.data_ptr(), 64, skip_scale, dx.data_ptr(), 64, s)
+              skd.data_ptr(), 64, skip_scale, None if exd is None else exd.data_ptr(), 64, dx.data_ptr(), 64, s)
     torch.cuda.synchronize()
     assert torch.isnan(gbuf[..., :64]).all() and torch.isfinite(gbuf[..., 64:]).all() and torch.isfinite(dx).all()
     got_g = gbuf[..., 64:].permute(0, 3, 1, 2).cpu()       # g1..g4
@@ -910,4 +917,6 @@ def test_fused_dense_block_backward(dev, n, h, w):
         assert rel(got, want) < 2e-5, (j, rel(got, want))
         gs[j] = got
     want_dx = sum(share(k, 0, 64) for k in range(1, 6)) + skip_scale * skip.double()
+    if extra is not None:
+        want_dx = want_dx + extra.double()
     assert rel(dx.permute(0, 3, 1, 2).cpu(), want_dx) < 2e-5

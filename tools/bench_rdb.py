@@ -25,7 +25,7 @@ biases = (C.c_void_p * 5)(*[t.data_ptr() for t in bs])
 def chain():
     s = torch.cuda.current_stream().cuda_stream  # (the capture stream inside torch.cuda.graph)
     for i in range(nb):
-        _lib.call('srx_rdb_fwd', n, h, w, bufs[i % 4].data_ptr(), 192, pk.data_ptr() + i * per, biases, 0.2, 0.2,
+        _lib.call('srx_rdb_fwd', n, h, w, bufs[i % 4].data_ptr(), 192, pk.data_ptr() + i * per, biases, 0.2, 0.2, 1.0, None, 0,
                   bufs[(i + 1) % 4].data_ptr(), 192, s)
 
 

@@ -95,8 +95,8 @@ _SIGS = {
     'srx_rdb_packed_bytes': (_Z, []),
     'srx_rdb_pack': (_I, [_P, _I, _P, _P]),
     'srx_rdb_pack_bwd': (_I, [_P, _I, _P, _P]),
-    'srx_rdb_bwd': (_I, [_I, _I, _I, _P, _I, _F, _P, _I, _P, _F, _P, _I, _P, _I, _F, _P, _I, _P]),
-    'srx_rdb_fwd': (_I, [_I, _I, _I, _P, _I, _P, _P, _F, _F, _P, _I, _P]),
+    'srx_rdb_bwd': (_I, [_I, _I, _I, _P, _I, _F, _P, _I, _P, _F, _P, _I, _P, _I, _F, _P, _I, _P, _I, _P]),
+    'srx_rdb_fwd': (_I, [_I, _I, _I, _P, _I, _P, _P, _F, _F, _F, _P, _I, _P, _I, _P]),
     'srx_colsum_ws_floats': (_Z, [_L, _I]),
     'srx_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     'srx_crop_flip_u8': (_I, [_P, _P, _P, _I, _I, _P]),

@@ -80,11 +80,14 @@ struct RdbArgs {
   float* buf;            // [N][H][W][bld]: forward: c1..c4 are written to channels 64..191; backward: read for the masks
   float* gout;           // backward: [N][H][W][gld], g1..g4 at channels 64..191
   const float* skip;     // backward: [N][H][W][skip_ld], added to dx with skip_scale
+  const float* extra;    // optional second addend of the last stage ([N][H][W][extra_ld], channels 0..63): forward
+                         //   out = ((conv5 + b5) * scale + x) * post_scale + extra  (the `out * 0.2 + x` that ends an RRDB,
+                         //   esrgan/residual.py:128); backward  dx = ... + skip_scale * skip + extra  (the RRDB's own skip gradient)
   const unsigned char* wpk;
   const float* bias[5];  // forward only
   float* out;            // [N][H][W][out_ld], channels 0..63
-  int N, H, W, ld, bld, gld, skip_ld, out_ld, tiles_x, tiles_y;
-  float scale, slope, skip_scale;
+  int N, H, W, ld, bld, gld, skip_ld, extra_ld, out_ld, tiles_x, tiles_y;
+  float scale, slope, skip_scale, post_scale;
 };
 
 // Roles.  Waves 0..3 (one per SIMD) multiply: a wave owns up to two 32-pixel tiles of the current conv's region and reads
@@ -245,7 +248,8 @@ __device__ __forceinline__ void epilogue_mid(const RdbArgs& a, unsigned char* ld
 
 // last stage.  Forward: (acc + bias) * scale + x -> out; backward: acc + skip_scale * skip -> out
 template <bool BWD>
-__device__ __forceinline__ void epilogue_out(const RdbArgs& a, const unsigned char* lds, Wave& w, const f32x4 (&xs)[4]) {
+__device__ __forceinline__ void epilogue_out(const RdbArgs& a, const unsigned char* lds, Wave& w, const f32x4 (&xs)[4],
+                                             const f32x4 (&ex)[4]) {
   int mt0, nt, cnt;
   job<5>(w.wave, mt0, nt, cnt);
   if (cnt == 0) return;
@@ -262,10 +266,12 @@ __device__ __forceinline__ void epilogue_out(const RdbArgs& a, const unsigned ch
     if constexpr (BWD) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = w.acc[0][4 * g + e] + a.skip_scale * xs[g][e];
+      if (a.extra) v += ex[g];
     } else {
       const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 8 * g);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = (w.acc[0][4 * g + e] + b[e]) * a.scale + xs[g][e];
+      if (a.extra) v = v * a.post_scale + ex[g];
     }
     *reinterpret_cast<f32x4*>(op + 8 * g) = v;
   }
@@ -274,7 +280,7 @@ __device__ __forceinline__ void epilogue_out(const RdbArgs& a, const unsigned ch
 // the last stage's fp32 addend (forward: the skip connection's x; backward: the gradient that bypasses the block) for
 // this wave's tile, requested a few units before it is needed
 template <bool BWD>
-__device__ __forceinline__ void load_skip(const RdbArgs& a, const Wave& w, f32x4 (&xs)[4]) {
+__device__ __forceinline__ void load_skip(const RdbArgs& a, const Wave& w, f32x4 (&xs)[4], f32x4 (&ex)[4]) {
   int mt0, nt, cnt;
   job<5>(w.wave, mt0, nt, cnt);
   const int q = mt0 * 32 + w.l31;
@@ -284,10 +290,16 @@ __device__ __forceinline__ void load_skip(const RdbArgs& a, const Wave& w, f32x4
   const float* xp = (BWD ? a.skip + pix * a.skip_ld : a.src + pix * a.ld) + 32 * min(nt, 1) + 4 * w.h;
 #pragma unroll
   for (int g = 0; g < 4; ++g) xs[g] = *reinterpret_cast<const f32x4*>(xp + 8 * g);
+  if (a.extra) {  // (workgroup-uniform)
+    const float* ep = a.extra + pix * a.extra_ld + 32 * min(nt, 1) + 4 * w.h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ex[g] = *reinterpret_cast<const f32x4*>(ep + 8 * g);
+  }
 }
 
 template <int U, bool BWD>
-__device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, Wave& w, int tid, f32x4 (&xs)[4]) {
+__device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, Wave& w, int tid, f32x4 (&xs)[4],
+                                          f32x4 (&ex)[4]) {
   constexpr int K = unit_conv(U), S = U - unit_first(K);
   __syncthreads();  // unit U's weights (and, for S == 0, the previous conv's output image) are in LDS; slot (U+1)&1 is free
   if (w.wave >= NCOMPUTE) {
@@ -303,14 +315,14 @@ __device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) w.acc[i][r] = 0.f;
     }
-    if constexpr (U == unit_first(5)) load_skip<BWD>(a, w, xs);
+    if constexpr (U == unit_first(5)) load_skip<BWD>(a, w, xs, ex);
     mma_unit<K, S, U>(lds, w);
     if constexpr (S == K) {  // last source of stage K
       if constexpr (K < 5) epilogue_mid<K, BWD>(a, lds, w);
-      else epilogue_out<BWD>(a, lds, w, xs);
+      else epilogue_out<BWD>(a, lds, w, xs, ex);
     }
   }
-  if constexpr (U + 1 < NUNITS) run_units<U + 1, BWD>(a, lds, w, tid, xs);
+  if constexpr (U + 1 < NUNITS) run_units<U + 1, BWD>(a, lds, w, tid, xs, ex);
 }
 
 template <bool BWD>
@@ -366,8 +378,8 @@ __global__ __launch_bounds__(NTHREADS) void rdb_kernel(const RdbArgs a) {
       reinterpret_cast<float*>(lds + OFF_BIAS)[tid] = a.bias[k][tid < 128 ? (tid & 31) : tid - 128];
     }
   }
-  f32x4 xs[4];
-  run_units<0, BWD>(a, lds, w, tid, xs);
+  f32x4 xs[4], ex[4];
+  run_units<0, BWD>(a, lds, w, tid, xs, ex);
 }
 
 // OIHW fp32 weights of every block's five convs -> the bf16 unit streams rdb_kernel reads (one thread per 16 bytes).
@@ -445,7 +457,8 @@ static int rdb_launch(RdbArgs& a, const char* what, void* stream) {
 }
 
 extern "C" int srx_rdb_fwd(int N, int H, int W, float* buf, int ld, const void* wpk, const float* const* bias5, float scale,
-                           float slope, float* out, int out_ld, void* stream) {
+                           float slope, float post_scale, const float* extra, int extra_ld, float* out, int out_ld,
+                           void* stream) {
   SRX_REQUIRE(buf && wpk && bias5 && out, "rdb_fwd: null pointer");
   SRX_REQUIRE(N > 0 && H > 0 && W > 0 && ld >= 192 && ld % 4 == 0 && out_ld >= 64 && out_ld % 4 == 0,
               "rdb_fwd: the block buffer needs >= 192 channels per pixel (x, c1..c4), the output >= 64, in whole quads");
@@ -456,14 +469,15 @@ extern "C" int srx_rdb_fwd(int N, int H, int W, float* buf, int ld, const void* 
     SRX_REQUIRE(bias5[k], "rdb_fwd: null bias %d", k);
     a.bias[k] = bias5[k];
   }
+  SRX_REQUIRE(!extra || (extra_ld >= 64 && extra_ld % 4 == 0 && extra != out), "rdb_fwd: the second addend needs >= 64 channels per pixel and a tensor of its own");
   a.N = N; a.H = H; a.W = W; a.ld = ld; a.bld = ld; a.out_ld = out_ld;
-  a.scale = scale; a.slope = slope;
+  a.scale = scale; a.slope = slope; a.post_scale = post_scale; a.extra = extra; a.extra_ld = extra_ld;
   return rdb_launch<false>(a, "rdb_fwd", stream);
 }
 
 extern "C" int srx_rdb_bwd(int N, int H, int W, const float* dy, int dy_ld, float scale, const float* buf, int ld,
                            const void* wpk_bwd, float slope, float* gbuf, int gld, const float* skip, int skip_ld,
-                           float skip_scale, float* dx, int dx_ld, void* stream) {
+                           float skip_scale, const float* extra, int extra_ld, float* dx, int dx_ld, void* stream) {
   SRX_REQUIRE(dy && buf && wpk_bwd && gbuf && skip && dx, "rdb_bwd: null pointer");
   SRX_REQUIRE(N > 0 && H > 0 && W > 0 && dy_ld >= 64 && dy_ld % 4 == 0 && ld >= 192 && ld % 4 == 0 && gld >= 192 && gld % 4 == 0 &&
                   skip_ld >= 64 && skip_ld % 4 == 0 && dx_ld >= 64 && dx_ld % 4 == 0,
@@ -474,6 +488,7 @@ extern "C" int srx_rdb_bwd(int N, int H, int W, const float* dy, int dy_ld, floa
   a.src = dy; a.buf = const_cast<float*>(buf); a.gout = gbuf; a.skip = skip; a.out = dx;
   a.wpk = reinterpret_cast<const unsigned char*>(wpk_bwd);
   a.N = N; a.H = H; a.W = W; a.ld = dy_ld; a.bld = ld; a.gld = gld; a.skip_ld = skip_ld; a.out_ld = dx_ld;
-  a.scale = scale; a.slope = slope; a.skip_scale = skip_scale;
+  SRX_REQUIRE(!extra || (extra_ld >= 64 && extra_ld % 4 == 0 && extra != dx), "rdb_bwd: the second addend needs >= 64 channels per pixel and a tensor of its own");
+  a.scale = scale; a.slope = slope; a.skip_scale = skip_scale; a.extra = extra; a.extra_ld = extra_ld;
   return rdb_launch<true>(a, "rdb_bwd", stream);
 }

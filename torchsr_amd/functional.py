@@ -1455,10 +1455,17 @@ class _RRDBTrunk(Function):
                     call('srx_conv2d_fwd', dref, _p(buf), _p(st.wpk_fwd), bp, buf.data_ptr() + 4 * cin, None, _p(ws), nws, s)
             if fused:
                 biases = (C.c_void_p * 5)(*[_p(_chk(wb[10 * i + 2 * k + 1].detach(), 'rrdb_trunk.bias')) for k in range(5)])
-                call('srx_rdb_fwd', n, h, w, _p(buf), total, pack.block_ptr(i), biases, float(rdb_scales[i]),
-                     float(states[i][0].slope), _p(nxt), total, s)
+                if i % 3 == 2:  # end of an RRDB: its `out * 0.2 + x` (:128) is the second addend of this block's last epilogue
+                    out, out_ld = (nxt, total) if i < nb - 1 else (torch.empty_like(x), c0)
+                    call('srx_rdb_fwd', n, h, w, _p(buf), total, pack.block_ptr(i), biases, float(rdb_scales[i]),
+                         float(states[i][0].slope), float(rrdb_scale), _p(bufs[i - 2]), total, _p(out), out_ld, s)
+                    if i == nb - 1:
+                        y = out
+                else:
+                    call('srx_rdb_fwd', n, h, w, _p(buf), total, pack.block_ptr(i), biases, float(rdb_scales[i]),
+                         float(states[i][0].slope), 1.0, None, 0, _p(nxt), total, s)
             descs.append(row)
-            if i % 3 == 2:  # end of an RRDB: out * 0.2 + x, x = the input of its first dense block (:128)
+            if i % 3 == 2 and not fused:  # end of an RRDB: out * 0.2 + x, x = the input of its first dense block (:128)
                 first = bufs[i - 2]
                 if i == nb - 1:
                     y = torch.empty_like(x)
@@ -1500,7 +1507,7 @@ class _RRDBTrunk(Function):
                 eff = 1.0
             # the `+ x` of :86 hands eff * grad to the block's input; the first block's input is also the RRDB's x
             skip, skip_scale = grad, eff
-            if j == 0:
+            if j == 0 and ctx.pack is None:
                 skip = torch.empty_like(grad)
                 call('srx_axpby', _p(grad), _p(rrdb_grad), _p(skip), grad.numel(), eff, 1.0, s)
                 skip_scale = 1.0
@@ -1508,8 +1515,10 @@ class _RRDBTrunk(Function):
             if ctx.pack is not None:
                 # bf16 products: the whole data-gradient chain of the block in one launch (srx_rdb_bwd): g5 = eff * scale * dy,
                 # the masked slice gradients g4..g1 (what the weight gradients below read) into gbuf, dx = the x share + skip
+                # (+ the RRDB's own skip gradient where this block is the first of its RRDB)
+                extra = rrdb_grad if j == 0 else None
                 call('srx_rdb_bwd', n, h, w, _p(grad), c0, float(eff * rdb_scales[i]), _p(buf), total, ctx.pack.bwd_ptr(i),
-                     float(ctx.states[i][0].slope), _p(gbuf), total, _p(skip), c0, float(skip_scale), _p(dx), c0, s)
+                     float(ctx.states[i][0].slope), _p(gbuf), total, _p(skip), c0, float(skip_scale), _p(extra), c0, _p(dx), c0, s)
             keep = (buf, gbuf, grad)
             # conv1 + conv2 and conv3 + conv4 read the same buffer and their output gradients are adjacent slices of gbuf:
             # queued as two 64-column weight-gradient problems instead of four 32-column ones (half a tile of padding each)
