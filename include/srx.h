@@ -183,6 +183,20 @@ typedef struct srx_dgrad_epilogue {
 } srx_dgrad_epilogue_t;
 int srx_conv2d_bwd_data_ex(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
                            const srx_dgrad_epilogue_t* e, float* ws, size_t ws_floats, void* stream);
+/* dx = conv^T(dy) [+ addend] AND, in the same launch, the first pass of the backward of the BatchNorm (+ PReLU) layer whose
+ * output gradient dx is -- the layer that fed this conv in the forward pass (srgan/residual.py:86-90: conv2's data gradient
+ * arrives at bn1 + prelu, conv1's (plus the skip gradient) at the previous block's bn2): table[row block][2C+4] = per-channel
+ * sums of dz = dx * act'(bn(y)) and dz * xhat, and the PReLU slope partial in columns 2C and 2C+1.  bn_prelu: the slope
+ * (device scalar) or NULL for a BatchNorm without activation.  Finish with srx_bn_act_bwd_finish(..., rows, 2, ...).
+ * Only layers for which srx_conv2d_bwd_data_bn_rows returns non-zero (3x3, 64 -> 64, stride 1, few pixels: the residual tower). */
+int srx_conv2d_bwd_data_bn_rows(const srx_conv2d_t* d);
+int srx_conv2d_bwd_data_bn(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, const float* addend, float* dx,
+                           const float* bn_y, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                           const float* bn_beta, const float* bn_prelu, float* table, void* stream);
+int srx_bn_act_bwd_finish(const float* dout, const float* y, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, const float* table, int rows, int prelu_cols, float* sums, float* dy, int64_t M,
+                          int C, int act, float slope, const float* prelu, float* dgamma_acc, float* dbeta_acc,
+                          float* dprelu_acc, void* stream);
 /* dw (OIHW) = autograd of nn.Conv2d wrt its weight; accumulate != 0 adds into dw (a .grad buffer)
  * instead of overwriting it.  db (may be NULL; not for shuffle layers) receives the bias gradient
  * sum_m dy[m][co] under the same flag: the kernel stages every dy row anyway.  The same flag exists on srx_colsum, srx_linear_bwd_weight,

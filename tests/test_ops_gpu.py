@@ -920,3 +920,71 @@ def test_fused_dense_block_backward(dev, n, h, w):
     if extra is not None:
         want_dx = want_dx + extra.double()
     assert rel(dx.permute(0, 3, 1, 2).cpu(), want_dx) < 2e-5
+
+
+@pytest.mark.parametrize('prelu', [False, True])
+def test_data_gradient_with_bn_backward_reduce_epilogue(dev, prelu):
+    """``srx_conv2d_bwd_data_bn`` + ``srx_bn_act_bwd_finish`` (the BatchNorm backward's reduce pass in the epilogue of the
+    data gradient that produces its output gradient) against the separate launches: ``srx_conv2d_bwd_data[_add]`` then
+    ``srx_bn_act_bwd`` -- same dx (bit for bit: same kernel body), same sums / dy / parameter gradients to rounding."""
+    import ctypes as C
+    from torchsr_amd import _lib
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    n, h, w, c = 4, 12, 12, 64
+    m = n * h * w
+    d = _lib.Conv2dDesc(n, h, w, c, c, c, c, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
+    rows = L.srx_conv2d_bwd_data_bn_rows(C.byref(d))
+    assert rows == m // 36
+    g = torch.Generator().manual_seed(31)
+    rnd = lambda *shape: torch.randn(*shape, generator=g).to(dev)  # noqa: E731
+    wt = rnd(c, c, 3, 3) * 0.05
+    wf = torch.empty(L.srx_conv2d_packed_fwd_floats(C.byref(d)), device=dev)
+    wb = torch.empty(L.srx_conv2d_packed_bwd_floats(C.byref(d)), device=dev)
+    _lib.call('srx_conv2d_pack', C.byref(d), wt.data_ptr(), wf.data_ptr(), wb.data_ptr(), s)
+    dy, addend, y = rnd(n, h, w, c), rnd(n, h, w, c), rnd(n, h, w, c)
+    mean, invstd = rnd(c) * 0.1, torch.rand(c, generator=g).to(dev) + 0.5
+    gamma, beta = rnd(c), rnd(c) * 0.3
+    slope = torch.tensor([0.25], device=dev) if prelu else None
+    act = _lib.ACT_PRELU if prelu else _lib.ACT_NONE
+    W = 2 * c + 4
+    for add in (None, addend):
+        # separate launches
+        dx0 = torch.empty_like(dy)
+        nws = L.srx_conv2d_bwd_data_ws_floats(C.byref(d))
+        ws = torch.empty(max(nws, 4), device=dev)
+        if add is None:
+            _lib.call('srx_conv2d_bwd_data', C.byref(d), dy.data_ptr(), wb.data_ptr(), dx0.data_ptr(), 0, ws.data_ptr(), nws, s)
+        else:
+            _lib.call('srx_conv2d_bwd_data_add', C.byref(d), dy.data_ptr(), wb.data_ptr(), add.data_ptr(), dx0.data_ptr(), ws.data_ptr(), nws, s)
+        sums0, out0 = torch.empty(W, device=dev), torch.empty_like(dy)
+        gg0, gb0, gp0 = torch.zeros(c, device=dev), torch.zeros(c, device=dev), torch.zeros(1, device=dev)
+        nbw = L.srx_bn_bwd_ws_floats(m, c)
+        bws = torch.empty(nbw, device=dev)
+        _lib.call('srx_bn_act_bwd', dx0.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                  sums0.data_ptr(), out0.data_ptr(), m, c, 1, act, 0.0, None if slope is None else slope.data_ptr(), 1, gg0.data_ptr(),
+                  gb0.data_ptr(), gp0.data_ptr() if prelu else None, bws.data_ptr(), nbw, s)
+        # fused
+        dx1 = torch.empty_like(dy)
+        table = torch.full((rows, W), float('nan'), device=dev)
+        _lib.call('srx_conv2d_bwd_data_bn', C.byref(d), dy.data_ptr(), wb.data_ptr(), None if add is None else add.data_ptr(),
+                  dx1.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                  None if slope is None else slope.data_ptr(), table.data_ptr(), s)
+        sums1, out1 = torch.empty(W, device=dev), torch.empty_like(dy)
+        gg1, gb1, gp1 = torch.zeros(c, device=dev), torch.zeros(c, device=dev), torch.zeros(1, device=dev)
+        _lib.call('srx_bn_act_bwd_finish', dx1.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                  beta.data_ptr(), table.data_ptr(), rows, 2, sums1.data_ptr(), out1.data_ptr(), m, c, act, 0.0,
+                  None if slope is None else slope.data_ptr(), gg1.data_ptr(), gb1.data_ptr(), gp1.data_ptr() if prelu else None, s)
+        torch.cuda.synchronize()
+        assert torch.equal(dx0, dx1)
+        assert torch.isfinite(table[:, :2 * c + 2]).all()
+        assert rel_err(sums1[:2 * c], sums0[:2 * c]) < 1e-5 and rel_err(out1, out0) < 1e-5
+        assert rel_err(gg1, gg0) < 1e-5 and rel_err(gb1, gb0) < 1e-5
+        if prelu:
+            assert abs(gp1.item() - gp0.item()) <= 1e-5 * max(abs(gp0.item()), 1.0)
+    # layers the row-tile kernel does not serve are refused, and say so beforehand
+    d2 = _lib.Conv2dDesc(1, 100, 100, c, c, c, c, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
+    assert L.srx_conv2d_bwd_data_bn_rows(C.byref(d2)) == 0
+    rc = L.srx_conv2d_bwd_data_bn(C.byref(d2), dy.data_ptr(), wb.data_ptr(), None, dy.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                  invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, table.data_ptr(), s)
+    assert rc != 0 and 'row tile' in _lib.last_error()

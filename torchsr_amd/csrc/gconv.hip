@@ -1830,6 +1830,28 @@ extern "C" int srx_conv2d_bwd_data_act(const srx_conv2d_t* d, const float* dy, c
   return conv_bwd_data_impl(d, dy, wpk_bwd, dx, accumulate, x, slope, c_lo, c_hi, ws, ws_floats, stream);
 }
 
+// Rows of the BatchNorm-backward partial table srx_conv2d_bwd_data_bn writes for this layer; 0: the layer does not run on the
+// kernel that has that epilogue (the 36-pixel row tile) and the caller keeps the separate srx_bn_act_bwd
+extern "C" int srx_conv2d_bwd_data_bn_rows(const srx_conv2d_t* d) {
+  if (check_desc(d) != SRX_OK || !srx_rt36_applicable(d) || d->Cin != 64) return 0;
+  return srx_rt36_rows(d);
+}
+
+extern "C" int srx_conv2d_bwd_data_bn(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, const float* addend, float* dx,
+                                      const float* bn_y, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                      const float* bn_beta, const float* bn_prelu, float* table, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRX_REQUIRE(dy && wpk_bwd && dx && bn_y && bn_mean && bn_invstd && bn_gamma && bn_beta && table, "conv2d_bwd_data_bn: null pointer");
+  SRX_REQUIRE(!addend || addend != dx, "conv2d_bwd_data_bn: the addend must be a tensor of its own");
+  if (srx_conv2d_bwd_data_bn_rows(d) == 0)
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data_bn: 3x3 / 64 -> 64 / stride 1 layers on the 36-pixel row tile only (srx_conv2d_bwd_data_bn_rows)");
+  BwdClass cls[16];
+  size_t total;
+  (void)bwd_classes(d, cls, total);
+  const srx_rt36_bn_t bn{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_prelu, table};
+  return srx_rt36_run(d, dy, wpk_bwd + cls[0].woff, nullptr, addend, dx, nullptr, SRX_ACT_NONE, 0.f, srx_stream(stream), &bn);
+}
+
 extern "C" int srx_conv2d_bwd_data_ex(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, float* dx,
                                       const srx_dgrad_epilogue_t* e, float* ws, size_t ws_floats, void* stream) {
   SRX_REQUIRE(e, "conv2d_bwd_data_ex: null epilogue");

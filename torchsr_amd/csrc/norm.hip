@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ ws, int rows, int C, int groups,
                                                               float* __restrict__ sums, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ dprelu) {
+                                                              float* __restrict__ dbeta, float* __restrict__ dprelu,
+                                                              int prelu_cols) {
   // one wave per column: lanes stride over the partial rows (a few hundred at most), fp64 butterfly; per group
   // (each group's own sums feed its rows' input gradient), the parameter gradients take the total
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -199,7 +200,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   double total = 0.0;
   for (int g = 0; g < groups; ++g) {
     double s = 0.0;
-    for (int r = g * rpg + lane; r < (g + 1) * rpg; r += 64) s += (double)ws[(size_t)r * (2 * C + 4) + c];
+    for (int r = g * rpg + lane; r < (g + 1) * rpg; r += 64) {
+      s += (double)ws[(size_t)r * (2 * C + 4) + c];
+      // (a table written by a conv epilogue holds the PReLU partial of each of its two column waves: columns 2C, 2C + 1)
+      if (c == 2 * C && prelu_cols == 2) s += (double)ws[(size_t)r * (2 * C + 4) + c + 1];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (lane == 0) sums[(size_t)g * (2 * C + 4) + c] = (float)s;
@@ -311,7 +316,7 @@ int bwd_reduce_impl(const float* dout, const float* y, const float* mean, const 
                      ws, M, C, act, slope, prelu, rows_per_block(M), M / groups);
   SRX_CHECK_LAUNCH("bn_bwd_reduce_kernel");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)srx_cdiv(2 * C + 1, 4)), dim3(256), 0, st, ws, rows, C, groups,
-                     sums, dgamma_acc, dbeta_acc, dprelu_acc);
+                     sums, dgamma_acc, dbeta_acc, dprelu_acc, 1);
   SRX_CHECK_LAUNCH("bn_bwd_finalize_kernel");
   return SRX_OK;
 }
@@ -409,4 +414,22 @@ extern "C" int srx_bn_act_bwd(const float* dout, const float* y, const float* me
     return rc;
   if (!dy) return SRX_OK;
   return bwd_apply_impl(dout, y, mean, invstd, gamma, beta, sums, dy, M, C, groups, act, slope, prelu, training, stream);
+}
+
+// The last two passes of srx_bn_act_bwd on a partial table somebody else produced: `table` [rows][2C+4] holds, per row
+// block, sum dz ([0,C)), sum dz * xhat ([C,2C)) and the PReLU slope partial in `prelu_cols` (1 or 2) columns from 2C --
+// written by srx_conv2d_bwd_data_bn, the data gradient that produced `dout`.  One group.
+extern "C" int srx_bn_act_bwd_finish(const float* dout, const float* y, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, const float* table, int rows, int prelu_cols,
+                                     float* sums, float* dy, int64_t M, int C, int act, float slope, const float* prelu,
+                                     float* dgamma_acc, float* dbeta_acc, float* dprelu_acc, void* stream) {
+  if (int rc = check_c(C, "bn_act_bwd_finish")) return rc;
+  SRX_REQUIRE(dout && y && mean && invstd && gamma && beta && table && sums && dy && M > 0 && rows > 0,
+              "bn_act_bwd_finish: bad argument");
+  SRX_REQUIRE(prelu_cols == 1 || prelu_cols == 2, "bn_act_bwd_finish: the PReLU partial sits in 1 or 2 table columns");
+  SRX_REQUIRE(act != SRX_ACT_PRELU || prelu, "bn_act_bwd_finish: PReLU needs its slope pointer");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)srx_cdiv(2 * C + 1, 4)), dim3(256), 0, srx_stream(stream), table, rows,
+                     C, 1, sums, dgamma_acc, dbeta_acc, dprelu_acc, prelu_cols);
+  SRX_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  return bwd_apply_impl(dout, y, mean, invstd, gamma, beta, sums, dy, M, C, 1, act, slope, prelu, 1, stream);
 }

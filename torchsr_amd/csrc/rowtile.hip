@@ -37,12 +37,18 @@ struct RtArgs {
   float slope;       // branch-free activation: v > 0 ? v : v * slope  (none: 1, ReLU: 0, LeakyReLU: its slope)
   unsigned in_bytes, out_bytes;
   int step_r, step_c;  // 16 / (W+2), 16 % (W+2): patch-fill stride of one thread
+  // BNR (data gradients only): this launch's OUTPUT is the gradient arriving at a BatchNorm (+ PReLU) layer -- the one that
+  // produced this conv's input in the forward pass -- and the epilogue also does the first pass of that layer's backward:
+  // per-channel partial sums of dz = out * act'(z) and dz * xhat over the workgroup's 36 rows (and the PReLU slope's
+  // partial), one table row [2C + 4] per workgroup, exactly what bn_bwd_reduce_kernel would compute from a second read
+  // of `out` and `y` in a launch of its own.
+  srx_rt36_bn_t bn;
 };
 
 // NB = batches of PB patch loads per thread (1 up to 2048 b128 slots, 2 up to the 64 KB LDS limit): a
 // compile-time count, so that ALL input loads and the first weight fragments are in flight together
 // and the compiler can wait on them with exact vmcnt values (a runtime loop drains the queue per trip).
-template <int NB>
+template <int NB, bool BNR = false>
 __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   extern __shared__ __attribute__((aligned(16))) float patch[];
   const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
@@ -169,12 +175,36 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     rv4[i] = a.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)obase4, (32 + i) * 256, 0)) : 0.f;
+  // BNR: the BatchNorm input at this lane's 20 (row, column) positions, and the layer's per-channel constants
+  float yv[16], yv4[4];
+  float bmu = 0.f, bis = 0.f, bgm = 0.f, bbt = 0.f, bsl = 1.f, t1 = 0.f, t2 = 0.f, tp = 0.f;
+  if constexpr (BNR) {
+    const __amdgpu_buffer_rsrc_t rby = srx_rsrc(a.bn.y, a.out_bytes);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rby, (int)obase, ((r & 3) + 8 * (r >> 2)) * 256, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      yv4[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rby, (int)obase4, (32 + i) * 256, 0));
+    bmu = a.bn.mean[col]; bis = a.bn.invstd[col]; bgm = a.bn.gamma[col]; bbt = a.bn.beta[col];
+    if (a.bn.prelu) bsl = a.bn.prelu[0];
+  }
+  auto bn_acc = [&](float o, float y) {
+    const float xh = (y - bmu) * bis;
+    const float z = xh * bgm + bbt;
+    const bool pos = z > 0.f;
+    const float dz = pos ? o : o * bsl;
+    t1 += dz;
+    t2 += dz * xh;
+    if (a.bn.prelu && !pos) tp += o * z;
+  };
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float v = acc[r] + bv;
     s1 += v;
     s2 += v * v;
     const float o = (v > 0.f ? v : v * a.slope) + rv[r];
+    if constexpr (BNR) bn_acc(o, yv[r]);
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rout, obase, ((r & 3) + 8 * (r >> 2)) * 256, 0);
   }
 #pragma unroll
@@ -182,7 +212,16 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     const float v = acc4[i] + bv;
     if (h2 == 0) { s1 += v; s2 += v * v; }
     const float o = (v > 0.f ? v : v * a.slope) + rv4[i];
+    if constexpr (BNR) { if (h2 == 0) bn_acc(o, yv4[i]); }
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rout, obase4, (32 + i) * 256, 0);
+  }
+  if constexpr (BNR) {  // table row of this workgroup: [0, C) sum dz, [C, 2C) sum dz * xhat, 2C + j the PReLU partial of wave j
+    t1 += __shfl_xor(t1, 32, 64);
+    t2 += __shfl_xor(t2, 32, 64);
+    tp = srx_wave_sum(tp);
+    float* row = a.bn.part + (size_t)blockIdx.x * (2 * 64 + 4);
+    if (h2 == 0) { row[col] = t1; row[64 + col] = t2; }
+    if (lane == 0) row[128 + j] = tp;
   }
   if (a.part) {  // per-channel (sum, sum of squares) of this workgroup's 36 rows
     s1 += __shfl_xor(s1, 32, 64);
@@ -231,8 +270,9 @@ bool srx_rt36_applicable(const srx_conv2d_t* d) {
 int srx_rt36_rows(const srx_conv2d_t* d) { return (int)((int64_t)d->N * d->H * d->W / RT); }
 
 int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, const float* residual,
-                 float* out, float* part, int act, float slope, hipStream_t st) {
+                 float* out, float* part, int act, float slope, hipStream_t st, const srx_rt36_bn_t* bn) {
   RtArgs a{};
+  if (bn) a.bn = *bn;
   a.in = in; a.w = wpk; a.bias = bias; a.res = residual; a.out = out; a.part = part;
   a.H = d->H; a.W = d->W; a.HW = d->H * d->W; a.M = d->N * a.HW;
   a.slope = act == SRX_ACT_RELU ? 0.f : (act == SRX_ACT_LRELU ? slope : 1.f);
@@ -246,13 +286,20 @@ int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   });
   const int nb = patch_batches(d->W);
   const double fl = 2.0 * a.M * 64 * KTOT;
   const dim3 grid((unsigned)(a.M / RT));
   char nm[112];
   if (srx_prof_on()) snprintf(nm, sizeof(nm), "rt36_conv3x3_c64_kernel<%d> MxNxK=%dx64x%d", nb, a.M, KTOT);
-  if (nb == 1) SRX_LAUNCH_PROF(nm, fl, rt36_conv3x3_c64_kernel<1>, grid, dim3(256), lds, st, a);
+  if (bn) {
+    if (nb == 1) SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<1, true>), grid, dim3(256), lds, st, a);
+    else SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<2, true>), grid, dim3(256), lds, st, a);
+  } else if (nb == 1) SRX_LAUNCH_PROF(nm, fl, rt36_conv3x3_c64_kernel<1>, grid, dim3(256), lds, st, a);
   else SRX_LAUNCH_PROF(nm, fl, rt36_conv3x3_c64_kernel<2>, grid, dim3(256), lds, st, a);
   SRX_CHECK_LAUNCH("rt36_conv3x3_c64_kernel");
   return SRX_OK;

@@ -56,8 +56,12 @@ int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const
 // rowtile.hip: 3x3 / 64 -> 64 convolutions with few pixels (the SRGAN residual tower), 36 pixels per CU
 bool srx_rt36_applicable(const srx_conv2d_t* d);
 int srx_rt36_rows(const srx_conv2d_t* d);  // workgroups = rows of the BatchNorm partial table
+// optional second epilogue of a data gradient: first pass of the backward of the BatchNorm (+ PReLU: prelu != null) layer
+// whose output gradient this launch produces (see rowtile.hip); part: [workgroups][2 * 64 + 4]
+struct srx_rt36_bn_t { const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta;
+                       const float* prelu; float* part; };
 int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, const float* residual,
-                 float* out, float* part, int act, float slope, hipStream_t st);
+                 float* out, float* part, int act, float slope, hipStream_t st, const srx_rt36_bn_t* bn = nullptr);
 
 static inline hipStream_t srx_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t srx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -640,6 +640,142 @@ class _ResidualBlock(Function):
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
+class _ResidualTower(Function):
+    """The chain of SRGAN ``ResidualBlock``s (srgan/generator.py:42-45,76) as ONE autograd node: the same kernels as
+    ``_ResidualBlock`` per block, plus what only a node that sees neighbouring layers can do -- the first pass of every
+    BatchNorm backward (the per-channel sums of dz and dz * xhat) rides in the epilogue of the data gradient that
+    PRODUCES that BatchNorm's output gradient (``srx_conv2d_bwd_data_bn``): conv2's data gradient reduces for bn1 + PReLU
+    of its own block, conv1's (plus the skip gradient) for bn2 of the block BEFORE.  32 of the 33 ``bn_bwd_reduce``
+    launches of a generator backward pass (and their second read of two 2.4 MB tensors each) disappear.
+    """
+
+    @staticmethod
+    def forward(ctx, x: Tensor, blocks, *params):
+        ctx.set_materialize_grads(False)
+        x = _chk(x, 'residual_tower.input')
+        n, h, w, c = x.shape
+        m = n * h * w
+        L, s = _lib.lib(), _stream()
+        saved, descs = [], None
+        for block in blocks:
+            convs, bns = (block.conv1, block.conv2), (block.bn1, block.bn2)
+            inp, ys, stats = x, [], []
+            for i in range(2):
+                st, bn = convs[i]._st, bns[i]
+                d = st.desc(n, h, w)
+                dref = C.byref(d)
+                st.pack(convs[i].weight, d)
+                y = torch.empty_like(x)
+                part = torch.empty((L.srx_conv2d_stat_rows(dref), c, 2), dtype=torch.float32, device=x.device)
+                nws = L.srx_conv2d_fwd_ws_floats(dref)
+                call('srx_conv2d_fwd', dref, _p(inp), _p(st.wpk_fwd), None, _p(y), _p(part), _p(_ws(nws, x)) if nws else None, nws, s)
+                mean = torch.empty(c, dtype=torch.float32, device=x.device)
+                invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+                out = torch.empty_like(x)
+                momentum = 0.1 if bn.momentum is None else bn.momentum
+                g, b = bn.weight.detach(), bn.bias.detach()
+                if i == 0:   # BN1 + PReLU
+                    call('srx_bn_train_fwd', _p(y), _p(part), part.shape[0], m, c, 1, bn.eps, momentum, _p(g), _p(b), None, _p(out),
+                         ACT_PRELU, 0.0, _p(block.prelu.weight.detach()), _p(mean), _p(invstd), _p(bn.running_mean),
+                         _p(bn.running_var), _p(bn.num_batches_tracked), s)
+                    a1 = inp = out
+                else:        # BN2 + skip connection
+                    call('srx_bn_train_fwd', _p(y), _p(part), part.shape[0], m, c, 1, bn.eps, momentum, _p(g), _p(b), _p(x), _p(out),
+                         ACT_NONE, 0.0, None, _p(mean), _p(invstd), _p(bn.running_mean), _p(bn.running_var),
+                         _p(bn.num_batches_tracked), s)
+                ys.append(y)
+                stats += [mean, invstd]
+                descs = d
+            saved += [x, ys[0], a1, ys[1], *stats]
+            x = out
+        ctx.blocks, ctx.desc = blocks, descs
+        ctx.packs = [(b.conv1._st.wpk_bwd, b.conv2._st.wpk_bwd) for b in blocks]
+        ctx.save_for_backward(*saved)
+        return x
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        saved, blocks, d = ctx.saved_tensors, ctx.blocks, ctx.desc
+        grad = _chk(dout, 'residual_tower.grad')
+        n, h, w, c = grad.shape
+        m = n * h * w
+        L, s = _lib.lib(), _stream()
+        queue = wgrad_queue[0]
+        dref = C.byref(d)
+        rows = L.srx_conv2d_bwd_data_bn_rows(dref)  # 0: the layers do not run on the row-tile kernel at this size
+        import os
+        if os.environ.get('SRX_NO_BN_DGRAD_FUSE') == '1':  # developer switch (A/B runs): separate reduce launches
+            rows = 0
+        W = 2 * c + 4
+        nws_d = L.srx_conv2d_bwd_data_ws_floats(dref)
+
+        def finish(dz_in, y, mean, invstd, bn, act, prelu, table):
+            """dy of act(BN(y)) given dz_in; the reduce pass comes from `table` when the producer of dz_in filled one"""
+            sums = torch.empty(W, dtype=torch.float32, device=grad.device)
+            dy = torch.empty_like(y)
+            pw = None if prelu is None else prelu.detach()
+            gw, gb = bn.weight.detach(), bn.bias.detach()
+            pg = None if prelu is None else _p(prelu.grad)
+            if table is not None:
+                call('srx_bn_act_bwd_finish', _p(dz_in), _p(y), _p(mean), _p(invstd), _p(gw), _p(gb), _p(table), rows, 2, _p(sums),
+                     _p(dy), m, c, act, 0.0, _p(pw), _p(bn.weight.grad), _p(bn.bias.grad), pg, s)
+            else:
+                nws = L.srx_bn_bwd_ws_floats(m, c)
+                call('srx_bn_act_bwd', _p(dz_in), _p(y), _p(mean), _p(invstd), _p(gw), _p(gb), _p(sums), _p(dy), m, c, 1, act, 0.0,
+                     _p(pw), 1, _p(bn.weight.grad), _p(bn.bias.grad), pg, _p(_ws(nws, y)), nws, s)
+            return dy
+
+        def dgrad(pack, dy, addend, below):
+            """conv^T(dy) [+ addend]; `below` = (y, mean, invstd, bn, prelu) of the BatchNorm the result arrives at, or None"""
+            dx = torch.empty_like(dy)
+            if below is not None and rows:
+                y, mean, invstd, bn, prelu = below
+                table = torch.empty((rows, W), dtype=torch.float32, device=dy.device)
+                call('srx_conv2d_bwd_data_bn', dref, _p(dy), _p(pack), _p(addend), _p(dx), _p(y), _p(mean), _p(invstd),
+                     _p(bn.weight.detach()), _p(bn.bias.detach()), None if prelu is None else _p(prelu.detach()), _p(table), s)
+                return dx, table
+            ws = _ws(nws_d, dy) if nws_d else None
+            if addend is None:
+                call('srx_conv2d_bwd_data', dref, _p(dy), _p(pack), _p(dx), 0, _p(ws), nws_d, s)
+            else:
+                call('srx_conv2d_bwd_data_add', dref, _p(dy), _p(pack), _p(addend), _p(dx), _p(ws), nws_d, s)
+            return dx, None
+
+        def wgrad(conv, inp, dy):
+            if queue is not None:
+                queue.add(d, _p(inp), _p(dy), _p(conv.weight.grad), None, (inp, dy))
+                return
+            nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
+            call('srx_conv2d_bwd_weight', dref, _p(inp), _p(dy), _p(conv.weight.grad), 1, None, _p(_ws(nws, inp)), nws, s)
+
+        table2 = None  # the reduce pass of the top block's bn2 has no producer inside this node
+        for i in range(len(blocks) - 1, -1, -1):
+            block = blocks[i]
+            x, y1, a1, y2, mean1, inv1, mean2, inv2 = saved[8 * i:8 * i + 8]
+            dy2 = finish(grad, y2, mean2, inv2, block.bn2, ACT_NONE, None, table2)
+            wgrad(block.conv2, a1, dy2)
+            da1, table1 = dgrad(ctx.packs[i][1], dy2, None, (y1, mean1, inv1, block.bn1, block.prelu.weight))
+            dy1 = finish(da1, y1, mean1, inv1, block.bn1, ACT_PRELU, block.prelu.weight, table1)
+            wgrad(block.conv1, x, dy1)
+            if i > 0 or ctx.needs_input_grad[0]:
+                below = None
+                if i > 0:
+                    pb = blocks[i - 1]
+                    below = (saved[8 * (i - 1) + 3], saved[8 * (i - 1) + 6], saved[8 * (i - 1) + 7], pb.bn2, None)
+                grad, table2 = dgrad(ctx.packs[i][0], dy1, grad, below)
+            else:
+                grad = None
+        return (grad, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+def residual_tower(x: Tensor, blocks) -> Tensor:
+    """``nn.Sequential(*blocks)(x)`` for ``ResidualBlock`` modules that all satisfy ``residual_block_fused_ok``."""
+    ps = []
+    for b in blocks:
+        ps += [b.conv1.weight, b.bn1.weight, b.bn1.bias, b.prelu.weight, b.conv2.weight, b.bn2.weight, b.bn2.bias]
+    return _ResidualTower.apply(x, list(blocks), *ps)
+
+
 def residual_block_fused_ok(block) -> bool:
     """The one-node form applies in training mode with autograd on, when every parameter of the block accumulates
     its gradient straight into a flat ``.grad`` buffer (``direct_grads``: the trainers)."""

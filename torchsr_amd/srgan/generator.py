@@ -41,7 +41,10 @@ class Generator(nn.Module):
             out = f[1](self.blocks(conv1), residual=conv1)
             return self.conv3(self.conv_layers(out))
         conv1 = self.conv1[1](self.conv1[0](x4))
-        block = self.blocks(conv1)
+        if len(self.blocks) and all(F.residual_block_fused_ok(b) for b in self.blocks):
+            block = F.residual_tower(conv1, self.blocks)  # training under a trainer: the whole chain is one autograd node
+        else:
+            block = self.blocks(conv1)
         bn = self.conv2[1]
         y, part = self.conv2[0](block, want_stats=True) if bn.training else (self.conv2[0](block), None)
         out = bn(y, part, residual=conv1)  # torch.add(conv1, conv2), generator.py:78
