@@ -988,3 +988,34 @@ def test_data_gradient_with_bn_backward_reduce_epilogue(dev, prelu):
     rc = L.srx_conv2d_bwd_data_bn(C.byref(d2), dy.data_ptr(), wb.data_ptr(), None, dy.data_ptr(), y.data_ptr(), mean.data_ptr(),
                                   invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, table.data_ptr(), s)
     assert rc != 0 and 'row tile' in _lib.last_error()
+
+
+@pytest.mark.parametrize('n,h,w,cin', [(2, 32, 32, 192), (3, 7, 32, 96), (1, 5, 16, 64)])
+def test_bf16_weight_gradient_on_image_rows(dev, n, h, w, cin):
+    """The image-row bf16 weight-gradient kernel (3x3 / stride 1 / 64 output columns / rows of 16 or 32 pixels: ESRGAN's dense
+    blocks) through ``srx_conv2d_bwd_weight_multi_scaled``: two problems with their own multipliers, bias gradients riding
+    along, accumulation into existing gradients, against fp64 of the bf16-rounded operands -- images of several rows, of
+    few rows (every row a border row) and a 192-strided input read on its first `cin` channels."""
+    from torchsr_amd import _lib
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    d = _lib.Conv2dDesc(n, h, w, cin, 192, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 1)
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
+    r16 = lambda t: t.bfloat16().double()  # noqa: E731
+    xs = [rnd((n, 192, h, w), 40 + i) for i in range(2)]
+    dys = [rnd((n, 64, h, w), 50 + i) for i in range(2)]
+    scales = [0.2, 1.5]
+    gw = [torch.full((64, cin, 3, 3), 0.5, device=dev) for _ in range(2)]
+    gb = [torch.full((64,), -1.0, device=dev) for _ in range(2)]
+    nws = L.srx_conv2d_bwd_weight_multi_ws_floats(C.byref(d), 2)
+    ws = torch.empty(max(nws, 4), device=dev)
+    xd = [nhwc(x, 192).to(dev) for x in xs]
+    dd = [nhwc(t).to(dev) for t in dys]
+    _lib.call('srx_conv2d_bwd_weight_multi_scaled', C.byref(d), 2, 1, arr(xd), arr(dd), arr(gw), 1, arr(gb), (C.c_float * 2)(*scales),
+              ws.data_ptr(), nws, s)
+    torch.cuda.synchronize()
+    for i in range(2):
+        want = scales[i] * torch.nn.grad.conv2d_weight(r16(xs[i][:, :cin]), (64, cin, 3, 3), r16(dys[i]), padding=1) + 0.5
+        assert rel_err(gw[i].cpu(), want.float()) < 2e-5, (i, rel_err(gw[i].cpu(), want.float()))
+        want_b = scales[i] * dys[i].double().sum((0, 2, 3)) - 1.0
+        assert rel_err(gb[i].cpu(), want_b.float()) < 2e-5, i

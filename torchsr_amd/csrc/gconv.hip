@@ -766,9 +766,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WMulti mp) {
   const int tiles_ = a.ktiles * (a.Cnw / 64);
   const int tile_id = wi % tiles_, rest_ = wi / tiles_;
   const int prob = srx_uniform(rest_ % a.nprob), zsplit = srx_uniform(rest_ / a.nprob);
-  constexpr int LROWS = PR ? 16 : 32;  // LDS rows per chunk (row pairs for bf16)
-  __shared__ __attribute__((aligned(16))) float sD[2][LROWS * 64];
-  __shared__ __attribute__((aligned(16))) float sX[2][LROWS * 64];
+  // LDS image of a chunk (32 pixels x 64 columns).  fp32: [pixel][64] floats.  bf16: [pixel][64] bf16 in rows of PSTR = 192
+  // bytes (the 64-byte pad puts the four rows of a transposing read on different banks): operands are stored as they
+  // arrive -- one 8-byte store per loaded quad -- and an MFMA operand (eight consecutive PIXELS of one column) is two
+  // ds_read_b64_tr_b16, the hardware's transposing read, instead of four scalar reads of hand-interleaved row pairs
+  constexpr int PSTR = 192;
+  constexpr int BUF_FLOATS = PR ? 32 * PSTR / 4 : 32 * 64;
+  __shared__ __attribute__((aligned(16))) float sD[2][BUF_FLOATS];
+  __shared__ __attribute__((aligned(16))) float sX[2][BUF_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
   const int ntile = srx_uniform(tile_id / a.ktiles), kt = srx_uniform(tile_id - ntile * a.ktiles);
   const int k0 = kt * 64, n0 = ntile * 64;
@@ -839,18 +844,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WMulti mp) {
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   auto swrite = [&](int buf, const f32x4 (&rd)[2], const f32x4 (&rx)[2]) {
     if (want_bias) bsum += rd[0] + rd[1];  // (fp32 values, whatever the product precision)
-    if (PR) {  // word (pair row r0, column 4q + e) = (bf16 of row 2 r0, bf16 of row 2 r0 + 1)
-      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 wd, wx;
+    if (PR) {  // row 2 r0 + p, columns 4q .. 4q + 3, rounded to bf16
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bf16x2 pd = {(__bf16)rd[0][e], (__bf16)rd[1][e]}, px = {(__bf16)rx[0][e], (__bf16)rx[1][e]};
-        wd[e] = __builtin_bit_cast(unsigned, pd);
-        wx[e] = __builtin_bit_cast(unsigned, px);
+      for (int p = 0; p < 2; ++p) {
+        const bf16x4 pd = {(__bf16)rd[p][0], (__bf16)rd[p][1], (__bf16)rd[p][2], (__bf16)rd[p][3]};
+        const bf16x4 px = {(__bf16)rx[p][0], (__bf16)rx[p][1], (__bf16)rx[p][2], (__bf16)rx[p][3]};
+        unsigned char* bD = reinterpret_cast<unsigned char*>(&sD[buf][0]) + (2 * r0 + p) * PSTR + 8 * q;
+        unsigned char* bX = reinterpret_cast<unsigned char*>(&sX[buf][0]) + (2 * r0 + p) * PSTR + 8 * q;
+        *reinterpret_cast<bf16x4*>(bD) = pd;
+        *reinterpret_cast<bf16x4*>(bX) = px;
       }
-      *reinterpret_cast<u32x4*>(&sD[buf][r0 * 64 + q * 4]) = wd;
-      *reinterpret_cast<u32x4*>(&sX[buf][r0 * 64 + q * 4]) = wx;
       return;
     }
 #pragma unroll
@@ -867,17 +871,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WMulti mp) {
   const int wn = wave >> 1, wk = wave & 1;
 
   auto compute = [&](int buf) {
-    if (PR) {  // MFMA s takes rows 16 s + 8 h .. + 7 = pair rows 8 s + 4 h + {0..3}
+    if (PR) {  // MFMA s contracts pixels 16 s + 8 h .. + 7: two transposing reads of 4 pixels x 16 columns per 16-lane group
       typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-      const float* cD = &sD[buf][4 * h * 64 + wn * 32 + l31];
-      const float* cX = &sX[buf][4 * h * 64 + wk * 32 + l31];
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+      const int li = lane & 15, colh = 16 * ((lane >> 4) & 1) + 4 * (li & 3), rq = li >> 2;
+      const unsigned char* bD = reinterpret_cast<const unsigned char*>(&sD[buf][0]) + (8 * h + rq) * PSTR + 2 * (wn * 32 + colh);
+      const unsigned char* bX = reinterpret_cast<const unsigned char*>(&sX[buf][0]) + (8 * h + rq) * PSTR + 2 * (wk * 32 + colh);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        f32x4 fd, fx;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { fd[t] = cD[(8 * s + t) * 64]; fx[t] = cX[(8 * s + t) * 64]; }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc, 0,
-                                                      0, 0);
+        const s16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bD + (16 * s) * PSTR));
+        const s16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bD + (16 * s + 4) * PSTR));
+        const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bX + (16 * s) * PSTR));
+        const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bX + (16 * s + 4) * PSTR));
+        const s16x8 fd = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+        const s16x8 fx = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc, 0, 0, 0);
       }
       return;
     }
@@ -929,6 +939,168 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WMulti mp) {
 #pragma unroll
       for (int r = 1; r < 16; ++r) t += red[r * 16 + tid];
       *reinterpret_cast<f32x4*>(a.bslab + slab_id * a.Cnw + n0 + 4 * tid) = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// bf16 weight gradient of 3x3 / stride 1 / pad 1 convs with 64 output columns, on WHOLE IMAGE ROWS (round 3).
+// wgrad_kernel above gathers one (tap, channel) k-tile per workgroup: every tap re-reads the same x pixels and every k-tile
+// re-reads the dy tile -- 16 FLOP per byte pulled through the L2s, and with bf16 MFMAs (16x the fp32 rate) ESRGAN's 207
+// dense-block problems per step (32 GB of reads) ran at the speed of that traffic: 205 TFLOP/s, unmoved by a 4x longer
+// chunk per barrier or by half the LDS instructions (tools/experiments/README.md).  Here a workgroup owns 32 input channels
+// of one problem and ALL NINE taps: per image row it loads one new x row (the window of three rows rolls through four LDS
+// slots, zero columns left and right) and one dy row, rounds them to bf16 as they arrive, and multiplies
+// dy[row]^T (64 columns) with the nine shifted views of the window -- 95 FLOP per byte.  Operands are pixel-major in LDS
+// and an MFMA operand (eight consecutive PIXELS of one column) is two ds_read_b64_tr_b16; a tap is an address offset.
+// Wave (wn, th): output-column half wn, taps 0..4 (th = 0) or 5..8 (th = 1): 5 / 4 accumulators of 32 columns x 32 channels.
+// Rows outside the image are skipped tap-wise (the slots hold the neighbouring image's rows).  The slab layout is
+// wgrad_kernel's ([n][tap * Ck + channel]), so wgrad_reduce_kernel, the pairs and the scales work unchanged.
+// ---------------------------------------------------------------------------
+template <int WPX>
+__global__ __launch_bounds__(256) void wgrad_rows_bf16_kernel(const WMulti mp) {
+  const WArgs& a = mp.a;
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+  constexpr int XPS = 64, XROW = (WPX + 2) * XPS;  // window: bytes per pixel (32 channels), per row (one zero pixel each side)
+  constexpr int DPS = 192, DROW = WPX * DPS;       // dy: bytes per pixel (64 columns + pad: see wgrad_kernel), per row
+  constexpr int XR = (WPX * 8 + 255) / 256, DR = (WPX * 16 + 255) / 256, KS = WPX / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char sX[4 * XROW];
+  __shared__ __attribute__((aligned(16))) unsigned char sD[2 * DROW > 4096 ? 2 * DROW : 4096];
+  const int groups = a.Ck >> 5;
+  int wi;
+  {  // XCD-contiguous work order (see wgrad_kernel): the channel groups of one (problem, row split) share their dy rows
+    const int G = (int)gridDim.x, b = (int)blockIdx.x, xcd = b & 7, slot = b >> 3, q = G >> 3, r = G & 7;
+    wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int cg = srx_uniform(wi % groups), rest = wi / groups;
+  const int prob = srx_uniform(rest % a.nprob), zsplit = srx_uniform(rest / a.nprob);
+  const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31, wn = wave & 1, th = wave >> 1;
+  const int rbeg = zsplit * a.rows_per_split / WPX;
+  const int rend = min(a.M, (zsplit + 1) * a.rows_per_split) / WPX;  // global image rows [rbeg, rend)
+  const int totrows = a.N * a.Hi;
+  const __amdgpu_buffer_rsrc_t rx_ = srx_rsrc(mp.x[prob], a.in_bytes), rd_ = srx_rsrc(mp.dy[prob], a.dy_bytes);
+  const bool want_bias = a.bslab != nullptr && cg == 0;  // workgroup-uniform
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  auto xload = [&](int gr, f32x4 (&v)[XR]) {
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+      const int idx = u * 256 + tid, px = idx >> 3, quad = idx & 7;
+      const bool ok = idx < WPX * 8 && (unsigned)gr < (unsigned)totrows;
+      v[u] = srx_bload(rx_, ok ? 4u * (unsigned)((gr * WPX + px) * a.Ci + 32 * cg + 4 * quad) : 0xffffffffu, 0);
+    }
+  };
+  auto xstore = [&](int gr, const f32x4 (&v)[XR]) {
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+      const int idx = u * 256 + tid, px = idx >> 3, quad = idx & 7;
+      if (idx >= WPX * 8) continue;
+      const bf16x4 pk = {(__bf16)v[u][0], (__bf16)v[u][1], (__bf16)v[u][2], (__bf16)v[u][3]};
+      *reinterpret_cast<bf16x4*>(sX + (gr & 3) * XROW + (px + 1) * XPS + 8 * quad) = pk;
+    }
+  };
+  auto dload = [&](int gr, f32x4 (&v)[DR]) {
+#pragma unroll
+    for (int u = 0; u < DR; ++u) {
+      const int idx = u * 256 + tid, px = idx >> 4, quad = idx & 15;
+      const bool ok = idx < WPX * 16 && (unsigned)gr < (unsigned)totrows;
+      v[u] = srx_bload(rd_, ok ? 4u * (unsigned)((gr * WPX + px) * a.Cd + 4 * quad) : 0xffffffffu, 0);
+    }
+  };
+  auto dstore = [&](int gr, const f32x4 (&v)[DR]) {
+#pragma unroll
+    for (int u = 0; u < DR; ++u) {
+      const int idx = u * 256 + tid, px = idx >> 4, quad = idx & 15;
+      if (idx >= WPX * 16) continue;
+      if (want_bias && gr < rend) bsum += v[u];  // (fp32 values, whatever the product precision)
+      const bf16x4 pk = {(__bf16)v[u][0], (__bf16)v[u][1], (__bf16)v[u][2], (__bf16)v[u][3]};
+      *reinterpret_cast<bf16x4*>(sD + (gr & 1) * DROW + px * DPS + 8 * quad) = pk;
+    }
+  };
+
+  f32x16 acc[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int li = lane & 15, colh = 16 * ((lane >> 4) & 1) + 4 * (li & 3), rq = li >> 2;
+
+  // taps T0 .. T0 + NT - 1 of output row gr
+  auto compute = [&](int gr, auto t0_c, auto nt_c) {
+    constexpr int T0 = decltype(t0_c)::value, NT = decltype(nt_c)::value;
+    const int ih = gr % a.Hi;
+    const unsigned char* dbase = sD + (gr & 1) * DROW + (8 * h + rq) * DPS + 2 * (32 * wn + colh);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const s16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dbase + (16 * s) * DPS));
+      const s16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dbase + (16 * s + 4) * DPS));
+      const s16x8 fd = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti) {
+        constexpr int dummy = 0; (void)dummy;
+        const int t = T0 + ti, ty = t / 3 - 1, tx = t % 3 - 1;
+        if ((unsigned)(ih + ty) >= (unsigned)a.Hi) continue;  // (wave-uniform) the row above / below lies outside the image
+        const unsigned char* xb = sX + ((gr + ty) & 3) * XROW + (16 * s + 8 * h + rq + tx + 1) * XPS + 2 * colh;
+        const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(xb));
+        const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(xb + 4 * XPS));
+        const s16x8 fx = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc[ti], 0, 0, 0);
+      }
+    }
+  };
+
+  // zero columns left and right of every window slot
+  if (tid < 32) {
+    const int slot = tid >> 3, side = (tid >> 2) & 1, part = tid & 3;
+    *reinterpret_cast<f32x4*>(sX + slot * XROW + (side ? (WPX + 1) * XPS : 0) + 16 * part) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 xa[XR], xb2[XR], xc[XR], da[DR];
+  xload(rbeg - 1, xa);
+  xload(rbeg, xb2);
+  xload(rbeg + 1, xc);
+  dload(rbeg, da);
+  xstore(rbeg - 1, xa);
+  xstore(rbeg, xb2);
+  xstore(rbeg + 1, xc);
+  dstore(rbeg, da);
+  xload(rbeg + 2, xa);
+  dload(rbeg + 1, da);
+  for (int gr = rbeg; gr < rend; ++gr) {
+    __syncthreads();  // rows gr - 1 .. gr + 1 and dy row gr are in LDS; the slots of x row gr - 2 and dy row gr - 1 are free
+    xstore(gr + 2, xa);
+    dstore(gr + 1, da);
+    xload(gr + 3, xa);
+    dload(gr + 2, da);
+    if (th == 0) compute(gr, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+    else compute(gr, std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+  }
+  const size_t slab_id = (size_t)prob * a.nsplit + zsplit;
+  float* slab = a.slab + slab_id * a.Cnw * a.Kw;
+#pragma unroll
+  for (int ti = 0; ti < 5; ++ti) {
+    const int t = 5 * th + ti;
+    if (t >= 9) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      slab[(size_t)row * a.Kw + t * a.Ck + 32 * cg + l31] = acc[ti][r];
+    }
+  }
+  if (want_bias) {  // 16 pixel lanes x 16 column quads -> 64 column sums of this row split
+    __syncthreads();  // (every wave is done with the dy slots)
+    f32x4* red = reinterpret_cast<f32x4*>(sD);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 16) {
+      f32x4 t = red[tid];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) t += red[r * 16 + tid];
+      *reinterpret_cast<f32x4*>(a.bslab + slab_id * a.Cnw + 4 * tid) = t;
     }
   }
 }
@@ -2003,11 +2175,24 @@ static int wgrad_multi_impl(const srx_conv2d_t* d, int nprob, int per_out, const
   dim3 grid((unsigned)(tiles * nprob * nsplit));
   const double wfl = 2.0 * a.M * d->Cout * a.K * nprob;
   char nm[112];
+  // bf16 products, 3x3 / stride 1 / pad 1, 64 output columns, whole 32-channel groups, image rows of 16 or 32 pixels
+  // (ESRGAN's dense blocks at the training crop size): the image-row kernel
+  static const bool no_rows = getenv("SRX_NO_WGRAD_ROWS") != nullptr;  // developer switch (A/B runs)
+  const bool rows_kernel = d->precision && !no_rows && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->shuffle &&
+                           d->Cout == 64 && a.Cnw == 64 && g.Ck % 32 == 0 && (d->W == 32 || d->W == 16) && g.Ho == d->H && g.Wo == d->W;
+  if (rows_kernel) {
+    grid = dim3((unsigned)((g.Ck / 32) * nprob * nsplit));
+    if (srx_prof_on()) snprintf(nm, sizeof(nm), "wgrad_rows_bf16_kernel<%d> MxNxK=%dx%dx%d x%d", d->W, a.M, d->Cout, a.K, nprob);
+    if (d->W == 32) SRX_LAUNCH_PROF(nm, wfl, wgrad_rows_bf16_kernel<32>, grid, dim3(256), 0, st, mp);
+    else SRX_LAUNCH_PROF(nm, wfl, wgrad_rows_bf16_kernel<16>, grid, dim3(256), 0, st, mp);
+    SRX_CHECK_LAUNCH("wgrad_rows_bf16_kernel");
+  } else {
   if (srx_prof_on())
     snprintf(nm, sizeof(nm), "wgrad_kernel<%d> MxNxK=%dx%dx%d x%d", d->precision ? 1 : 0, a.M, d->Cout, a.K, nprob);
   if (d->precision) SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<1>, grid, dim3(256), 0, st, mp);
   else SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<0>, grid, dim3(256), 0, st, mp);
   SRX_CHECK_LAUNCH("wgrad_kernel");
+  }
   const int64_t n = (int64_t)d->Cout * g.K;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)srx_cdiv(n, 256), (unsigned)nout), dim3(256), 0, st, ws,
                      nsplit * per_out, a.Cnw, a.Kw, g.K, g.Ck, d->Cout, d->Cin, d->KH, d->KW, g.cps, outs, accumulate,
