@@ -1627,6 +1627,32 @@ static int wgrad_nsplit(int M, int64_t tiles, int nprob, int Cnw, int Kw) {
   return (int)srx_cdiv(M, rps);
 }
 
+// bf16 products, 3x3 / stride 1 / pad 1, 64 output columns, whole 32-channel groups, image rows of 16 or 32 pixels (ESRGAN's
+// dense blocks at the training crop size): the image-row kernel (wgrad_rows_bf16_kernel)
+static bool wgrad_rows_ok(const srx_conv2d_t* d) {
+  static const bool off = getenv("SRX_NO_WGRAD_ROWS") != nullptr;  // developer switch (A/B runs)
+  if (off || !d->precision || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->shuffle || d->up == 2) return false;
+  return d->Cout == 64 && srx_roundup(d->Cin, 4) % 32 == 0 && (d->W == 32 || d->W == 16);
+}
+// row splits of the image-row kernel: workgroups = channel groups x problems x splits, four resident per CU
+static int wgrad_rows_nsplit(const srx_conv2d_t* d, int nprob) {
+  static int cus = 0;
+  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
+  const int groups = (int)srx_roundup(d->Cin, 4) / 32, rows = d->N * d->H;
+  int best = 1;
+  float best_cost = 1e30f;
+  for (int ns = 1; ns <= 32 && ns <= rows; ++ns) {
+    const int rps = (int)srx_cdiv(rows, ns);
+    if ((int)srx_cdiv(rows, rps) != ns) continue;
+    const int rounds = (int)srx_cdiv((int64_t)groups * nprob * ns, 4 * cus);
+    const float cost = rounds * (rps + 8.0f) + 0.25f * ns;  // (+ the slab reduction grows with the splits)
+    if (cost < best_cost) { best_cost = cost; best = ns; }
+  }
+  if (const char* e = getenv("SRX_WGRAD_ROWS_NSPLIT")) { const int v = atoi(e); if (v > 0 && v <= 64 && v <= rows) best = v; }
+  const int rps = (int)srx_cdiv(rows, best);
+  return (int)srx_cdiv(rows, rps);
+}
+
 extern "C" size_t srx_conv2d_bwd_weight_multi_ws_floats(const srx_conv2d_t* d, int nprob) {
   if (check_desc(d) || nprob < 1 || nprob > WG_MAXP) return 0;
   if (d->up == 2) { const srx_conv2d_t h = upsampled_desc(d); return nprob * upsampled_floats(d) + srx_conv2d_bwd_weight_multi_ws_floats(&h, nprob); }
@@ -1634,7 +1660,8 @@ extern "C" size_t srx_conv2d_bwd_weight_multi_ws_floats(const srx_conv2d_t* d, i
     return srx_thin_wgrad_ws_floats(d) + srx_colsum_ws_floats((int64_t)d->N * d->H * d->W, d->Cout);
   const Geo g = fwd_geo(d);
   const size_t Cnw = (size_t)srx_roundup(d->Cout, 64), Kw = (size_t)srx_roundup(g.K, 64);
-  const int ns = wgrad_nsplit(d->N * g.Ho * g.Wo, (int64_t)(Kw / 64) * (Cnw / 64), nprob, (int)Cnw, (int)Kw);
+  const int ns = wgrad_rows_ok(d) ? wgrad_rows_nsplit(d, nprob)
+                                  : wgrad_nsplit(d->N * g.Ho * g.Wo, (int64_t)(Kw / 64) * (Cnw / 64), nprob, (int)Cnw, (int)Kw);
   return Cnw * (Kw + 1) * (size_t)ns * nprob;  // one slab (+ one bias row) per problem and row split
 }
 
@@ -2154,8 +2181,9 @@ static int wgrad_multi_impl(const srx_conv2d_t* d, int nprob, int per_out, const
   }
   const int ntiles = a.Cnw / 64;
   const int64_t tiles = (int64_t)a.ktiles * ntiles;
-  const int nsplit = wgrad_nsplit(a.M, tiles, nprob, a.Cnw, a.Kw);
-  a.rows_per_split = (int)srx_roundup(srx_cdiv(a.M, nsplit), 32);
+  const bool rows_kernel = wgrad_rows_ok(d);
+  const int nsplit = rows_kernel ? wgrad_rows_nsplit(d, nprob) : wgrad_nsplit(a.M, tiles, nprob, a.Cnw, a.Kw);
+  a.rows_per_split = rows_kernel ? (int)srx_cdiv(d->N * d->H, nsplit) * d->W : (int)srx_roundup(srx_cdiv(a.M, nsplit), 32);
   a.nsplit = nsplit;
   a.nprob = nprob;
   const size_t nslabs = (size_t)nsplit * nprob;
@@ -2175,11 +2203,6 @@ static int wgrad_multi_impl(const srx_conv2d_t* d, int nprob, int per_out, const
   dim3 grid((unsigned)(tiles * nprob * nsplit));
   const double wfl = 2.0 * a.M * d->Cout * a.K * nprob;
   char nm[112];
-  // bf16 products, 3x3 / stride 1 / pad 1, 64 output columns, whole 32-channel groups, image rows of 16 or 32 pixels
-  // (ESRGAN's dense blocks at the training crop size): the image-row kernel
-  static const bool no_rows = getenv("SRX_NO_WGRAD_ROWS") != nullptr;  // developer switch (A/B runs)
-  const bool rows_kernel = d->precision && !no_rows && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->shuffle &&
-                           d->Cout == 64 && a.Cnw == 64 && g.Ck % 32 == 0 && (d->W == 32 || d->W == 16) && g.Ho == d->H && g.Wo == d->W;
   if (rows_kernel) {
     grid = dim3((unsigned)((g.Ck / 32) * nprob * nsplit));
     if (srx_prof_on()) snprintf(nm, sizeof(nm), "wgrad_rows_bf16_kernel<%d> MxNxK=%dx%dx%d x%d", d->W, a.M, d->Cout, a.K, nprob);
