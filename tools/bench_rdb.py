@@ -22,6 +22,19 @@ bufs = [torch.randn(n, h, w, 192, device=dev) for _ in range(4)]
 biases = (C.c_void_p * 5)(*[t.data_ptr() for t in bs])
 
 
+pkb = torch.empty(per * nb, dtype=torch.uint8, device=dev)
+_lib.call('srx_rdb_pack_bwd', table.data_ptr(), nb, pkb.data_ptr(), s)
+gbufs = [torch.empty(n, h, w, 192, device=dev) for _ in range(2)]
+dys = [torch.randn(n, h, w, 64, device=dev) for _ in range(2)]
+
+
+def chain_bwd():
+    s = torch.cuda.current_stream().cuda_stream
+    for i in range(nb):
+        _lib.call('srx_rdb_bwd', n, h, w, dys[i % 2].data_ptr(), 64, 0.2, bufs[i % 4].data_ptr(), 192, pkb.data_ptr() + i * per, 0.2,
+                  gbufs[i % 2].data_ptr(), 192, dys[i % 2].data_ptr(), 64, 1.0, None, 0, dys[(i + 1) % 2].data_ptr(), 64, s)
+
+
 def chain():
     s = torch.cuda.current_stream().cuda_stream  # (the capture stream inside torch.cuda.graph)
     for i in range(nb):
@@ -29,20 +42,21 @@ def chain():
                   bufs[(i + 1) % 4].data_ptr(), 192, s)
 
 
-chain()
-torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    chain()
-for _ in range(3):
-    g.replay()
-torch.cuda.synchronize()
-ts = []
-for _ in range(10):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); g.replay(); e1.record(); e1.synchronize()
-    ts.append(e0.elapsed_time(e1) * 1e3 / nb)
-ts.sort()
 gf = 2.0 * n * h * w * 9 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64) / 1e9
-print(f'rdb_fwd: {ts[len(ts) // 2]:.2f} us per block in-graph (min {ts[0]:.2f}); {gf:.3f} GFLOP -> {gf / ts[len(ts) // 2] * 1e3:.1f} TFLOP/s')
+for name, fn in (('rdb_fwd', chain), ('rdb_bwd', chain_bwd)):
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(10):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / nb)
+    ts.sort()
+    print(f'{name}: {ts[len(ts) // 2]:.2f} us per block in-graph (min {ts[0]:.2f}); {gf:.3f} GFLOP -> {gf / ts[len(ts) // 2] * 1e3:.1f} TFLOP/s')
 

@@ -195,8 +195,27 @@ __device__ __forceinline__ void mma_unit(const unsigned char* lds, Wave& w) {
 // stage K < 5.  Forward: bias + LeakyReLU; backward: the LeakyReLU mask of c_{5-K} (read from the saved buffer, halo pixels
 // included).  bf16 to the LDS image of source K + 1 (zeros outside the image), fp32 to the block's buffer / gradient buffer
 // (tile centre only: the halo belongs to the neighbouring workgroups)
+// backward: the saved activations c_{5-K} at this wave's stage-K pixels (their signs are the LeakyReLU masks), requested
+// before the stage's last unit is multiplied so that the epilogue does not wait for them (clamped addresses: every lane
+// loads, out-of-image lanes discard)
+template <int K>
+__device__ __forceinline__ void load_masks(const RdbArgs& a, const Wave& w, f32x4 (&m)[2][4]) {
+  constexpr int WK = reg_w(K), RK = WK * WK, ORG = reg_org(K), TPW = tpw<K>(), CH = 64 + 32 * (4 - K);
+  int mt0, nt, cnt;
+  job<K>(w.wave, mt0, nt, cnt);
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int q = min((mt0 + i) * 32 + w.l31, RK - 1);
+    const int qy = q / WK, qx = q - qy * WK;
+    const int iy = min(max(w.ty0 + qy + ORG, 0), a.H - 1), ix = min(max(w.tx0 + qx + ORG, 0), a.W - 1);
+    const float* mp = a.buf + ((size_t)(w.n_img * a.H + iy) * a.W + ix) * a.bld + CH + 4 * w.h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) m[i][g] = *reinterpret_cast<const f32x4*>(mp + 8 * g);
+  }
+}
+
 template <int K, bool BWD>
-__device__ __forceinline__ void epilogue_mid(const RdbArgs& a, unsigned char* lds, Wave& w) {
+__device__ __forceinline__ void epilogue_mid(const RdbArgs& a, unsigned char* lds, Wave& w, const f32x4 (&masks)[2][4]) {
   constexpr int WK = reg_w(K), RK = WK * WK, ORG = reg_org(K), TPW = tpw<K>();
   constexpr int CH = BWD ? 64 + 32 * (4 - K) : 64 + 32 * (K - 1);  // channel slot of this stage's tensor in buf / gout
   int mt0, nt, cnt;
@@ -220,19 +239,13 @@ __device__ __forceinline__ void epilogue_mid(const RdbArgs& a, unsigned char* ld
     float* gp = (BWD ? a.gout + pix * a.gld : a.buf + pix * a.bld) + CH + 4 * w.h;
     unsigned char* cp = lds + src_off(K + 1) + q * 64 + 8 * w.h;
     const int psw = (q >> 2) & 3;
-    f32x4 m[4];
-    if constexpr (BWD) {  // (clamped address: every lane loads, out-of-image lanes discard)
-      const float* mp = a.buf + pix * a.bld + CH + 4 * w.h;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) m[g] = *reinterpret_cast<const f32x4*>(mp + 8 * g);
-    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if constexpr (BWD) {
-          v[e] = m[g][e] > 0.f ? w.acc[i][4 * g + e] : w.acc[i][4 * g + e] * a.slope;
+          v[e] = masks[i][g][e] > 0.f ? w.acc[i][4 * g + e] : w.acc[i][4 * g + e] * a.slope;
         } else {
           const float z = w.acc[i][4 * g + e] + b[g][e];
           v[e] = z > 0.f ? z : z * a.slope;
@@ -316,9 +329,11 @@ __device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, 
         for (int r = 0; r < 16; ++r) w.acc[i][r] = 0.f;
     }
     if constexpr (U == unit_first(5)) load_skip<BWD>(a, w, xs, ex);
+    f32x4 masks[2][4];
+    if constexpr (BWD && S == K && K < 5) load_masks<K>(a, w, masks);
     mma_unit<K, S, U>(lds, w);
     if constexpr (S == K) {  // last source of stage K
-      if constexpr (K < 5) epilogue_mid<K, BWD>(a, lds, w);
+      if constexpr (K < 5) epilogue_mid<K, BWD>(a, lds, w, masks);
       else epilogue_out<BWD>(a, lds, w, xs, ex);
     }
   }
