@@ -41,9 +41,18 @@ def test_tiled_inference_equals_untiled(dev):
                 m.running_var.uniform_(0.5, 1.5)
     lr = torch.rand(1, 3, 150, 210, device=dev)
     whole = upscale(gen, lr, max_tile_pixels=10 ** 9)
-    tiled = upscale(gen, lr, halo=48, max_tile_pixels=150 * 110)
+    tiled = upscale(gen, lr, halo=48, max_tile_pixels=150 * 110, staged=False)  # halo tiles of the whole generator
     assert whole.shape == (1, 3, 600, 840)
     assert (whole - tiled).abs().max().item() <= 1e-4 * whole.abs().max().item()
+    # the two-stage form (trunk on the whole image, last sub-pixel layer + conv3 on row strips with head_halo rows around):
+    # 150 * 24 * 16 output pixels per strip -> feature strips of 82 rows, four of them
+    staged = upscale(gen, lr, max_tile_pixels=150 * 24)
+    assert staged.shape == whole.shape
+    assert (whole - staged).abs().max().item() <= 1e-5 * whole.abs().max().item()
+    for p in ('fp32', 'bf16'):  # and at either precision it is the same arithmetic as the untiled call
+        a = upscale(gen, lr, max_tile_pixels=10 ** 9, precision=p)
+        b = upscale(gen, lr, max_tile_pixels=150 * 24, precision=p)
+        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item(), p
 
 
 def test_1080p_inference_windows_vs_oracle(dev):

@@ -4,6 +4,7 @@
 
   rt36     : the north-star kernel, 3x3 64->64 forward at 16x24x24 (66 launches per GAN step)
   wgrad33  : the grouped weight gradient of the generator's 33 residual convs (one launch per step)
+  wgrad256 : the weight gradient of the discriminator's 128->256 conv at 32x24x24 (M 18432 N 256 K 1152)
   vgg256   : 3x3 256->256 at 32x24x24 -- the VGG19 block-3 layers with source and target as one batch
   vgg256h  : the same at 16x24x24 (its data gradient: source half only)
   vgg512   : 3x3 512->512 at 32x12x12 (VGG19 block 4, M 4608 N 512 K 4608);  vgg512h: at 16x12x12 (M 2304)
@@ -32,16 +33,17 @@ if name in SHAPES:
     with torch.no_grad():
         for _ in range(reps):
             conv(x)
-elif name == 'wgrad33':
-    d = _lib.Conv2dDesc(16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
-    xs = [torch.rand(16, 24, 24, 64, device=dev) for _ in range(33)]
-    dys = [torch.rand(16, 24, 24, 64, device=dev) for _ in range(33)]
-    dws = [torch.zeros(64, 64, 3, 3, device=dev) for _ in range(33)]
+elif name in ('wgrad33', 'wgrad256'):
+    nprob, (n, h, w, cin, cout) = (33, (16, 24, 24, 64, 64)) if name == 'wgrad33' else (1, (32, 24, 24, 128, 256))
+    d = _lib.Conv2dDesc(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
+    xs = [torch.rand(n, h, w, cin, device=dev) for _ in range(nprob)]
+    dys = [torch.rand(n, h, w, cout, device=dev) for _ in range(nprob)]
+    dws = [torch.zeros(cout, cin, 3, 3, device=dev) for _ in range(nprob)]
     arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
-    nws = _lib.lib().srx_conv2d_bwd_weight_multi_ws_floats(C.byref(d), 33)
+    nws = _lib.lib().srx_conv2d_bwd_weight_multi_ws_floats(C.byref(d), nprob)
     ws = torch.empty(nws, device=dev)
     for _ in range(reps):
-        _lib.call('srx_conv2d_bwd_weight_multi', C.byref(d), 33, 1, arr(xs), arr(dys), arr(dws), 1, None, ws.data_ptr(), nws,
+        _lib.call('srx_conv2d_bwd_weight_multi', C.byref(d), nprob, 1, arr(xs), arr(dys), arr(dws), 1, None, ws.data_ptr(), nws,
                   torch.cuda.current_stream().cuda_stream)
 else:
     sys.exit(f'unknown workload {name}')

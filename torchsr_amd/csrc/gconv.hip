@@ -893,9 +893,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WMulti mp) {
     }
     const float* cD = &sD[buf][h * 64 + wn * 32 + l31];
     const float* cX = &sX[buf][h * 64 + wk * 32 + l31];
+    // Operands run two MFMA pairs ahead of the multiplies (one ds_read2st64_b32 fetches a pair's d or x): left to itself
+    // the compiler read each pair right before its MFMAs and waited for it -- an LDS round trip per 128 MFMA cycles, which
+    // three waves per SIMD did not hide (PMC, round 3: MFMA pipe 54 % busy, 61 % of wave time in s_waitcnt)
+    float dv[16], xv[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cD[s * 128], cX[s * 128], acc, 0, 0, 0);
+    for (int s = 0; s < 16; ++s) { dv[s] = cD[s * 128]; xv[s] = cX[s * 128]; }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[s], xv[s], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
   };
   // every step issues the same four loads (rows past `mend` are pointed out of range and read 0), so
   // the prefetch waits are exact vmcnt counts -- see gconv_body

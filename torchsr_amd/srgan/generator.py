@@ -30,16 +30,32 @@ class Generator(nn.Module):
         self.conv_layers = nn.Sequential(*[SubpixelConvolutionLayer(64) for _ in range(num_conv_layers)])
         self.conv3 = Conv2d(64, 3, kernel_size=9, stride=1, padding=4)
 
+    # feature-map pixels (input of the last sub-pixel layer) a head tile must see beyond its border: 1 for that layer's
+    # 3x3 conv + 4 output pixels of conv3's 9x9 window = 2 feature pixels
+    head_halo = 4
+
+    def infer_trunk_nhwc(self, x4: Tensor) -> Tensor:
+        """Inference, first stage: NHWC ``[N,h,w,4]`` -> the 64-channel feature map that enters the LAST sub-pixel layer
+        (``[N,s*h/2,s*w/2,64]``): conv1, the residual tower, conv2 + skip and all sub-pixel layers but the last.  33 of the
+        36 convs; their receptive field (radius 38 pixels) is why ``test.upscale`` runs this stage on the whole image."""
+        f = self.__dict__.get('_folded')
+        if f is None:
+            f = self.__dict__.setdefault('_folded', (F.FoldedConv(self.conv1[0], None, self.conv1[1]),
+                                                     F.FoldedConv(self.conv2[0], self.conv2[1], None)))
+        conv1 = f[0](x4)
+        out = f[1](self.blocks(conv1), residual=conv1)
+        for layer in list(self.conv_layers)[:-1]:
+            out = layer(out)
+        return out
+
+    def infer_head_nhwc(self, feat: Tensor) -> Tensor:
+        """Inference, second stage: feature map (or a tile of it with ``head_halo`` pixels around) -> NHWC image."""
+        return self.conv3(self.conv_layers[-1](feat))
+
     def forward_nhwc(self, x4: Tensor) -> Tensor:
         """NHWC ``[N,h,w,4]`` -> NHWC ``[N,s*h,s*w,4]`` (4th channel zero)."""
         if F.inference_mode(self):
-            f = self.__dict__.get('_folded')
-            if f is None:
-                f = self.__dict__.setdefault('_folded', (F.FoldedConv(self.conv1[0], None, self.conv1[1]),
-                                                         F.FoldedConv(self.conv2[0], self.conv2[1], None)))
-            conv1 = f[0](x4)
-            out = f[1](self.blocks(conv1), residual=conv1)
-            return self.conv3(self.conv_layers(out))
+            return self.infer_head_nhwc(self.infer_trunk_nhwc(x4))
         conv1 = self.conv1[1](self.conv1[0](x4))
         if len(self.blocks) and all(F.residual_block_fused_ok(b) for b in self.blocks):
             block = F.residual_tower(conv1, self.blocks)  # training under a trainer: the whole chain is one autograd node
