@@ -1615,11 +1615,10 @@ extern "C" size_t srx_conv2d_bwd_data_ws_floats(const srx_conv2d_t* d) {
   return plan_ws_floats(bwd_plan(d, cls[0]));  // (also covers srx_conv2d_bwd_data_act, which never takes the row-tile path)
 }
 
-// Row splits of a (group of) weight-gradient problem(s): the slabs cost a write + a read each, a workgroup alone on
-// its CU runs latency-bound (~1 us per 32-row chunk, ~0.65 us with four co-resident), and workgroup counts just
-// above a multiple of the CU count leave a nearly empty last round.  Calibrated on the SRGAN layer shapes
-// (tools/bench_kernels.py --graph); SRX_WGRAD_NSPLIT overrides for experiments.
-static int wgrad_nsplit(int M, int64_t tiles, int nprob, int Cnw, int Kw) {
+// Row splits of a (group of) weight-gradient problem(s): the slabs cost a write + a read each, and workgroup counts just
+// above a whole round of resident workgroups leave a nearly empty last round.  Calibrated on the SRGAN layer shapes
+// (bf16: tools/bench_kernels.py --graph, round 1; fp32: tools/wgrad_sweep.sh, round 3); SRX_WGRAD_NSPLIT overrides for experiments.
+static int wgrad_nsplit(int M, int64_t tiles, int nprob, int Cnw, int Kw, int precision) {
   static int cus = 0;
   if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
   const int max_by_rows = (int)srx_cdiv(M, 128);  // at least 128 rows per split
@@ -1628,9 +1627,19 @@ static int wgrad_nsplit(int M, int64_t tiles, int nprob, int Cnw, int Kw) {
   for (int ns = 1; ns <= 64 && ns <= max_by_rows; ++ns) {
     const int rps = (int)srx_roundup(srx_cdiv(M, ns), 32);
     if ((int)srx_cdiv(M, rps) != ns) continue;  // not reachable after rounding to whole chunks
-    const int L = (int)srx_cdiv(tiles * nprob * ns, cus);
-    const float hide = L >= 4 ? 0.65f : (L == 3 ? 0.7f : (L == 2 ? 0.8f : 1.0f));
-    const float cost = 1.07f * L * (rps / 32 + 6) * hide + (float)nprob * ns * Cnw * Kw * 8.0f / 3.0e6f;
+    float cost;
+    if (precision == 0) {
+      // fp32 (round 3, least-squares fit of 57 in-graph timings of the SRGAN layer shapes, `tools/wgrad_sweep.sh`, rms 4.7 us):
+      // three workgroups are resident per CU (VGPRs); a round of three takes 1.70 us per 32-row chunk, a last round of two
+      // 1.18 us, of one 0.63 us -- so a workgroup count just ABOVE a multiple of three per CU pays a whole extra round
+      // (73728 x 128 x 576: 111 us with 42 splits = 2.95 per CU, 146 us with 43) -- plus 3.5 chunks of fill per round.
+      const int w = (int)srx_cdiv(tiles * nprob * ns, cus), f = w / 3, r = w - 3 * f;
+      cost = (rps / 32 + 3.5f) * (f * 1.696f + (r == 1 ? 0.633f : r == 2 ? 1.177f : 0.f)) + (float)nprob * ns * Cnw * Kw * 8.0f / 50.0e6f;
+    } else {
+      const int L = (int)srx_cdiv(tiles * nprob * ns, cus);
+      const float hide = L >= 4 ? 0.65f : (L == 3 ? 0.7f : (L == 2 ? 0.8f : 1.0f));
+      cost = 1.07f * L * (rps / 32 + 6) * hide + (float)nprob * ns * Cnw * Kw * 8.0f / 3.0e6f;
+    }
     if (cost < best_cost) { best_cost = cost; nsplit = ns; }
   }
   if (const char* e = getenv("SRX_WGRAD_NSPLIT")) { const int v = atoi(e); if (v > 0 && v <= 64 && v <= max_by_rows) nsplit = v; }
@@ -1672,7 +1681,7 @@ extern "C" size_t srx_conv2d_bwd_weight_multi_ws_floats(const srx_conv2d_t* d, i
   const Geo g = fwd_geo(d);
   const size_t Cnw = (size_t)srx_roundup(d->Cout, 64), Kw = (size_t)srx_roundup(g.K, 64);
   const int ns = wgrad_rows_ok(d) ? wgrad_rows_nsplit(d, nprob)
-                                  : wgrad_nsplit(d->N * g.Ho * g.Wo, (int64_t)(Kw / 64) * (Cnw / 64), nprob, (int)Cnw, (int)Kw);
+                                  : wgrad_nsplit(d->N * g.Ho * g.Wo, (int64_t)(Kw / 64) * (Cnw / 64), nprob, (int)Cnw, (int)Kw, d->precision);
   return Cnw * (Kw + 1) * (size_t)ns * nprob;  // one slab (+ one bias row) per problem and row split
 }
 
@@ -2193,7 +2202,7 @@ static int wgrad_multi_impl(const srx_conv2d_t* d, int nprob, int per_out, const
   const int ntiles = a.Cnw / 64;
   const int64_t tiles = (int64_t)a.ktiles * ntiles;
   const bool rows_kernel = wgrad_rows_ok(d);
-  const int nsplit = rows_kernel ? wgrad_rows_nsplit(d, nprob) : wgrad_nsplit(a.M, tiles, nprob, a.Cnw, a.Kw);
+  const int nsplit = rows_kernel ? wgrad_rows_nsplit(d, nprob) : wgrad_nsplit(a.M, tiles, nprob, a.Cnw, a.Kw, d->precision);
   a.rows_per_split = rows_kernel ? (int)srx_cdiv(d->N * d->H, nsplit) * d->W : (int)srx_roundup(srx_cdiv(a.M, nsplit), 32);
   a.nsplit = nsplit;
   a.nprob = nprob;
