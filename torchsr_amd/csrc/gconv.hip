@@ -647,33 +647,59 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const GArgs a) {
     for (int e = 0; e < 4; ++e) bv[e] = (col + e < a.Cn) ? a.bias[col + e] : 0.f;
   }
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  // All loads first, without branches around them (rows past the tile or the image read a valid row and are dropped
+  // afterwards): the K-split partials four at a time, the addend and the mask -- the launch is a few load round trips long,
+  // and a load behind a data-dependent branch or a runtime-count loop waits for the one before it (8 -> ~5 us per launch).
+  // The partials are added in the order z = 0, 1, 2, ... as before.
+  constexpr int NR = (BM + 63) / 64;
+  f32x4 v[NR], av[NR], mv[NR];
+  bool ok[NR];
+  const bool has_add = a.add != nullptr && col < a.Cs && col < a.add_hi;
+  const bool has_mask = a.mask != nullptr && col < a.Cs && col >= a.mask_lo && col < a.mask_hi;
 #pragma unroll
-  for (int r = rl; r < BM; r += 64) {
-    const int m = m0 + r;
-    if (m < a.M) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(slab + r * BN + lc);
-      for (int z = 1; z < a.tail_split; ++z)
-        v += *reinterpret_cast<const f32x4*>(slab + (size_t)z * (BM * BN) + r * BN + lc);
-      v += bv;
-      s1 += v;
-      s2 += v * v;
+  for (int j = 0; j < NR; ++j) {
+    const int r = rl + 64 * j;
+    ok[j] = r < BM && m0 + r < a.M;
+    const int mc = min(m0 + (r < BM ? r : rl), a.M - 1);
+    av[j] = has_add ? *reinterpret_cast<const f32x4*>(a.add + (size_t)mc * a.add_ld + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    mv[j] = has_mask ? *reinterpret_cast<const f32x4*>(a.mask + (size_t)mc * a.Co + col) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int z0 = 0; z0 < a.tail_split; z0 += 4) {
+    f32x4 t[NR][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+    for (int j = 0; j < NR; ++j) {
+      const int rc = rl + 64 * j < BM ? rl + 64 * j : rl;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        t[j][u] = *reinterpret_cast<const f32x4*>(slab + (size_t)min(z0 + u, a.tail_split - 1) * (BM * BN) + rc * BN + lc);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (z0 + u < a.tail_split) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) v[j] = (z0 + u == 0) ? t[j][u] : v[j] + t[j][u];
       }
-      if (col < a.Cs) {  // Cs is a multiple of 4
-        f32x4* o = reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col);
-        if (a.add) {  // (add_hi is a multiple of 4 or covers every column)
-          v = v * a.oscale;
-          if (col < a.add_hi) v += *reinterpret_cast<const f32x4*>(a.add + (size_t)m * a.add_ld + col) * a.ascale;
-        }
-        if (a.mask && col >= a.mask_lo && col < a.mask_hi) {  // (mask ranges are whole quads: channel counts are multiples of 4)
-          const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + (size_t)m * a.Co + col);
+  }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : v[e] * a.mask_slope;
-        }
-        *o = v;
+  for (int j = 0; j < NR; ++j) {
+    if (!ok[j]) continue;
+    const int m = m0 + rl + 64 * j;
+    f32x4 w = v[j] + bv;
+    s1 += w;
+    s2 += w * w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = w[e] > 0.f ? w[e] : w[e] * a.slope;
+    if (col < a.Cs) {  // Cs is a multiple of 4
+      if (a.add) {  // (add_hi is a multiple of 4 or covers every column)
+        w = w * a.oscale;
+        if (col < a.add_hi) w += av[j] * a.ascale;
       }
+      if (has_mask) {  // (mask ranges are whole quads: channel counts are multiples of 4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = mv[j][e] > 0.f ? w[e] : w[e] * a.mask_slope;
+      }
+      *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col) = w;
     }
   }
   if (a.part) {
