@@ -185,7 +185,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   const int64_t rend = min(M, rbeg + rpb);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (rl < nrl && q < cq)
-    for (int64_t r = rbeg + rl; r < rend; r += nrl) s += *reinterpret_cast<const f32x4*>(x + r * Cs + q * 4);
+    for (int64_t r = rbeg + rl; r < rend; r += 4 * nrl) {  // four rows per trip, loads first (one L2 round trip per four rows)
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + min(r + u * nrl, rend - 1) * Cs + q * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + u * nrl < rend) s += v[u];
+    }
   red[tid] = s;
   __syncthreads();
   if (tid < qpb && q < cq) {
@@ -201,7 +208,14 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int rows, in
   const int lane = threadIdx.x & 63;
   if (c >= C) return;
   double s = 0.0;
-  for (int r = lane; r < rows; r += 64) s += (double)part[(size_t)r * C4 + c];
+  for (int r = lane; r < rows; r += 256) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = part[(size_t)min(r + 64 * u, rows - 1) * C4 + c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r + 64 * u < rows) s += (double)v[u];
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;

@@ -62,7 +62,14 @@ __global__ void linear_fwd_final_kernel(const float* __restrict__ part, int nspl
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)B * J) return;
   float s = 0.f;
-  for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * B * J + i];
+  for (int z = 0; z < nsplit; z += 8) {  // eight partials per trip, loads first (same order of additions)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)min(z + u, nsplit - 1) * B * J + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (z + u < nsplit) s += v[u];
+  }
   if (bias) s += bias[i % J];
   if (act == SRX_ACT_RELU) s = fmaxf(s, 0.f);
   else if (act == SRX_ACT_LRELU) s = s > 0.f ? s : s * slope;
@@ -119,7 +126,14 @@ __global__ void sum_slabs_kernel(const float* __restrict__ part, int nsplit, int
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i * 4 >= n) return;
   f32x4 s = *reinterpret_cast<const f32x4*>(part + i * 4);
-  for (int z = 1; z < nsplit; ++z) s += *reinterpret_cast<const f32x4*>(part + (size_t)z * n + i * 4);
+  for (int z = 1; z < nsplit; z += 4) {  // four slabs per trip, loads first (same order of additions)
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(part + (size_t)min(z + u, nsplit - 1) * n + i * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (z + u < nsplit) s += v[u];
+  }
   *reinterpret_cast<f32x4*>(out + i * 4) = s;
 }
 

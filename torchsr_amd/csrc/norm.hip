@@ -41,10 +41,13 @@ __global__ __launch_bounds__(256) void bn_partial_stats_kernel(const float* __re
   const int64_t rend = min(M, rbeg + rows_per_block(M));
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   if (rl < nrl) {
-    for (int64_t r = rbeg + rl; r < rend; r += nrl) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + q * 4);
-      s += v;
-      s2 += v * v;
+    for (int64_t r = rbeg + rl; r < rend; r += 4 * nrl) {  // four rows per trip, loads first (see bn_finalize_kernel)
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(y + min(r + u * nrl, rend - 1) * C + q * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + u * nrl < rend) { s += v[u]; s2 += v[u] * v[u]; }
     }
   }
   red[0][tid] = s;
@@ -162,17 +165,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + goff + q * 4);
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
     const f32x4 b = *reinterpret_cast<const f32x4*>(beta + q * 4);
-    for (int64_t r = rbeg + rl; r < rend; r += nrl) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + q * 4);
-      const f32x4 d = *reinterpret_cast<const f32x4*>(dout + r * C + q * 4);
+    for (int64_t r = rbeg + rl; r < rend; r += 4 * nrl) {  // four rows per trip, all eight loads before the first use
+      f32x4 vv[4], dd[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float xh = (v[e] - mu[e]) * is[e];
-        const float z = xh * g[e] + b[e];
-        const float dz = d[e] * act_grad(z, act, slope);
-        s[e] += dz;
-        s2[e] += dz * xh;
-        if (act == SRX_ACT_PRELU && !(z > 0.f)) sp += d[e] * z;
+      for (int u = 0; u < 4; ++u) {
+        const int64_t rr = min(r + u * nrl, rend - 1);
+        vv[u] = *reinterpret_cast<const f32x4*>(y + rr * C + q * 4);
+        dd[u] = *reinterpret_cast<const f32x4*>(dout + rr * C + q * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r + u * nrl >= rend) continue;
+        const f32x4 v = vv[u], d = dd[u];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (v[e] - mu[e]) * is[e];
+          const float z = xh * g[e] + b[e];
+          const float dz = d[e] * act_grad(z, act, slope);
+          s[e] += dz;
+          s2[e] += dz * xh;
+          if (act == SRX_ACT_PRELU && !(z > 0.f)) sp += d[e] * z;
+        }
       }
     }
   }
