@@ -1826,27 +1826,43 @@ __global__ void pack_table_kernel(const PackRec* __restrict__ table) {
     r.dst[idx] = v;
     return;
   }
-  const int row = (int)(idx / r.Kp), k = (int)(idx - (int64_t)row * r.Kp);
-  if (k < r.K) {
-    const int tap = k / r.Ck, c = k - tap * r.Ck;
-    if (r.kind == 0) {
-      if (row < r.Cout && c < r.Cin) {
-        int co = row;
-        if (r.cps) { const int ij = row / r.cps, cc = row - ij * r.cps; co = cc * 4 + ij; }
-        const int kh = tap / r.KW, kw = tap - kh * r.KW;
-        v = r.w[(((size_t)co * r.Cin + c) * r.KH + kh) * r.KW + kw];
-      }
-    } else {
-      if (row < r.Cin && c < r.Cout) {
-        const int th = tap / r.ntw, tw = tap - th * r.ntw;
-        const int kh = r.ph + r.pad - r.stride * (r.dminh + th), kw = r.pw + r.pad - r.stride * (r.dminw + tw);
-        int co = c;
-        if (r.cps) { const int ij = c / r.cps, cc = c - ij * r.cps; co = cc * 4 + ij; }
-        v = r.w[(((size_t)co * r.Cin + row) * r.KH + kh) * r.KW + kw];
-      }
+  // One thread per (packed row, channel): it reads the channel's taps -- adjacent floats of the OIHW weight, so a wave reads one
+  // contiguous stretch once -- and writes each to its k = tap * Ck + channel (a wave: 256 contiguous bytes per tap).  One thread
+  // per DESTINATION element made every tap's wave pull the same lines through the L2 again (9x the weight bytes for 3x3).
+  // The threads behind the (row, channel) range zero the K .. Kp padding.
+  const int taps = r.K / r.Ck;  // K = taps * Ck
+  const int64_t nmain = (int64_t)r.rows * r.Ck;
+  if (idx >= nmain) {
+    const int padk = r.Kp - r.K;
+    const int64_t j = idx - nmain;
+    if (padk > 0 && j < (int64_t)r.rows * padk) {
+      const int row = (int)(j / padk);
+      r.dst[(size_t)row * r.Kp + r.K + (int)(j - (int64_t)row * padk)] = 0.f;
     }
+    return;
   }
-  r.dst[idx] = v;
+  const int row = (int)(idx / r.Ck), c = (int)(idx - (int64_t)row * r.Ck);
+  float* d = r.dst + (size_t)row * r.Kp + c;
+  const bool live = r.kind == 0 ? (row < r.Cout && c < r.Cin) : (row < r.Cin && c < r.Cout);
+  int co = r.kind == 0 ? row : c;  // the conv's output channel this element belongs to
+  if (r.cps) { const int ij = co / r.cps, cc = co - ij * r.cps; co = cc * 4 + ij; }
+  const float* src = r.w + ((size_t)co * r.Cin + (r.kind == 0 ? c : row)) * (r.KH * r.KW);
+  for (int t0 = 0; t0 < taps; t0 += 9) {
+    float v[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int tap = min(t0 + u, taps - 1);
+      int off = tap;  // forward: k runs over (kh, kw) in the weight's own order
+      if (r.kind == 1) {
+        const int th = tap / r.ntw, tw = tap - th * r.ntw;
+        off = (r.ph + r.pad - r.stride * (r.dminh + th)) * r.KW + (r.pw + r.pad - r.stride * (r.dminw + tw));
+      }
+      v[u] = live ? src[off] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 9; ++u)
+      if (t0 + u < taps) d[(size_t)(t0 + u) * r.Ck] = v[u];
+  }
 }
 
 extern "C" size_t srx_pack_table_bytes(int n_layers) { return (size_t)n_layers * 17 * sizeof(PackRec); }
@@ -1875,7 +1891,7 @@ extern "C" int srx_pack_table_build(const srx_conv2d_t* descs, int n, const floa
       PackRec r = base; r.kind = 2; r.dst = wpk_fwd[i]; r.n_elems = 4LL * d->KH * d->KW * 64; emit(r);
     } else {
       PackRec r = base; r.kind = 0; r.dst = wpk_fwd[i]; r.rows = g.Cnp; r.K = g.K; r.Kp = g.Kp; r.Ck = g.Ck; r.ntw = 1;
-      r.n_elems = (long long)g.Cnp * g.Kp; emit(r);
+      r.n_elems = (long long)g.Cnp * (g.Ck + g.Kp - g.K); emit(r);  // work items: (row, channel) pairs + the K..Kp padding
     }
     if (!wpk_bwd[i]) continue;
     if (srx_thin_dgrad_applicable(d)) {
@@ -1892,7 +1908,7 @@ extern "C" int srx_pack_table_build(const srx_conv2d_t* descs, int n, const floa
       r.rows = Cnp; r.K = cls[c].K; r.Kp = cls[c].Kp; r.Ck = bwd_ck(d);
       r.ph = cls[c].ph; r.pw = cls[c].pw; r.dminh = cls[c].dminh; r.dminw = cls[c].dminw;
       r.ntw = cls[c].ntw > 0 ? cls[c].ntw : 1;
-      r.n_elems = (long long)Cnp * cls[c].Kp;
+      r.n_elems = (long long)Cnp * (r.Ck + cls[c].Kp - cls[c].K);
       emit(r);
     }
   }
