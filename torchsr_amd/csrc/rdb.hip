@@ -397,40 +397,58 @@ __global__ __launch_bounds__(NTHREADS) void rdb_kernel(const RdbArgs a) {
   run_units<0, BWD>(a, lds, w, tid, xs, ex);
 }
 
-// OIHW fp32 weights of every block's five convs -> the bf16 unit streams rdb_kernel reads (one thread per 16 bytes).
+// OIHW fp32 weights of every block's five convs -> the bf16 unit streams rdb_kernel reads.  One thread per (row, 8 channels)
+// of a unit: it reads the nine taps of its eight (input or output) channels -- forward 72 adjacent floats, backward eight runs
+// of nine -- and writes the nine 16-byte pieces, one per tap.  (One thread per 16 destination bytes made the nine taps' threads
+// pull the same lines through the L2 nine times: 66 us per launch for 66 MB of weights.)
 // bwd = 0: stage K = conv K, rows = its output channels, k = the source's 32 input channels, taps as stored.
 // bwd = 1: stage K, source S: the conv is k = 5 (S < 2: its output channels 32 S ..) or 6 - S; rows = the INPUT channels of
 // that conv that make up the stage's slice (c_{5-K}, or x for K = 5), k = 32 of its output channels, taps flipped.
 __global__ void rdb_pack_kernel(const float* const* __restrict__ wtab, unsigned char* __restrict__ dst, int nblk, int bwd) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  constexpr int per_blk = PACKED_BYTES / 16;
+  constexpr int per_blk = PACKED_BYTES / (16 * 9);  // (a unit is 9 taps x rows x 64 bytes)
   if (gid >= (int64_t)nblk * per_blk) return;
   const int blk = (int)(gid / per_blk);
-  int c = (int)(gid - (int64_t)blk * per_blk) * 16;  // byte offset in the block's stream
+  int c = (int)(gid - (int64_t)blk * per_blk) * (16 * 9);  // byte offset of the unit + 144 x (item in the unit)
   int u = 0;
 #pragma unroll 1
   while (u + 1 < NUNITS && c >= unit_off(u + 1)) ++u;
   const int K = unit_conv(u), S = u - unit_first(K), NK = conv_n(K);
-  c -= unit_off(u);
-  const int t = c / (NK * 64);
-  c -= t * NK * 64;
-  const int n = c / 64, js = (c & 63) >> 4;
+  const int item = (c - unit_off(u)) / (16 * 9);
+  const int n = item >> 2, js = item & 3;
   const int j = js ^ ((n >> 2) & 3);  // logical quad stored in this position
-  bf16x8 pk;
+  float v[8][9];                      // [channel][tap as stored in OIHW]
   if (!bwd) {
     const int cin0 = (S < 2 ? 32 * S : 64 + 32 * (S - 2)) + 8 * j;
-    const float* wk = wtab[blk * 5 + (K - 1)] + ((size_t)n * conv_cin(K) + cin0) * 9 + t;
+    const float* wk = wtab[blk * 5 + (K - 1)] + ((size_t)n * conv_cin(K) + cin0) * 9;
+    if ((reinterpret_cast<uintptr_t>(wk) & 15) == 0) {  // (288-byte items: aligned whenever the weight tensor is)
+      f32x4 q[18];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) pk[e] = (__bf16)wk[e * 9];
+      for (int i = 0; i < 18; ++i) q[i] = reinterpret_cast<const f32x4*>(wk)[i];
+#pragma unroll
+      for (int i = 0; i < 72; ++i) v[i / 9][i % 9] = q[i >> 2][i & 3];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 72; ++i) v[i / 9][i % 9] = wk[i];
+    }
   } else {
     const int k = S < 2 ? 5 : 6 - S;
     const int co0 = (S < 2 ? 32 * S : 0) + 8 * j;
     const int ci = (K < 5 ? 64 + 32 * (4 - K) : 0) + n;
-    const float* wk = wtab[blk * 5 + (k - 1)] + ((size_t)co0 * conv_cin(k) + ci) * 9 + (8 - t);
+    const float* wk = wtab[blk * 5 + (k - 1)] + ((size_t)co0 * conv_cin(k) + ci) * 9;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) pk[e] = (__bf16)wk[(size_t)e * conv_cin(k) * 9];
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v[e][t] = wk[(size_t)e * conv_cin(k) * 9 + t];
   }
-  *reinterpret_cast<bf16x8*>(dst + gid * 16) = pk;
+  unsigned char* d = dst + (size_t)blk * PACKED_BYTES + unit_off(u) + n * 64 + js * 16;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int ts = bwd ? 8 - t : t;  // taps flipped for the data gradient
+    const bf16x8 pk = {(__bf16)v[0][ts], (__bf16)v[1][ts], (__bf16)v[2][ts], (__bf16)v[3][ts],
+                       (__bf16)v[4][ts], (__bf16)v[5][ts], (__bf16)v[6][ts], (__bf16)v[7][ts]};
+    *reinterpret_cast<bf16x8*>(d + (size_t)t * NK * 64) = pk;
+  }
 }
 
 }  // namespace
@@ -439,7 +457,7 @@ extern "C" size_t srx_rdb_packed_bytes(void) { return (size_t)PACKED_BYTES; }
 
 static int rdb_pack_impl(const float* const* w_table_dev, int nblk, void* dst, int bwd, void* stream) {
   SRX_REQUIRE(w_table_dev && dst && nblk > 0 && nblk <= 4096, "rdb_pack: bad argument");
-  const int64_t n = (int64_t)nblk * (PACKED_BYTES / 16);
+  const int64_t n = (int64_t)nblk * (PACKED_BYTES / (16 * 9));
   hipLaunchKernelGGL(rdb_pack_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, srx_stream(stream), w_table_dev,
                      reinterpret_cast<unsigned char*>(dst), nblk, bwd);
   SRX_CHECK_LAUNCH("rdb_pack_kernel");
