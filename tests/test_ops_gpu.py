@@ -990,6 +990,63 @@ def test_data_gradient_with_bn_backward_reduce_epilogue(dev, prelu):
     assert rc != 0 and 'row tile' in _lib.last_error()
 
 
+@pytest.mark.parametrize('prelu', [True, False])
+@pytest.mark.parametrize('n,h,w', [(4, 12, 12), (16, 24, 24), (1, 6, 18)])
+def test_forward_conv_with_batchnorm_on_its_input(dev, prelu, n, h, w):
+    """``srx_conv2d_fwd_bn_in`` (normalise + PReLU of the conv below applied while this conv stages its input, the activation
+    tensor written on the side) against the separate launches ``srx_bn_act_fwd`` then ``srx_conv2d_fwd``: the same activation
+    tensor, conv output and BatchNorm partial sums bit for bit (same expressions, same kernel body)."""
+    import ctypes as C
+    from torchsr_amd import _lib
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    c = 64
+    m = n * h * w
+    d = _lib.Conv2dDesc(n, h, w, c, c, c, c, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
+    assert L.srx_conv2d_fwd_bn_in_ok(C.byref(d)) == 1
+    g = torch.Generator().manual_seed(7 + n)
+    rnd = lambda *shape: torch.randn(*shape, generator=g).to(dev)  # noqa: E731
+    wt = rnd(c, c, 3, 3) * 0.05
+    wf = torch.empty(L.srx_conv2d_packed_fwd_floats(C.byref(d)), device=dev)
+    wb = torch.empty(L.srx_conv2d_packed_bwd_floats(C.byref(d)), device=dev)
+    _lib.call('srx_conv2d_pack', C.byref(d), wt.data_ptr(), wf.data_ptr(), wb.data_ptr(), s)
+    y_in = rnd(n, h, w, c)
+    mean, invstd = rnd(c) * 0.1, torch.rand(c, generator=g).to(dev) + 0.5
+    gamma, beta = rnd(c), rnd(c) * 0.3
+    slope = torch.tensor([0.25], device=dev) if prelu else None
+    act = _lib.ACT_PRELU if prelu else _lib.ACT_NONE
+    rows = L.srx_conv2d_stat_rows(C.byref(d))
+    # separate launches
+    a0 = torch.empty_like(y_in)
+    _lib.call('srx_bn_act_fwd', y_in.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None,
+              a0.data_ptr(), m, c, act, 0.0, None if slope is None else slope.data_ptr(), s)
+    y0, part0 = torch.empty_like(y_in), torch.empty(rows, c, 2, device=dev)
+    nws = L.srx_conv2d_fwd_ws_floats(C.byref(d))
+    ws = torch.empty(max(nws, 4), device=dev)
+    _lib.call('srx_conv2d_fwd', C.byref(d), a0.data_ptr(), wf.data_ptr(), None, y0.data_ptr(), part0.data_ptr(), ws.data_ptr(), nws, s)
+    # one launch
+    a1 = torch.full_like(y_in, float('nan'))
+    y1, part1 = torch.empty_like(y_in), torch.empty(rows, c, 2, device=dev)
+    _lib.call('srx_conv2d_fwd_bn_in', C.byref(d), y_in.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+              beta.data_ptr(), None if slope is None else slope.data_ptr(), a1.data_ptr(), wf.data_ptr(), None, y1.data_ptr(),
+              part1.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(a0, a1)          # every pixel written exactly once, by the workgroup that owns it
+    assert torch.equal(y0, y1) and torch.equal(part0, part1)
+    # and against plain torch
+    z = (y_in - mean) * invstd * gamma + beta
+    ref_a = torch.where(z > 0, z, z * 0.25) if prelu else z
+    assert rel_err(a1, ref_a) < 1e-5
+    ref_y = torch.nn.functional.conv2d(ref_a.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    assert rel_err(y1.cpu().double(), ref_y) < 1e-5
+    # layers the row-tile kernel does not serve are refused, and say so beforehand
+    d2 = _lib.Conv2dDesc(1, 100, 100, c, c, c, c, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
+    assert L.srx_conv2d_fwd_bn_in_ok(C.byref(d2)) == 0
+    rc = L.srx_conv2d_fwd_bn_in(C.byref(d2), y_in.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                None, a1.data_ptr(), wf.data_ptr(), None, y1.data_ptr(), None, s)
+    assert rc != 0 and 'row tile' in _lib.last_error()
+
+
 @pytest.mark.parametrize('n,h,w,cin', [(2, 32, 32, 192), (3, 7, 32, 96), (1, 5, 16, 64)])
 def test_bf16_weight_gradient_on_image_rows(dev, n, h, w, cin):
     """The image-row bf16 weight-gradient kernel (3x3 / stride 1 / 64 output columns / rows of 16 or 32 pixels: ESRGAN's dense

@@ -43,12 +43,17 @@ struct RtArgs {
   // partial), one table row [2C + 4] per workgroup, exactly what bn_bwd_reduce_kernel would compute from a second read
   // of `out` and `y` in a launch of its own.
   srx_rt36_bn_t bn;
+  // BNL (forward only): `in` is the conv output below a BatchNorm (+ PReLU) layer; the patch pixels are normalised and
+  // activated between their load and their LDS store -- the exact expression of bn_act_fwd_kernel -- and every workgroup
+  // writes its own 36 transformed pixels to bnl.z_out, so the layer's normalise launch (5.3 us, 16 per generator forward,
+  // a read and a write of 2.4 MB each) disappears while the backward pass still finds the activation tensor it saved.
+  srx_rt36_bnl_t bnl;
 };
 
 // NB = batches of PB patch loads per thread (1 up to 2048 b128 slots, 2 up to the 64 KB LDS limit): a
 // compile-time count, so that ALL input loads and the first weight fragments are in flight together
 // and the compiler can wait on them with exact vmcnt values (a runtime loop drains the queue per trip).
-template <int NB, bool BNR = false>
+template <int NB, bool BNR = false, bool BNL = false>
 __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   extern __shared__ __attribute__((aligned(16))) float patch[];
   const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
@@ -70,13 +75,31 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   const unsigned quad16 = 16u * (tid & 15);
   int pr = (tid >> 4) / W2, pc = (tid >> 4) - pr * W2, sidx = tid >> 4;
   const int npix = prows * W2;
+  unsigned okm = 0, ownm = 0;  // BNL: slots that hold an image pixel / one of this workgroup's own 36 pixels
+  unsigned zoff[NB * PB];      // BNL: byte offset of the slot's pixel quad (input and z_out have the same shape)
 #pragma unroll
   for (int u = 0; u < NB * PB; ++u) {
     const int ih = r_first - 1 + pr, iw = pc - 1;
     const bool ok = sidx < npix && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-    v[u] = srx_bload(rin, ok ? (unsigned)((n * a.H + ih) * a.W + iw) * 256u + quad16 : 0xffffffffu, 0);
+    const unsigned off = (unsigned)((n * a.H + ih) * a.W + iw) * 256u + quad16;
+    v[u] = srx_bload(rin, ok ? off : 0xffffffffu, 0);
+    if constexpr (BNL) {
+      const unsigned q = (unsigned)(ih * a.W + iw - p0);  // (wraps for pixels in front of the tile)
+      okm |= (ok ? 1u : 0u) << u;
+      ownm |= ((ok && q < (unsigned)RT) ? 1u : 0u) << u;
+      zoff[u] = off;
+    }
     sidx += 16; pr += a.step_r; pc += a.step_c;
     if (pc >= W2) { pc -= W2; pr += 1; }
+  }
+  f32x4 nmu, nis, ngm, nbt;
+  float nsl = 1.f;
+  if constexpr (BNL) {  // this thread's four channels (quad tid & 15) of the layer's constants
+    nmu = *reinterpret_cast<const f32x4*>(a.bnl.mean + 4 * (tid & 15));
+    nis = *reinterpret_cast<const f32x4*>(a.bnl.invstd + 4 * (tid & 15));
+    ngm = *reinterpret_cast<const f32x4*>(a.bnl.gamma + 4 * (tid & 15));
+    nbt = *reinterpret_cast<const f32x4*>(a.bnl.beta + 4 * (tid & 15));
+    if (a.bnl.prelu) nsl = a.bnl.prelu[0];
   }
   // ---- weight stream: fragment `it` = (tap it>>2, channels 32hk + 8(it&3) + 4h2 .. +3) of column 32j+i31
   const unsigned wvoff = 4u * (unsigned)((32 * j + i31) * KTOT + 32 * hk + 4 * h2);
@@ -84,6 +107,22 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
 #pragma unroll
   for (int it = 0; it < PF; ++it) bq[it] = srx_bload(rw, wvoff, (unsigned)(((it >> 2) * 64 + 8 * (it & 3)) * 4));
   __builtin_amdgcn_sched_barrier(0);  // keep the weight loads ahead of the waits on the patch loads
+  if constexpr (BNL) {  // normalise + activate in registers; padding slots stay zero (the conv pads the ACTIVATION with zeros)
+    const __amdgpu_buffer_rsrc_t rz = srx_rsrc(a.bnl.z_out, a.in_bytes);
+#pragma unroll
+    for (int u = 0; u < NB * PB; ++u) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = (v[u][e] - nmu[e]) * (nis[e] * ngm[e]) + nbt[e];
+        o[e] = z > 0.f ? z : z * nsl;
+      }
+      v[u] = ((okm >> u) & 1u) ? o : f32x4{0.f, 0.f, 0.f, 0.f};
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[u]), rz,
+                                             (int)(((ownm >> u) & 1u) ? zoff[u] : 0xffffffffu), 0, 0);  // (out of range: dropped)
+    }
+  }
   // ---- patch -> LDS.  Surplus slots (e >= nslots) land in the slack the host adds behind the patch.
 #pragma unroll
   for (int u = 0; u < NB * PB; ++u) {
@@ -270,9 +309,11 @@ bool srx_rt36_applicable(const srx_conv2d_t* d) {
 int srx_rt36_rows(const srx_conv2d_t* d) { return (int)((int64_t)d->N * d->H * d->W / RT); }
 
 int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, const float* residual,
-                 float* out, float* part, int act, float slope, hipStream_t st, const srx_rt36_bn_t* bn) {
+                 float* out, float* part, int act, float slope, hipStream_t st, const srx_rt36_bn_t* bn,
+                 const srx_rt36_bnl_t* bnl) {
   RtArgs a{};
   if (bn) a.bn = *bn;
+  if (bnl) a.bnl = *bnl;
   a.in = in; a.w = wpk; a.bias = bias; a.res = residual; a.out = out; a.part = part;
   a.H = d->H; a.W = d->W; a.HW = d->H * d->W; a.M = d->N * a.HW;
   a.slope = act == SRX_ACT_RELU ? 0.f : (act == SRX_ACT_LRELU ? slope : 1.f);
@@ -290,13 +331,20 @@ int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<1, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   });
   const int nb = patch_batches(d->W);
   const double fl = 2.0 * a.M * 64 * KTOT;
   const dim3 grid((unsigned)(a.M / RT));
   char nm[112];
   if (srx_prof_on()) snprintf(nm, sizeof(nm), "rt36_conv3x3_c64_kernel<%d> MxNxK=%dx64x%d", nb, a.M, KTOT);
-  if (bn) {
+  if (bnl) {
+    if (nb == 1) SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<1, false, true>), grid, dim3(256), lds, st, a);
+    else SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<2, false, true>), grid, dim3(256), lds, st, a);
+  } else if (bn) {
     if (nb == 1) SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<1, true>), grid, dim3(256), lds, st, a);
     else SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<2, true>), grid, dim3(256), lds, st, a);
   } else if (nb == 1) SRX_LAUNCH_PROF(nm, fl, rt36_conv3x3_c64_kernel<1>, grid, dim3(256), lds, st, a);

@@ -60,8 +60,15 @@ int srx_rt36_rows(const srx_conv2d_t* d);  // workgroups = rows of the BatchNorm
 // whose output gradient this launch produces (see rowtile.hip); part: [workgroups][2 * 64 + 4]
 struct srx_rt36_bn_t { const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta;
                        const float* prelu; float* part; };
+// optional transform of a forward launch's INPUT while it is staged: the input tensor is the output of the conv BELOW and
+// the patch pixels become act(BatchNorm(in)) (training-mode statistics already finalised; prelu == null: no activation) on
+// their way into LDS; the workgroup also writes the transformed values of its own 36 pixels to z_out -- the tensor the
+// separate normalise pass would have produced, which the backward pass reads (see rowtile.hip)
+struct srx_rt36_bnl_t { const float* mean; const float* invstd; const float* gamma; const float* beta; const float* prelu;
+                        float* z_out; };
 int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, const float* residual,
-                 float* out, float* part, int act, float slope, hipStream_t st, const srx_rt36_bn_t* bn = nullptr);
+                 float* out, float* part, int act, float slope, hipStream_t st, const srx_rt36_bn_t* bn = nullptr,
+                 const srx_rt36_bnl_t* bnl = nullptr);
 
 static inline hipStream_t srx_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t srx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -660,6 +660,7 @@ class _ResidualTower(Function):
         for block in blocks:
             convs, bns = (block.conv1, block.conv2), (block.bn1, block.bn2)
             inp, ys, stats = x, [], []
+            pending = None  # (y1, mean1, invstd1, gamma1, beta1, slope, a1): bn1 + PReLU left to conv2's input staging
             for i in range(2):
                 st, bn = convs[i]._st, bns[i]
                 d = st.desc(n, h, w)
@@ -667,14 +668,25 @@ class _ResidualTower(Function):
                 st.pack(convs[i].weight, d)
                 y = torch.empty_like(x)
                 part = torch.empty((L.srx_conv2d_stat_rows(dref), c, 2), dtype=torch.float32, device=x.device)
-                nws = L.srx_conv2d_fwd_ws_floats(dref)
-                call('srx_conv2d_fwd', dref, _p(inp), _p(st.wpk_fwd), None, _p(y), _p(part), _p(_ws(nws, x)) if nws else None, nws, s)
+                if pending is not None:  # conv2 normalises + activates conv1's output while it stages it, and writes a1
+                    y1, mean1, inv1, g1, b1, slope, a1 = pending
+                    call('srx_conv2d_fwd_bn_in', dref, _p(y1), _p(mean1), _p(inv1), _p(g1), _p(b1), _p(slope), _p(a1),
+                         _p(st.wpk_fwd), None, _p(y), _p(part), s)
+                else:
+                    nws = L.srx_conv2d_fwd_ws_floats(dref)
+                    call('srx_conv2d_fwd', dref, _p(inp), _p(st.wpk_fwd), None, _p(y), _p(part), _p(_ws(nws, x)) if nws else None, nws, s)
                 mean = torch.empty(c, dtype=torch.float32, device=x.device)
                 invstd = torch.empty(c, dtype=torch.float32, device=x.device)
                 out = torch.empty_like(x)
                 momentum = 0.1 if bn.momentum is None else bn.momentum
                 g, b = bn.weight.detach(), bn.bias.detach()
-                if i == 0:   # BN1 + PReLU
+                if i == 0 and L.srx_conv2d_fwd_bn_in_ok(C.byref(convs[1]._st.desc(n, h, w))):
+                    # BN1: statistics only; the normalise + PReLU pass rides in conv2's launch (srx_conv2d_fwd_bn_in)
+                    call('srx_bn_finalize', _p(part), part.shape[0], m, c, bn.eps, momentum, _p(mean), _p(invstd),
+                         _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), s)
+                    pending = (y, mean, invstd, g, b, block.prelu.weight.detach(), out)
+                    a1 = inp = out
+                elif i == 0:   # BN1 + PReLU
                     call('srx_bn_train_fwd', _p(y), _p(part), part.shape[0], m, c, 1, bn.eps, momentum, _p(g), _p(b), None, _p(out),
                          ACT_PRELU, 0.0, _p(block.prelu.weight.detach()), _p(mean), _p(invstd), _p(bn.running_mean),
                          _p(bn.running_var), _p(bn.num_batches_tracked), s)
