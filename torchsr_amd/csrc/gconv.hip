@@ -1932,6 +1932,8 @@ static int conv_fwd_impl(const srx_conv2d_t* d, const float* x, const float* wpk
   if (residual && d->shuffle) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_fwd: residual with PixelShuffle is not implemented");
   hipStream_t st = srx_stream(stream);
   if (srx_thin_fwd_applicable(d) && !bn_partials && !residual && d->up != 2) return srx_thin_fwd(d, x, wpk, bias, y, d->Cout, st);
+  if (srx_first3_fwd_applicable(d) && !bn_partials && !residual && d->act != SRX_ACT_PRELU)
+    return srx_first3_fwd(d, x, wpk, fwd_geo(d).Kp, bias, y, st);
   if (srx_rt36_applicable(d) && out_scale == 1.f)
     return srx_rt36_run(d, x, wpk, bias, residual, y, bn_partials, d->act, d->slope, st);
   if (srx_rt36_applicable(d)) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_fwd_residual: out_scale != 1 on the 36-pixel row tile");

@@ -9,6 +9,7 @@
 // the 64 lanes of B hold the wide side: 75 % of the pipe does useful work and the thin operand is a
 // 4-address broadcast.  Same 64 FLOP/clk/SIMD rate as the 32x32 MFMA, exact fp32.
 #include "srx_common.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -255,6 +256,75 @@ __global__ __launch_bounds__(256) void thin_fwd2_kernel(const ThinF a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Thin INPUT convolution, forward: 3x3 / stride 1 / pad 1, image (<= 4 channels, stored as 4) -> 64 channels + bias +
+// ReLU / LeakyReLU -- the first layers of the discriminators and of VGG19 (srgan/discriminator.py:32, VGG cfg 'E').
+// K is only 36 (9 taps x 4 stored channels): on the generic tile that is two 32-wide k-chunks, one of them padding, and a
+// pipeline that never fills (45 us for 295 k pixels, 30 TFLOP/s).  Here nothing is staged: a wave owns 32 pixels x 64
+// columns (two 32x32x2 accumulators), keeps the WHOLE weight matrix in 36 registers per lane (lane = column, lane half =
+// k parity, as the MFMA's B operand wants it) and reads each pixel's nine 16-byte neighbours straight into registers
+// (lane = pixel; both lane halves load the same quad and pick their k parity's channel).  36 MFMAs per 32 pixels;
+// the kernel is a write stream of 256 bytes per pixel.  The packed weights are the generic forward layout
+// ([64][Kp], k = tap * 4 + channel), so nothing else changes.  PR: operands rounded to bf16 (products stay fp32).
+// ---------------------------------------------------------------------------------------------
+struct First3 {
+  const float* in; const float* w; const float* bias; float* out;
+  int H, W, HW, M, Kp, ntiles;
+  float inv_HW, inv_W, slope;
+  unsigned in_bytes, out_bytes;
+};
+
+template <int PR>
+__global__ __launch_bounds__(256) void first3x3_fwd_kernel(const First3 a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i31 = lane & 31, h2 = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes);
+  const __amdgpu_buffer_rsrc_t rout = srx_rsrc(a.out, a.out_bytes);
+  auto rnd = [](float v) { return PR ? (float)(__bf16)v : v; };
+  float b[18][2], bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    bv[j] = a.bias ? a.bias[32 * j + i31] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 18; ++s) b[s][j] = rnd(a.w[(size_t)(32 * j + i31) * a.Kp + 2 * s + h2]);
+  }
+  for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
+    const int p = tile * 32 + i31;
+    int n, rem, ih, iw;
+    srx_divmod(min(p, a.M - 1), a.HW, a.inv_HW, n, rem);
+    srx_divmod(rem, a.W, a.inv_W, ih, iw);
+    f32x4 v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int y = ih + t / 3 - 1, x = iw + t % 3 - 1;
+      const bool ok = p < a.M && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+      v[t] = srx_bload(rin, ok ? (unsigned)((n * a.H + y) * a.W + x) * 16u : 0xffffffffu, 0);
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {  // k = 4 t + 2 jj + h2
+        const float av = rnd(h2 ? v[t][2 * jj + 1] : v[t][2 * jj]);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[2 * t + jj][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[2 * t + jj][1], acc1, 0, 0, 0);
+      }
+    // 32x32 accumulator: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); rows past M fall outside the descriptor
+    const unsigned obase = ((unsigned)tile * 32u * 64u + (unsigned)i31 + 256u * h2) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float o0 = acc0[r] + bv[0], o1 = acc1[r] + bv[1];
+      o0 = o0 > 0.f ? o0 : o0 * a.slope;
+      o1 = o1 > 0.f ? o1 : o1 * a.slope;
+      const int roff = ((r & 3) + 8 * (r >> 2)) * 256;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o0), rout, (int)obase, roff, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o1), rout, (int)obase, roff + 128, 0);
+    }
+  }
+}
+
 // packs OIHW weights for thin_fwd_kernel: p[c][tap][ch].
 //  mode 0 (forward, thin = Cout): p[c][kh*KW+kw][ch] = w[c][ch][kh][kw]
 //  mode 1 (data gradient of a Cin<=4 layer, thin = Cin, wide = Cout, taps flipped):
@@ -372,6 +442,31 @@ static int launch_thin_fwd2(const ThinF& a, hipStream_t st) {
 }
 
 // in: [N][H][W][64], out: [N][H][W][4]; wpk from srx_thin_pack; n_out = real output channels
+bool srx_first3_fwd_applicable(const srx_conv2d_t* d) {
+  static const bool off = getenv("SRX_NO_FIRST3") != nullptr;  // developer switch (A/B runs)
+  return !off && thin_geom_ok(d) && d->KH == 3 && d->Cin <= 4 && d->Cin_s == 4 && d->Cout == 64 && d->Cout_s == 64 &&
+         (int64_t)d->N * d->H * d->W < (1 << 24);
+}
+
+int srx_first3_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, int Kp, const float* bias, float* out,
+                   hipStream_t st) {
+  First3 a;
+  a.in = in; a.w = wpk; a.bias = bias; a.out = out;
+  a.H = d->H; a.W = d->W; a.HW = d->H * d->W; a.M = d->N * a.HW; a.Kp = Kp;
+  a.ntiles = (int)srx_cdiv(a.M, 32);
+  a.inv_HW = 1.0f / (float)a.HW; a.inv_W = 1.0f / (float)a.W;
+  a.slope = d->act == SRX_ACT_RELU ? 0.f : (d->act == SRX_ACT_LRELU ? d->slope : 1.f);  // v > 0 ? v : v * slope
+  a.in_bytes = (unsigned)((size_t)a.M * 4 * sizeof(float));
+  a.out_bytes = (unsigned)((size_t)a.M * 64 * sizeof(float));
+  const unsigned grid = (unsigned)std::min<int64_t>(srx_cdiv(a.ntiles, 4), 4096);
+  char nm[64];
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "first3x3_fwd_kernel<%d> MxNxK=%dx64x36", d->precision ? 1 : 0, a.M);
+  if (d->precision) SRX_LAUNCH_PROF(nm, 2.0 * a.M * 64 * 27, first3x3_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
+  else SRX_LAUNCH_PROF(nm, 2.0 * a.M * 64 * 27, first3x3_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+  SRX_CHECK_LAUNCH("first3x3_fwd_kernel");
+  return SRX_OK;
+}
+
 int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, float* out, int n_out,
                  hipStream_t st) {
   ThinF a;
