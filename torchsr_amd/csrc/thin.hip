@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void thin_fwd2_kernel(const ThinF a) {
 // K is only 36 (9 taps x 4 stored channels): on the generic tile that is two 32-wide k-chunks, one of them padding, and a
 // pipeline that never fills (45 us for 295 k pixels, 30 TFLOP/s).  Here nothing is staged: a wave owns 32 pixels x 64
 // columns (two 32x32x2 accumulators), keeps the WHOLE weight matrix in 36 registers per lane (lane = column, lane half =
-// k parity, as the MFMA's B operand wants it) and reads each pixel's nine 16-byte neighbours straight into registers
+// k parity, as the MFMA's B operand wants it; fetched through LDS) and reads each pixel's nine 16-byte neighbours straight into registers
 // (lane = pixel; both lane halves load the same quad and pick their k parity's channel).  36 MFMAs per 32 pixels;
 // the kernel is a write stream of 256 bytes per pixel.  The packed weights are the generic forward layout
 // ([64][Kp], k = tap * 4 + channel), so nothing else changes.  PR: operands rounded to bf16 (products stay fp32).
@@ -281,12 +281,17 @@ __global__ __launch_bounds__(256) void first3x3_fwd_kernel(const First3 a) {
   const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes);
   const __amdgpu_buffer_rsrc_t rout = srx_rsrc(a.out, a.out_bytes);
   auto rnd = [](float v) { return PR ? (float)(__bf16)v : v; };
+  // the 64 x 36 weights go through LDS once per workgroup (rows of 144 contiguous bytes; a lane reading its own column's
+  // row straight from memory touched 64 lines per load instruction: 41 us of L1 line requests per launch, measured 48.7 us)
+  __shared__ float sw[64][37];
+  for (int i = threadIdx.x; i < 64 * 36; i += 256) sw[i / 36][i % 36] = a.w[(size_t)(i / 36) * a.Kp + i % 36];
+  __syncthreads();
   float b[18][2], bv[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     bv[j] = a.bias ? a.bias[32 * j + i31] : 0.f;
 #pragma unroll
-    for (int s = 0; s < 18; ++s) b[s][j] = rnd(a.w[(size_t)(32 * j + i31) * a.Kp + 2 * s + h2]);
+    for (int s = 0; s < 18; ++s) b[s][j] = rnd(sw[32 * j + i31][2 * s + h2]);
   }
   for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
     const int p = tile * 32 + i31;
@@ -458,7 +463,11 @@ int srx_first3_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, int
   a.slope = d->act == SRX_ACT_RELU ? 0.f : (d->act == SRX_ACT_LRELU ? d->slope : 1.f);  // v > 0 ? v : v * slope
   a.in_bytes = (unsigned)((size_t)a.M * 4 * sizeof(float));
   a.out_bytes = (unsigned)((size_t)a.M * 64 * sizeof(float));
-  const unsigned grid = (unsigned)std::min<int64_t>(srx_cdiv(a.ntiles, 4), 4096);
+  // three workgroups per CU, each wave walking its share of the tiles: the weight prologue is paid 768 times, not 2304
+  static int cus = 0;
+  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
+  static const char* gdev = getenv("SRX_FIRST3_WGS_PER_CU");
+  const unsigned grid = (unsigned)std::min<int64_t>(srx_cdiv(a.ntiles, 4), (int64_t)cus * (gdev ? atoi(gdev) : 3));
   char nm[64];
   if (srx_prof_on()) snprintf(nm, sizeof(nm), "first3x3_fwd_kernel<%d> MxNxK=%dx64x36", d->precision ? 1 : 0, a.M);
   if (d->precision) SRX_LAUNCH_PROF(nm, 2.0 * a.M * 64 * 27, first3x3_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
