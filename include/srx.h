@@ -95,7 +95,9 @@ typedef struct srx_conv2d {
                          and the stride-1 data gradient -- the reference's torch.cuda.amp.autocast
                          region (srgan/trainer.py:379-383, esrgan/trainer.py:418-484); tensors stay
                          fp32 in memory, operands are rounded when staged into LDS; strided data
-                         gradients and the 3-channel (thin) layers remain fp32 */
+                         gradients and the 3-channel (thin) layers remain fp32.  2: only on the forward
+                         of a 64 -> <= 4 channel layer (the generators' output conv): bf16 products there
+                         as well -- inference with every conv in bf16 (test.upscale(precision='bf16')) */
 } srx_conv2d_t;
 
 /* sizes (in floats) of the packed weight copies and of scratch buffers */

@@ -30,16 +30,17 @@ State = Dict[str, Tensor]
 # gradients and the layers with a 3-channel side keep exact fp32 operands.  ``bf16_products()`` switches this oracle to
 # the same recipe so that an autocast step can be pinned at ~1e-3 instead of "within bf16 rounding of the fp32 step".
 _BF16 = [False]
+_BF16_THIN_OUT = [False]  # inference (test.upscale(precision='bf16')): the 64 -> 3 output conv rounds its operands too
 
 
 @contextlib.contextmanager
-def bf16_products():
-    old = _BF16[0]
-    _BF16[0] = True
+def bf16_products(thin_out: bool = False):
+    old = _BF16[0], _BF16_THIN_OUT[0]
+    _BF16[0], _BF16_THIN_OUT[0] = True, thin_out
     try:
         yield
     finally:
-        _BF16[0] = old
+        _BF16[0], _BF16_THIN_OUT[0] = old
 
 
 def _r(t: Tensor) -> Tensor:
@@ -53,7 +54,7 @@ class _ConvBF16(torch.autograd.Function):
         ctx.cfg = (stride, pad, b is not None)
         ctx.thin_in, ctx.thin_out = (cin <= 4 and cout == 64), (cout <= 4 and cin == 64)
         ctx.save_for_backward(x, w)
-        if ctx.thin_out:  # the product's thin forward kernel is exact fp32
+        if ctx.thin_out and not _BF16_THIN_OUT[0]:  # the product's thin forward kernel is exact fp32 (training paths)
             return F.conv2d(x, w, b, stride, pad)
         return F.conv2d(_r(x), _r(w), b, stride, pad)
 

@@ -157,7 +157,7 @@ def test_1080p_inference_bf16_products_vs_oracle(dev):
         with torch.no_grad():
             exact = crop(O.generator_forward(sd, cut, training=False))
             same = crop(O.generator_forward(folded, cut, training=False))
-            with O.bf16_products():
+            with O.bf16_products(thin_out=True):  # inference: the 64 -> 3 output conv rounds its operands too
                 ref = crop(O.generator_forward(folded, cut, training=False))
         assert (exact - same).abs().max().item() <= 2e-5 * exact.abs().max().item()  # the folding itself changes nothing
         got = out[:, :, 4 * y0:4 * (y0 + win), 4 * x0:4 * (x0 + win)].cpu()
@@ -175,7 +175,9 @@ def test_1080p_inference_bf16_products_vs_oracle(dev):
 def test_bf16_inference_layers_vs_rounded_operands(dev):
     """The arithmetic of ``precision='bf16'`` inference, one fused layer at a time on the layer's OWN input (so that nothing
     compounds): conv [+ folded BatchNorm] [+ PReLU] [+ PixelShuffle] [+ skip] = fp64 evaluation of
-    ``act(conv(bf16(x), bf16(w_folded)) + b_folded) + skip`` to 2e-5; the 64 -> 3 output conv is exact fp32."""
+    ``act(conv(bf16(x), bf16(w_folded)) + b_folded) + skip`` to 2e-5; the 64 -> 3 output conv is exact fp32 with the
+    training setting (precision 1) and rounds its operands like the others with the inference setting (precision 2, what
+    ``test.upscale(precision='bf16')`` selects)."""
     import torch.nn.functional as TF
     from oracle.weights import closed_form_state
     from torchsr_amd import functional as F
@@ -223,6 +225,10 @@ def test_bf16_inference_layers_vs_rounded_operands(dev):
             layer(out)
             out = check(f'conv_layers.{i} + PixelShuffle + PReLU', layer.__dict__['_folded'], out, shuffle=True)
         check('conv3 (exact fp32)', gen.conv3, out, exact=True, cout=3)
+        gen.conv3._st.precision = 2
+        check('conv3 (bf16 products)', gen.conv3, out, cout=3)
+        big = F.to_nhwc(torch.rand(1, 64, 150, 100, generator=torch.Generator().manual_seed(6)).to(dev) - 0.5)
+        check('conv3 (bf16 products, several tiles)', gen.conv3, big, cout=3)
 
 
 def test_device_data_pipeline_cli(dev, tmp_path, monkeypatch):

@@ -990,6 +990,29 @@ def test_data_gradient_with_bn_backward_reduce_epilogue(dev, prelu):
     assert rc != 0 and 'row tile' in _lib.last_error()
 
 
+@pytest.mark.parametrize('k,n,h,w', [(9, 2, 40, 70), (3, 1, 33, 45), (3, 40, 96, 96), (9, 1, 7, 5)])
+def test_output_conv_with_bf16_products(dev, k, n, h, w):
+    """``srx_conv2d_t::precision = 2``: the 64 -> 3 output convs (9x9 SRGAN, 3x3 ESRGAN) with bf16-rounded operands on
+    ``v_mfma_f32_4x4x4_16b_bf16`` (inference) against fp64 of the rounded operands; images of several tiles, of less than one
+    tile, and enough tiles for the six-rows-per-wave variant."""
+    from torchsr_amd import functional as F
+    from torchsr_amd.layers import Conv2d
+    torch.manual_seed(k + h)
+    conv = Conv2d(64, 3, kernel_size=k, stride=1, padding=(k - 1) // 2).to(dev)
+    conv._st.precision = 2
+    x = torch.rand(n, 64, h, w, device=dev) - 0.5
+    with torch.no_grad():
+        y = F.to_nchw(conv(F.to_nhwc(x)), 3)
+    r16 = lambda t: t.to(torch.bfloat16).double().cpu()  # noqa: E731
+    ref = torch.nn.functional.conv2d(r16(x), r16(conv.weight.detach()), conv.bias.detach().double().cpu(), 1, (k - 1) // 2)
+    assert rel_err(y, ref) < 2e-5
+    conv._st.precision = 0
+    with torch.no_grad():
+        y0 = F.to_nchw(conv(F.to_nhwc(x)), 3)
+    exact = torch.nn.functional.conv2d(x.double().cpu(), conv.weight.detach().double().cpu(), conv.bias.detach().double().cpu(), 1, (k - 1) // 2)
+    assert rel_err(y0, exact) < 2e-5 and rel_err(y, exact) > 1e-4  # (and the two settings are different arithmetic)
+
+
 @pytest.mark.parametrize('prelu', [True, False])
 @pytest.mark.parametrize('n,h,w', [(4, 12, 12), (16, 24, 24), (1, 6, 18)])
 def test_forward_conv_with_batchnorm_on_its_input(dev, prelu, n, h, w):

@@ -1292,7 +1292,8 @@ int check_desc(const srx_conv2d_t* d) {
     SRX_REQUIRE(d->Cout_s >= d->Cout && d->Cout_s % 4 == 0, "conv2d: Cout_s must be a multiple of 4 and >= Cout");
   }
   SRX_REQUIRE(d->act == SRX_ACT_NONE || d->act == SRX_ACT_RELU || d->act == SRX_ACT_LRELU, "conv2d: bad act");
-  SRX_REQUIRE(d->precision == 0 || d->precision == 1, "conv2d: precision must be 0 (fp32) or 1 (bf16 products)");
+  SRX_REQUIRE(d->precision == 0 || d->precision == 1 || (d->precision == 2 && srx_thin_fwd_applicable(d)),
+              "conv2d: precision must be 0 (fp32), 1 (bf16 products) or, for the forward of a 64 -> <= 4 channel layer, 2 (bf16 products there too)");
   const int uf = d->up == 2 ? 2 : 1;
   const int Ho = (uf * d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (uf * d->W + 2 * d->pad - d->KW) / d->stride + 1;
   SRX_REQUIRE(Ho > 0 && Wo > 0, "conv2d: empty output");

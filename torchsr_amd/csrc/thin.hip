@@ -11,6 +11,7 @@
 #include "srx_common.h"
 #include <algorithm>
 #include <cstdio>
+#include <mutex>
 #include <cstdlib>
 
 namespace {
@@ -256,6 +257,110 @@ __global__ __launch_bounds__(256) void thin_fwd2_kernel(const ThinF a) {
   }
 }
 
+// The same forward kernel with bf16 products (srx_conv2d_t::precision = 2: inference with bf16 products in EVERY conv; the
+// training paths keep the 3-channel layers exact, precision 0 / 1).  Same tiles, same LDS byte layout -- a pixel is 32 bytes,
+// now 16 bf16 channels instead of 8 floats, so a round covers 16 channels (four rounds) and the two lane halves hold channels
+// 0-7 / 8-15 -- and v_mfma_f32_4x4x4_16b_bf16 contracts four channels per instruction (probed on gfx950,
+// tools/probe/mfma4x4_bf16.hip: D[reg i] on lane l += sum_k A(lane 4 (l / 4) + i)[k] B(lane l)[k]): a quarter of the MFMAs
+// and half the LDS reads of the fp32 kernel, which the 9x9 64 -> 3 output conv at 8K resolution (33 M pixels) was bound by.
+// Operands are rounded to bf16 (nearest even) as they are staged; accumulation is fp32.
+template <int K, int R>
+__global__ __launch_bounds__(256) void thin_fwd2_bf16_kernel(const ThinF a) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  struct Frag { s16x4 lo, hi; };
+  constexpr int TH = 4 * R, TW = 32, CS = 16;  // CS: channels staged per round
+  constexpr int PH = TH + K - 1, PW = TW + K - 1, PAD = (K - 1) / 2, TAPS = K * K;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned char* sx = reinterpret_cast<unsigned char*>(smem);  // [PH][PW][CS] bf16
+  unsigned char* sw = sx + PH * PW * CS * 2;                   // [4][TAPS][CS] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
+  int b = blockIdx.x;
+  const int tw_i = b % a.tiles_w; b /= a.tiles_w;
+  const int th_i = b % a.tiles_h;
+  const int n = b / a.tiles_h;
+  const int h0 = th_i * TH, w0 = tw_i * TW;
+  const int pc = lane & 31, hh = lane >> 5, r0 = wave * R, wc = lane & 3;
+  const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes);
+  const __amdgpu_buffer_rsrc_t rw = srx_rsrc(a.w, 4 * TAPS * 64 * 4);
+
+  f32x4 acc[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NPX = PH * PW * 2;       // 16-byte units of the patch (pixel, 8-channel half)
+  constexpr int LP = (NPX + 255) / 256;  // units per thread (all loads issued before any is written)
+  constexpr int NWQ = 4 * TAPS * 2, LW = (NWQ + 255) / 256;
+  auto pack = [](const f32x4& u, const f32x4& v) {
+    return bf16x8{(__bf16)u[0], (__bf16)u[1], (__bf16)u[2], (__bf16)u[3], (__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  };
+  for (int cc = 0; cc < 64; cc += CS) {
+    f32x4 vp[LP][2], vw[LW][2];
+#pragma unroll
+    for (int u = 0; u < LP; ++u) {
+      const int i = u * 256 + tid;
+      const int q = i & 1, pix = i >> 1;
+      const int pw = pix % PW, ph = pix / PW;
+      const int ih = h0 - PAD + ph, iw = w0 - PAD + pw;
+      const bool ok = i < NPX && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      const unsigned off = ok ? 4u * (unsigned)(((n * a.H + ih) * a.W + iw) * 64 + cc + q * 8) : 0xffffffffu;
+      vp[u][0] = srx_bload(rin, off, 0);
+      vp[u][1] = srx_bload(rin, off, 16);
+    }
+#pragma unroll
+    for (int u = 0; u < LW; ++u) {
+      const int i = u * 256 + tid;  // (c*TAPS + tap) * 2 + q
+      const unsigned off = i < NWQ ? 4u * (unsigned)((i >> 1) * 64 + cc + (i & 1) * 8) : 0xffffffffu;
+      vw[u][0] = srx_bload(rw, off, 0);
+      vw[u][1] = srx_bload(rw, off, 16);
+    }
+    __syncthreads();  // the previous round's reads are done
+#pragma unroll
+    for (int u = 0; u < LP; ++u) {
+      const int i = u * 256 + tid;
+      if (i < NPX) *reinterpret_cast<bf16x8*>(sx + i * 16) = pack(vp[u][0], vp[u][1]);
+    }
+#pragma unroll
+    for (int u = 0; u < LW; ++u) {
+      const int i = u * 256 + tid;
+      if (i < NWQ) *reinterpret_cast<bf16x8*>(sw + i * 16) = pack(vw[u][0], vw[u][1]);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kw = 0; kw < K; ++kw) {
+      Frag wr[K];
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh)
+        wr[kh] = *reinterpret_cast<const Frag*>(sw + ((wc * TAPS + kh * K + kw) * CS + 8 * hh) * 2);
+      const unsigned char* xp = sx + (((r0 * PW) + pc + kw) * CS + 8 * hh) * 2;
+#pragma unroll
+      for (int ir = 0; ir < R + K - 1; ++ir) {  // input row r0 + ir of the patch
+        const Frag xv = *reinterpret_cast<const Frag*>(xp + ir * PW * CS * 2);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const int kh = ir - j;
+          if (kh >= 0 && kh < K) {
+            acc[j] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wr[kh].lo, xv.lo, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wr[kh].hi, xv.hi, acc[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    f32x4 v = acc[j];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] += __shfl_xor(v[c], 32, 64);  // the other channel half
+    const int oh = h0 + r0 + j, ow = w0 + pc;
+    if (hh == 0 && oh < a.H && ow < a.W) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = c < a.Cout ? v[c] + (a.bias ? a.bias[c] : 0.f) : 0.f;
+      *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.H + oh) * a.W + ow) * 4) = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Thin INPUT convolution, forward: 3x3 / stride 1 / pad 1, image (<= 4 channels, stored as 4) -> 64 channels + bias +
 // ReLU / LeakyReLU -- the first layers of the discriminators and of VGG19 (srgan/discriminator.py:32, VGG cfg 'E').
@@ -476,6 +581,23 @@ int srx_first3_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, int
   return SRX_OK;
 }
 
+template <int K, int R>
+static int launch_thin_fwd2_bf16(const ThinF& a, hipStream_t st) {
+  constexpr int PH = 4 * R + K - 1, PW = 32 + K - 1;
+  const size_t lds = (size_t)(PH * PW * 16 + 4 * K * K * 16) * 2;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd2_bf16_kernel<K, R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              96 * 1024);
+  });
+  char nm[64];
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "thin_fwd2_bf16_kernel<%d, %d>", K, R);
+  SRX_LAUNCH_PROF(nm, 2.0 * a.N * a.H * a.W * K * K * 64 * a.Cout, (thin_fwd2_bf16_kernel<K, R>),
+                  dim3((unsigned)(a.N * a.tiles_h * a.tiles_w)), dim3(256), lds, st, a);
+  SRX_CHECK_LAUNCH("thin_fwd2_bf16_kernel");
+  return SRX_OK;
+}
+
 int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, float* out, int n_out,
                  hipStream_t st) {
   ThinF a;
@@ -491,6 +613,10 @@ int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const
   const int64_t big_tiles = (int64_t)d->N * srx_cdiv(d->H, 24) * a.tiles_w;
   const int R = dev ? atoi(dev) : (big_tiles >= 4 * cus ? 6 : 3);
   a.tiles_h = (int)srx_cdiv(d->H, 4 * R);
+  if (d->precision == 2) {  // bf16 products in the 3-channel layer too (inference)
+    if (d->KH == 9) return R == 3 ? launch_thin_fwd2_bf16<9, 3>(a, st) : launch_thin_fwd2_bf16<9, 6>(a, st);
+    return R == 3 ? launch_thin_fwd2_bf16<3, 3>(a, st) : launch_thin_fwd2_bf16<3, 6>(a, st);
+  }
   if (d->KH == 9) return R == 3 ? launch_thin_fwd2<9, 3>(a, st) : (R == 6 ? launch_thin_fwd2<9, 6>(a, st) : launch_thin_fwd2<9, 4>(a, st));
   return R == 3 ? launch_thin_fwd2<3, 3>(a, st) : (R == 6 ? launch_thin_fwd2<3, 6>(a, st) : launch_thin_fwd2<3, 4>(a, st));
 }

@@ -39,7 +39,7 @@ def upscale(generator: torch.nn.Module, low_res: Tensor, halo: int = None,
     """``generator(low_res)`` in eval mode, tiled when the image is large.  ``low_res``: [N,3,h,w].
 
     ``precision``: ``'fp32'`` (exact; the reference's ``test`` runs no autocast, test.py:57-62) or ``'bf16'`` (bf16
-    products with fp32 accumulation in every conv but the 3-channel ones); ``None`` keeps
+    products with fp32 accumulation in every conv but the 3-channel INPUT conv); ``None`` keeps
     whatever the generator's convs are set to.  The setting is restored afterwards.  ``staged=False`` forces the halo
     tiling for a generator that offers the two-stage interface (``_upscale_staged``)."""
     from .layers import Conv2d, set_conv_precision
@@ -49,6 +49,10 @@ def upscale(generator: torch.nn.Module, low_res: Tensor, halo: int = None,
             raise ValueError(f"upscale: precision must be 'fp32' or 'bf16', got {precision!r}")
         saved = [(m, m._st.precision) for m in generator.modules() if isinstance(m, Conv2d)]
         set_conv_precision(generator, precision)
+        if precision == 'bf16':  # inference: the 64 -> 3 output conv multiplies bf16 operands too (srx_conv2d_t::precision = 2)
+            for m, _ in saved:
+                if m.out_channels <= 4 and m.in_channels == 64:
+                    m._st.precision = 2
         try:
             return upscale(generator, low_res, halo, max_tile_pixels, scale, None, staged)
         finally:
