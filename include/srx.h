@@ -195,6 +195,17 @@ int srx_conv2d_bwd_data_bn_rows(const srx_conv2d_t* d);
 int srx_conv2d_bwd_data_bn(const srx_conv2d_t* d, const float* dy, const float* wpk_bwd, const float* addend, float* dx,
                            const float* bn_y, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
                            const float* bn_beta, const float* bn_prelu, float* table, void* stream);
+/* srx_conv2d_bwd_data_bn with the conv's output gradient produced on the way in: dout is the gradient arriving at the OUTPUT of
+ * the BatchNorm (+ PReLU) layer above this conv (in_*: that layer's forward input y, statistics, parameters, slope or NULL, and
+ * its finalised backward sums from srx_bn_act_bwd_finish(..., dy = NULL)); the second pass of that layer's backward runs while
+ * the data gradient stages its input, and dy_out receives the conv's output gradient (its weight gradient reads it).
+ * table == NULL: no BatchNorm below (then the bn_* pointers are ignored).  Same layers as srx_conv2d_bwd_data_bn. */
+int srx_conv2d_bwd_data_bn_in_ok(const srx_conv2d_t* d);
+int srx_conv2d_bwd_data_bn_in(const srx_conv2d_t* d, const float* dout, const float* in_y, const float* in_mean,
+                              const float* in_invstd, const float* in_gamma, const float* in_beta, const float* in_prelu,
+                              const float* in_sums, float* dy_out, const float* wpk_bwd, const float* addend, float* dx,
+                              const float* bn_y, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                              const float* bn_beta, const float* bn_prelu, float* table, void* stream);
 /* y = conv(act(BatchNorm(y_in))) in ONE launch: y_in is the output of the conv below (srgan/residual.py:86-88: conv1 -> bn1 ->
  * prelu -> conv2), the training-mode statistics are already finalised (srx_bn_finalize), and the normalise + activate pass
  * runs while the conv stages its input; act_out receives the activation tensor (what srx_bn_act_fwd would have written: the

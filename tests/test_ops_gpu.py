@@ -990,6 +990,79 @@ def test_data_gradient_with_bn_backward_reduce_epilogue(dev, prelu):
     assert rc != 0 and 'row tile' in _lib.last_error()
 
 
+@pytest.mark.parametrize('prelu', [True, False])
+@pytest.mark.parametrize('below', [True, False])
+def test_data_gradient_with_batchnorm_backward_on_its_input(dev, prelu, below):
+    """``srx_conv2d_bwd_data_bn_in`` (the apply pass of the BatchNorm (+ PReLU) backward ABOVE a conv formed while the conv's
+    data gradient stages its input, the conv's output gradient written on the side; optionally the reduce pass of the
+    BatchNorm BELOW in the epilogue) against the separate launches: same dy, same dx, same table to rounding."""
+    import ctypes as C
+    from torchsr_amd import _lib
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    n, h, w, c = 4, 12, 12, 64
+    m = n * h * w
+    d = _lib.Conv2dDesc(n, h, w, c, c, c, c, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
+    assert L.srx_conv2d_bwd_data_bn_in_ok(C.byref(d)) == 1
+    rows = L.srx_conv2d_bwd_data_bn_rows(C.byref(d))
+    g = torch.Generator().manual_seed(41)
+    rnd = lambda *shape: torch.randn(*shape, generator=g).to(dev)  # noqa: E731
+    wt = rnd(c, c, 3, 3) * 0.05
+    wf = torch.empty(L.srx_conv2d_packed_fwd_floats(C.byref(d)), device=dev)
+    wb = torch.empty(L.srx_conv2d_packed_bwd_floats(C.byref(d)), device=dev)
+    _lib.call('srx_conv2d_pack', C.byref(d), wt.data_ptr(), wf.data_ptr(), wb.data_ptr(), s)
+    dout, y_above, addend, y_below = rnd(n, h, w, c), rnd(n, h, w, c), rnd(n, h, w, c), rnd(n, h, w, c)
+    mean, invstd, gamma, beta = rnd(c) * 0.1, torch.rand(c, generator=g).to(dev) + 0.5, rnd(c), rnd(c) * 0.3
+    mean_b, invstd_b, gamma_b, beta_b = rnd(c) * 0.1, torch.rand(c, generator=g).to(dev) + 0.5, rnd(c), rnd(c) * 0.3
+    slope = torch.tensor([0.25], device=dev) if prelu else None
+    sp = None if slope is None else slope.data_ptr()
+    act = _lib.ACT_PRELU if prelu else _lib.ACT_NONE
+    W = 2 * c + 4
+    # the sums of the layer above (as its producer's table would give them)
+    sums = torch.empty(W, device=dev)
+    nbw = L.srx_bn_bwd_ws_floats(m, c)
+    bws = torch.empty(nbw, device=dev)
+    dy0 = torch.empty_like(dout)
+    gg, gb, gp = torch.zeros(c, device=dev), torch.zeros(c, device=dev), torch.zeros(1, device=dev)
+    _lib.call('srx_bn_act_bwd', dout.data_ptr(), y_above.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+              sums.data_ptr(), dy0.data_ptr(), m, c, 1, act, 0.0, sp, 1, gg.data_ptr(), gb.data_ptr(), gp.data_ptr() if prelu else None,
+              bws.data_ptr(), nbw, s)
+    # separate launches: dy0 from above, then the data gradient (+ addend) with or without the reduce epilogue
+    dx0, table0 = torch.empty_like(dout), torch.full((rows, W), float('nan'), device=dev)
+    if below:
+        _lib.call('srx_conv2d_bwd_data_bn', C.byref(d), dy0.data_ptr(), wb.data_ptr(), addend.data_ptr(), dx0.data_ptr(), y_below.data_ptr(),
+                  mean_b.data_ptr(), invstd_b.data_ptr(), gamma_b.data_ptr(), beta_b.data_ptr(), None, table0.data_ptr(), s)
+    else:
+        nws = L.srx_conv2d_bwd_data_ws_floats(C.byref(d))
+        ws = torch.empty(max(nws, 4), device=dev)
+        _lib.call('srx_conv2d_bwd_data_add', C.byref(d), dy0.data_ptr(), wb.data_ptr(), addend.data_ptr(), dx0.data_ptr(), ws.data_ptr(), nws, s)
+    # one launch
+    dy1, dx1 = torch.full_like(dout, float('nan')), torch.empty_like(dout)
+    table1 = torch.full((rows, W), float('nan'), device=dev)
+    _lib.call('srx_conv2d_bwd_data_bn_in', C.byref(d), dout.data_ptr(), y_above.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+              gamma.data_ptr(), beta.data_ptr(), sp, sums.data_ptr(), dy1.data_ptr(), wb.data_ptr(), addend.data_ptr(), dx1.data_ptr(),
+              y_below.data_ptr() if below else None, mean_b.data_ptr() if below else None, invstd_b.data_ptr() if below else None,
+              gamma_b.data_ptr() if below else None, beta_b.data_ptr() if below else None, None,
+              table1.data_ptr() if below else None, s)
+    torch.cuda.synchronize()
+    # (to rounding, not bit for bit: the two kernels contract the apply expression's multiplies and adds differently)
+    assert rel_err(dy1, dy0) < 2e-6 and rel_err(dx1, dx0) < 1e-5
+    assert not torch.isnan(dy1).any()   # every pixel written, by the workgroup that owns it
+    if below:
+        assert rel_err(table1[:, :2 * c], table0[:, :2 * c]) < 1e-5
+    # finalize alone (dy = NULL) leaves the sums the full call leaves
+    tab = torch.rand(rows, W, generator=g).to(dev)
+    s_a, s_b, out_b = torch.empty(W, device=dev), torch.empty(W, device=dev), torch.empty_like(dout)
+    z = lambda: torch.zeros(c, device=dev)  # noqa: E731
+    _lib.call('srx_bn_act_bwd_finish', None, None, None, None, None, None, tab.data_ptr(), rows, 2, s_a.data_ptr(), None, m, c, act, 0.0,
+              sp, z().data_ptr(), z().data_ptr(), gp.data_ptr() if prelu else None, s)
+    _lib.call('srx_bn_act_bwd_finish', dout.data_ptr(), y_above.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+              tab.data_ptr(), rows, 2, s_b.data_ptr(), out_b.data_ptr(), m, c, act, 0.0, sp, z().data_ptr(), z().data_ptr(),
+              gp.data_ptr() if prelu else None, s)
+    torch.cuda.synchronize()
+    assert torch.equal(s_a[:2 * c + 1], s_b[:2 * c + 1])
+
+
 @pytest.mark.parametrize('k,n,h,w', [(9, 2, 40, 70), (3, 1, 33, 45), (3, 40, 96, 96), (9, 1, 7, 5)])
 def test_output_conv_with_bf16_products(dev, k, n, h, w):
     """``srx_conv2d_t::precision = 2``: the 64 -> 3 output convs (9x9 SRGAN, 3x3 ESRGAN) with bf16-rounded operands on

@@ -89,6 +89,8 @@ _SIGS = {
     'srx_conv2d_bwd_data_bn_rows': (_I, [_D]),
     'srx_conv2d_bwd_data_bn': (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'srx_conv2d_fwd_bn_in_ok': (_I, [_D]),
+    'srx_conv2d_bwd_data_bn_in_ok': (_I, [_D]),
+    'srx_conv2d_bwd_data_bn_in': (_I, [_D] + [_P] * 20),
     'srx_conv2d_fwd_bn_in': (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'srx_bn_act_bwd_finish': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _I, _F, _P, _P, _P, _P, _P]),
     'srx_conv2d_bwd_data_ex': (_I, [_D, _P, _P, _P, C.POINTER(DgradEpilogue), _P, _Z, _P]),
@@ -150,7 +152,7 @@ _SIGS = {
     'srx_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
 }
 # functions whose int return value is data, not a status
-_UNCHECKED = {'srx_conv2d_bwd_data_bn_rows', 'srx_conv2d_fwd_bn_in_ok', 'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows', 'srx_bn_rows_per_block'}
+_UNCHECKED = {'srx_conv2d_bwd_data_bn_rows', 'srx_conv2d_fwd_bn_in_ok', 'srx_conv2d_bwd_data_bn_in_ok', 'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows', 'srx_bn_rows_per_block'}
 
 EXPORTS = tuple(_SIGS.keys())
 

@@ -2116,6 +2116,37 @@ extern "C" int srx_conv2d_bwd_data_bn(const srx_conv2d_t* d, const float* dy, co
   return srx_rt36_run(d, dy, wpk_bwd + cls[0].woff, nullptr, addend, dx, nullptr, SRX_ACT_NONE, 0.f, srx_stream(stream), &bn);
 }
 
+// srx_conv2d_bwd_data_bn whose INPUT is not yet the conv's output gradient but the gradient arriving at the output of the
+// BatchNorm (+ PReLU) layer ABOVE the conv (srgan/residual.py:89-90 / :87-88 read backwards): the second pass of that layer's
+// backward (sums finalised: srx_bn_act_bwd_finish with dy = NULL) runs while the patch is staged, dy_out receives the conv's
+// output gradient for its weight gradient.  table == NULL: no BatchNorm below (plain data gradient + addend).
+extern "C" int srx_conv2d_bwd_data_bn_in_ok(const srx_conv2d_t* d) {
+  static const bool off = getenv("SRX_NO_BN_BWD_FUSE") != nullptr;  // developer switch (A/B runs)
+  return (!off && srx_conv2d_bwd_data_bn_rows(d) != 0) ? 1 : 0;
+}
+
+extern "C" int srx_conv2d_bwd_data_bn_in(const srx_conv2d_t* d, const float* dout, const float* in_y, const float* in_mean,
+                                         const float* in_invstd, const float* in_gamma, const float* in_beta, const float* in_prelu,
+                                         const float* in_sums, float* dy_out, const float* wpk_bwd, const float* addend, float* dx,
+                                         const float* bn_y, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                         const float* bn_beta, const float* bn_prelu, float* table, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRX_REQUIRE(dout && in_y && in_mean && in_invstd && in_gamma && in_beta && in_sums && dy_out && wpk_bwd && dx,
+              "conv2d_bwd_data_bn_in: null pointer");
+  SRX_REQUIRE(dy_out != dout && dy_out != dx && dx != dout && (!addend || addend != dx), "conv2d_bwd_data_bn_in: dout, dy_out, dx and the addend must be tensors of their own");
+  SRX_REQUIRE(!table || (bn_y && bn_mean && bn_invstd && bn_gamma && bn_beta), "conv2d_bwd_data_bn_in: a table needs the BatchNorm below");
+  if (!srx_conv2d_bwd_data_bn_in_ok(d))
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data_bn_in: 3x3 / 64 -> 64 / stride 1 layers on the 36-pixel row tile only (srx_conv2d_bwd_data_bn_in_ok)");
+  BwdClass cls[16];
+  size_t total;
+  (void)bwd_classes(d, cls, total);
+  const srx_rt36_bn_t bn{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_prelu, table};
+  const srx_rt36_bnb_t bnb{in_y, in_mean, in_invstd, in_gamma, in_beta, in_prelu, in_sums,
+                           1.0f / (float)((int64_t)d->N * d->H * d->W), dy_out};
+  return srx_rt36_run(d, dout, wpk_bwd + cls[0].woff, nullptr, addend, dx, nullptr, SRX_ACT_NONE, 0.f, srx_stream(stream),
+                      table ? &bn : nullptr, nullptr, &bnb);
+}
+
 // The forward of a conv whose INPUT is act(BatchNorm(y_in)) of the conv below (training mode, statistics finalised): the
 // normalise + activate pass runs while the input patch is staged, and act_out receives the tensor that pass would have
 // written.  1: this layer can (the 36-pixel row tile: 3x3, 64 -> 64, stride 1, few pixels); 0: keep srx_bn_act_fwd + srx_conv2d_fwd.

@@ -456,12 +456,13 @@ extern "C" int srx_bn_act_bwd_finish(const float* dout, const float* y, const fl
                                      float* sums, float* dy, int64_t M, int C, int act, float slope, const float* prelu,
                                      float* dgamma_acc, float* dbeta_acc, float* dprelu_acc, void* stream) {
   if (int rc = check_c(C, "bn_act_bwd_finish")) return rc;
-  SRX_REQUIRE(dout && y && mean && invstd && gamma && beta && table && sums && dy && M > 0 && rows > 0,
+  SRX_REQUIRE(table && sums && M > 0 && rows > 0 && (!dy || (dout && y && mean && invstd && gamma && beta)),
               "bn_act_bwd_finish: bad argument");
   SRX_REQUIRE(prelu_cols == 1 || prelu_cols == 2, "bn_act_bwd_finish: the PReLU partial sits in 1 or 2 table columns");
   SRX_REQUIRE(act != SRX_ACT_PRELU || prelu, "bn_act_bwd_finish: PReLU needs its slope pointer");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)srx_cdiv(2 * C + 1, 4)), dim3(256), 0, srx_stream(stream), table, rows,
                      C, 1, sums, dgamma_acc, dbeta_acc, dprelu_acc, prelu_cols);
   SRX_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  if (!dy) return SRX_OK;  // sums and parameter gradients only: the apply pass rides in the consumer (srx_conv2d_bwd_data_bn_in)
   return bwd_apply_impl(dout, y, mean, invstd, gamma, beta, sums, dy, M, C, 1, act, slope, prelu, 1, stream);
 }

@@ -48,12 +48,16 @@ struct RtArgs {
   // writes its own 36 transformed pixels to bnl.z_out, so the layer's normalise launch (5.3 us, 16 per generator forward,
   // a read and a write of 2.4 MB each) disappears while the backward pass still finds the activation tensor it saved.
   srx_rt36_bnl_t bnl;
+  // BNB (data gradients only): `in` is the gradient arriving at the OUTPUT of a BatchNorm (+ PReLU) layer; the patch pixels
+  // become the layer's input gradient -- the expression of bn_bwd_apply_kernel, from a second patch load of the layer's
+  // forward input bnb.y and the finalised sums -- and every workgroup writes its own 36 pixels of it to bnb.dy_out.
+  srx_rt36_bnb_t bnb;
 };
 
 // NB = batches of PB patch loads per thread (1 up to 2048 b128 slots, 2 up to the 64 KB LDS limit): a
 // compile-time count, so that ALL input loads and the first weight fragments are in flight together
 // and the compiler can wait on them with exact vmcnt values (a runtime loop drains the queue per trip).
-template <int NB, bool BNR = false, bool BNL = false>
+template <int NB, bool BNR = false, bool BNL = false, bool BNB = false>
 __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   extern __shared__ __attribute__((aligned(16))) float patch[];
   const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
@@ -75,15 +79,18 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   const unsigned quad16 = 16u * (tid & 15);
   int pr = (tid >> 4) / W2, pc = (tid >> 4) - pr * W2, sidx = tid >> 4;
   const int npix = prows * W2;
-  unsigned okm = 0, ownm = 0;  // BNL: slots that hold an image pixel / one of this workgroup's own 36 pixels
-  unsigned zoff[NB * PB];      // BNL: byte offset of the slot's pixel quad (input and z_out have the same shape)
+  unsigned okm = 0, ownm = 0;  // BNL / BNB: slots that hold an image pixel / one of this workgroup's own 36 pixels
+  unsigned zoff[NB * PB];      // BNL / BNB: byte offset of the slot's pixel quad (input and side output have the same shape)
+  f32x4 yb[BNB ? NB * PB : 1];  // BNB: the BatchNorm layer's forward input at the slot
+  const __amdgpu_buffer_rsrc_t rby = srx_rsrc(BNB ? a.bnb.y : a.in, a.in_bytes);
 #pragma unroll
   for (int u = 0; u < NB * PB; ++u) {
     const int ih = r_first - 1 + pr, iw = pc - 1;
     const bool ok = sidx < npix && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
     const unsigned off = (unsigned)((n * a.H + ih) * a.W + iw) * 256u + quad16;
     v[u] = srx_bload(rin, ok ? off : 0xffffffffu, 0);
-    if constexpr (BNL) {
+    if constexpr (BNB) yb[u] = srx_bload(rby, ok ? off : 0xffffffffu, 0);
+    if constexpr (BNL || BNB) {
       const unsigned q = (unsigned)(ih * a.W + iw - p0);  // (wraps for pixels in front of the tile)
       okm |= (ok ? 1u : 0u) << u;
       ownm |= ((ok && q < (unsigned)RT) ? 1u : 0u) << u;
@@ -92,8 +99,17 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     sidx += 16; pr += a.step_r; pc += a.step_c;
     if (pc >= W2) { pc -= W2; pr += 1; }
   }
-  f32x4 nmu, nis, ngm, nbt;
+  f32x4 nmu, nis, ngm, nbt, nsd, nsx;
   float nsl = 1.f;
+  if constexpr (BNB) {
+    nmu = *reinterpret_cast<const f32x4*>(a.bnb.mean + 4 * (tid & 15));
+    nis = *reinterpret_cast<const f32x4*>(a.bnb.invstd + 4 * (tid & 15));
+    ngm = *reinterpret_cast<const f32x4*>(a.bnb.gamma + 4 * (tid & 15));
+    nbt = *reinterpret_cast<const f32x4*>(a.bnb.beta + 4 * (tid & 15));
+    nsd = *reinterpret_cast<const f32x4*>(a.bnb.sums + 4 * (tid & 15));
+    nsx = *reinterpret_cast<const f32x4*>(a.bnb.sums + 64 + 4 * (tid & 15));
+    if (a.bnb.prelu) nsl = a.bnb.prelu[0];
+  }
   if constexpr (BNL) {  // this thread's four channels (quad tid & 15) of the layer's constants
     nmu = *reinterpret_cast<const f32x4*>(a.bnl.mean + 4 * (tid & 15));
     nis = *reinterpret_cast<const f32x4*>(a.bnl.invstd + 4 * (tid & 15));
@@ -119,6 +135,26 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
       }
       v[u] = ((okm >> u) & 1u) ? o : f32x4{0.f, 0.f, 0.f, 0.f};
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[u]), rz,
+                                             (int)(((ownm >> u) & 1u) ? zoff[u] : 0xffffffffu), 0, 0);  // (out of range: dropped)
+    }
+  }
+  if constexpr (BNB) {  // BatchNorm (+ PReLU) backward, second pass, in registers; padding slots stay zero
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rz = srx_rsrc(a.bnb.dy_out, a.in_bytes);
+    const float invM = a.bnb.inv_m;
+    const bool has_act = a.bnb.prelu != nullptr;
+#pragma unroll
+    for (int u = 0; u < NB * PB; ++u) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (yb[u][e] - nmu[e]) * nis[e];
+        const float z = xh * ngm[e] + nbt[e];
+        const float dz = v[u][e] * (has_act ? (z > 0.f ? 1.f : nsl) : 1.f);
+        o[e] = ngm[e] * nis[e] * (dz - nsd[e] * invM - xh * nsx[e] * invM);
+      }
+      v[u] = ((okm >> u) & 1u) ? o : f32x4{0.f, 0.f, 0.f, 0.f};
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[u]), rz,
                                              (int)(((ownm >> u) & 1u) ? zoff[u] : 0xffffffffu), 0, 0);  // (out of range: dropped)
     }
@@ -218,13 +254,13 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   float yv[16], yv4[4];
   float bmu = 0.f, bis = 0.f, bgm = 0.f, bbt = 0.f, bsl = 1.f, t1 = 0.f, t2 = 0.f, tp = 0.f;
   if constexpr (BNR) {
-    const __amdgpu_buffer_rsrc_t rby = srx_rsrc(a.bn.y, a.out_bytes);
+    const __amdgpu_buffer_rsrc_t rbn = srx_rsrc(a.bn.y, a.out_bytes);
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rby, (int)obase, ((r & 3) + 8 * (r >> 2)) * 256, 0));
+      yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbn, (int)obase, ((r & 3) + 8 * (r >> 2)) * 256, 0));
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      yv4[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rby, (int)obase4, (32 + i) * 256, 0));
+      yv4[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbn, (int)obase4, (32 + i) * 256, 0));
     bmu = a.bn.mean[col]; bis = a.bn.invstd[col]; bgm = a.bn.gamma[col]; bbt = a.bn.beta[col];
     if (a.bn.prelu) bsl = a.bn.prelu[0];
   }
@@ -310,10 +346,11 @@ int srx_rt36_rows(const srx_conv2d_t* d) { return (int)((int64_t)d->N * d->H * d
 
 int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, const float* residual,
                  float* out, float* part, int act, float slope, hipStream_t st, const srx_rt36_bn_t* bn,
-                 const srx_rt36_bnl_t* bnl) {
+                 const srx_rt36_bnl_t* bnl, const srx_rt36_bnb_t* bnb) {
   RtArgs a{};
   if (bn) a.bn = *bn;
   if (bnl) a.bnl = *bnl;
+  if (bnb) a.bnb = *bnb;
   a.in = in; a.w = wpk; a.bias = bias; a.res = residual; a.out = out; a.part = part;
   a.H = d->H; a.W = d->W; a.HW = d->H * d->W; a.M = d->N * a.HW;
   a.slope = act == SRX_ACT_RELU ? 0.f : (act == SRX_ACT_LRELU ? slope : 1.f);
@@ -335,13 +372,27 @@ int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<1, true, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2, true, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<1, false, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2, false, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   });
   const int nb = patch_batches(d->W);
   const double fl = 2.0 * a.M * 64 * KTOT;
   const dim3 grid((unsigned)(a.M / RT));
   char nm[112];
   if (srx_prof_on()) snprintf(nm, sizeof(nm), "rt36_conv3x3_c64_kernel<%d> MxNxK=%dx64x%d", nb, a.M, KTOT);
-  if (bnl) {
+  if (bnb && bn) {
+    if (nb == 1) SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<1, true, false, true>), grid, dim3(256), lds, st, a);
+    else SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<2, true, false, true>), grid, dim3(256), lds, st, a);
+  } else if (bnb) {
+    if (nb == 1) SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<1, false, false, true>), grid, dim3(256), lds, st, a);
+    else SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<2, false, false, true>), grid, dim3(256), lds, st, a);
+  } else if (bnl) {
     if (nb == 1) SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<1, false, true>), grid, dim3(256), lds, st, a);
     else SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<2, false, true>), grid, dim3(256), lds, st, a);
   } else if (bn) {

@@ -69,9 +69,15 @@ struct srx_rt36_bn_t { const float* y; const float* mean; const float* invstd; c
 // separate normalise pass would have produced, which the backward pass reads (see rowtile.hip)
 struct srx_rt36_bnl_t { const float* mean; const float* invstd; const float* gamma; const float* beta; const float* prelu;
                         float* z_out; };
+// the same for a DATA GRADIENT whose input is the gradient arriving at the OUTPUT of a BatchNorm (+ PReLU) layer: the patch
+// pixels become that layer's input gradient (second pass of its backward: dy = gamma * invstd * (dz - sum_dz / M - xhat *
+// sum_dz_xhat / M), the sums already finalised) on their way into LDS -- this needs the layer's forward input y as a second
+// patch -- and the workgroup writes its own 36 pixels of dy to dy_out (the conv's weight gradient reads it)
+struct srx_rt36_bnb_t { const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta;
+                        const float* prelu; const float* sums; float inv_m; float* dy_out; };
 int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, const float* residual,
                  float* out, float* part, int act, float slope, hipStream_t st, const srx_rt36_bn_t* bn = nullptr,
-                 const srx_rt36_bnl_t* bnl = nullptr);
+                 const srx_rt36_bnl_t* bnl = nullptr, const srx_rt36_bnb_t* bnb = nullptr);
 
 static inline hipStream_t srx_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t srx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

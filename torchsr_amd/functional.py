@@ -760,20 +760,62 @@ class _ResidualTower(Function):
             nws = L.srx_conv2d_bwd_weight_ws_floats(dref)
             call('srx_conv2d_bwd_weight', dref, _p(inp), _p(dy), _p(conv.weight.grad), 1, None, _p(_ws(nws, inp)), nws, s)
 
+        # With a table from the producer, the APPLY pass of a BatchNorm backward rides in the data gradient that consumes its
+        # result too (srx_conv2d_bwd_data_bn_in: the layer's input gradient is formed while the patch is staged and written on
+        # the side for the weight gradient): per block two more launches disappear, finalize -> data gradient is all that is left
+        fuse_in = bool(rows) and L.srx_conv2d_bwd_data_bn_in_ok(dref) == 1
+
+        def sums_only(y, bn, act, prelu, table):
+            """finalize pass alone: the reduced sums (and the parameter gradients) from the producer's table"""
+            sums = torch.empty(W, dtype=torch.float32, device=grad.device)
+            pw = None if prelu is None else prelu.detach()
+            pg = None if prelu is None else _p(prelu.grad)
+            call('srx_bn_act_bwd_finish', None, None, None, None, None, None, _p(table), rows, 2, _p(sums), None, m, c, act, 0.0,
+                 _p(pw), _p(bn.weight.grad), _p(bn.bias.grad), pg, s)
+            return sums
+
+        def dgrad_in(pack, dz_in, above, sums, addend, below):
+            """conv^T(dy) [+ addend] with dy = the input gradient of the BatchNorm (+ PReLU) layer `above` = (y, mean, invstd,
+            bn, prelu), formed from dz_in on load and returned as well; `below` as in dgrad"""
+            y, mean, invstd, bn, prelu = above
+            dy, dx = torch.empty_like(y), torch.empty_like(y)
+            table = None
+            by = bmean = binv = bg = bb = bp = None
+            if below is not None:
+                table = torch.empty((rows, W), dtype=torch.float32, device=y.device)
+                by, bmean, binv, bbn, bprelu = below
+                bg, bb = bbn.weight.detach(), bbn.bias.detach()
+                bp = None if bprelu is None else bprelu.detach()
+            call('srx_conv2d_bwd_data_bn_in', dref, _p(dz_in), _p(y), _p(mean), _p(invstd), _p(bn.weight.detach()),
+                 _p(bn.bias.detach()), None if prelu is None else _p(prelu.detach()), _p(sums), _p(dy), _p(pack), _p(addend), _p(dx),
+                 _p(by), _p(bmean), _p(binv), _p(bg), _p(bb), _p(bp), _p(table), s)
+            return dy, dx, table
+
         table2 = None  # the reduce pass of the top block's bn2 has no producer inside this node
         for i in range(len(blocks) - 1, -1, -1):
             block = blocks[i]
             x, y1, a1, y2, mean1, inv1, mean2, inv2 = saved[8 * i:8 * i + 8]
-            dy2 = finish(grad, y2, mean2, inv2, block.bn2, ACT_NONE, None, table2)
+            below1 = (y1, mean1, inv1, block.bn1, block.prelu.weight)
+            if fuse_in and table2 is not None:
+                sums2 = sums_only(y2, block.bn2, ACT_NONE, None, table2)
+                dy2, da1, table1 = dgrad_in(ctx.packs[i][1], grad, (y2, mean2, inv2, block.bn2, None), sums2, None, below1)
+            else:
+                dy2 = finish(grad, y2, mean2, inv2, block.bn2, ACT_NONE, None, table2)
+                da1, table1 = dgrad(ctx.packs[i][1], dy2, None, below1)
             wgrad(block.conv2, a1, dy2)
-            da1, table1 = dgrad(ctx.packs[i][1], dy2, None, (y1, mean1, inv1, block.bn1, block.prelu.weight))
+            need_dx = i > 0 or ctx.needs_input_grad[0]
+            below = None
+            if i > 0:
+                pb = blocks[i - 1]
+                below = (saved[8 * (i - 1) + 3], saved[8 * (i - 1) + 6], saved[8 * (i - 1) + 7], pb.bn2, None)
+            if fuse_in and table1 is not None and need_dx:
+                sums1 = sums_only(y1, block.bn1, ACT_PRELU, block.prelu.weight, table1)
+                dy1, grad, table2 = dgrad_in(ctx.packs[i][0], da1, below1, sums1, grad, below)
+                wgrad(block.conv1, x, dy1)
+                continue
             dy1 = finish(da1, y1, mean1, inv1, block.bn1, ACT_PRELU, block.prelu.weight, table1)
             wgrad(block.conv1, x, dy1)
-            if i > 0 or ctx.needs_input_grad[0]:
-                below = None
-                if i > 0:
-                    pb = blocks[i - 1]
-                    below = (saved[8 * (i - 1) + 3], saved[8 * (i - 1) + 6], saved[8 * (i - 1) + 7], pb.bn2, None)
+            if need_dx:
                 grad, table2 = dgrad(ctx.packs[i][0], dy1, grad, below)
             else:
                 grad = None
