@@ -210,12 +210,13 @@ int srx_conv2d_bwd_data_bn_in(const srx_conv2d_t* d, const float* dout, const fl
  * prelu -> conv2), the training-mode statistics are already finalised (srx_bn_finalize), and the normalise + activate pass
  * runs while the conv stages its input; act_out receives the activation tensor (what srx_bn_act_fwd would have written: the
  * backward pass and the weight gradient of this conv read it).  bn_prelu: the slope (device scalar) or NULL for no
- * activation.  bn_partials as in srx_conv2d_fwd.  Only layers for which srx_conv2d_fwd_bn_in_ok returns 1 (3x3, 64 -> 64,
+ * activation.  bn_residual: NULL, or a tensor added behind the activation -- `x + bn2(conv2(.))` at the end of a residual block
+ * (srgan/residual.py:90-91) formed while the NEXT block's conv1 stages its input (a second patch load).  bn_partials as in srx_conv2d_fwd.  Only layers for which srx_conv2d_fwd_bn_in_ok returns 1 (3x3, 64 -> 64,
  * stride 1, few pixels: the residual tower at training sizes). */
 int srx_conv2d_fwd_bn_in_ok(const srx_conv2d_t* d);
 int srx_conv2d_fwd_bn_in(const srx_conv2d_t* d, const float* y_in, const float* bn_mean, const float* bn_invstd,
-                         const float* bn_gamma, const float* bn_beta, const float* bn_prelu, float* act_out,
-                         const float* wpk, const float* bias, float* y, float* bn_partials, void* stream);
+                         const float* bn_gamma, const float* bn_beta, const float* bn_prelu, const float* bn_residual,
+                         float* act_out, const float* wpk, const float* bias, float* y, float* bn_partials, void* stream);
 int srx_bn_act_bwd_finish(const float* dout, const float* y, const float* mean, const float* invstd, const float* gamma,
                           const float* beta, const float* table, int rows, int prelu_cols, float* sums, float* dy, int64_t M,
                           int C, int act, float slope, const float* prelu, float* dgamma_acc, float* dbeta_acc,

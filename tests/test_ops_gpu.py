@@ -1089,9 +1089,10 @@ def test_output_conv_with_bf16_products(dev, k, n, h, w):
 @pytest.mark.parametrize('prelu', [True, False])
 @pytest.mark.parametrize('n,h,w', [(4, 12, 12), (16, 24, 24), (1, 6, 18)])
 def test_forward_conv_with_batchnorm_on_its_input(dev, prelu, n, h, w):
-    """``srx_conv2d_fwd_bn_in`` (normalise + PReLU of the conv below applied while this conv stages its input, the activation
-    tensor written on the side) against the separate launches ``srx_bn_act_fwd`` then ``srx_conv2d_fwd``: the same activation
-    tensor, conv output and BatchNorm partial sums bit for bit (same expressions, same kernel body)."""
+    """``srx_conv2d_fwd_bn_in`` (normalise + PReLU of the conv below -- or normalise + skip addend, the end of a residual block --
+    applied while this conv stages its input, the result tensor written on the side) against the separate launches
+    ``srx_bn_act_fwd`` then ``srx_conv2d_fwd``: the same tensor, conv output and BatchNorm partial sums bit for bit (same
+    expressions, same kernel body)."""
     import ctypes as C
     from torchsr_amd import _lib
     L = _lib.lib()
@@ -1114,8 +1115,9 @@ def test_forward_conv_with_batchnorm_on_its_input(dev, prelu, n, h, w):
     rows = L.srx_conv2d_stat_rows(C.byref(d))
     # separate launches
     a0 = torch.empty_like(y_in)
-    _lib.call('srx_bn_act_fwd', y_in.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None,
-              a0.data_ptr(), m, c, act, 0.0, None if slope is None else slope.data_ptr(), s)
+    res = None if prelu else rnd(n, h, w, c)  # bn2 + skip (no activation, an addend) / bn1 + PReLU (no addend)
+    _lib.call('srx_bn_act_fwd', y_in.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+              None if res is None else res.data_ptr(), a0.data_ptr(), m, c, act, 0.0, None if slope is None else slope.data_ptr(), s)
     y0, part0 = torch.empty_like(y_in), torch.empty(rows, c, 2, device=dev)
     nws = L.srx_conv2d_fwd_ws_floats(C.byref(d))
     ws = torch.empty(max(nws, 4), device=dev)
@@ -1124,14 +1126,14 @@ def test_forward_conv_with_batchnorm_on_its_input(dev, prelu, n, h, w):
     a1 = torch.full_like(y_in, float('nan'))
     y1, part1 = torch.empty_like(y_in), torch.empty(rows, c, 2, device=dev)
     _lib.call('srx_conv2d_fwd_bn_in', C.byref(d), y_in.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-              beta.data_ptr(), None if slope is None else slope.data_ptr(), a1.data_ptr(), wf.data_ptr(), None, y1.data_ptr(),
-              part1.data_ptr(), s)
+              beta.data_ptr(), None if slope is None else slope.data_ptr(), None if res is None else res.data_ptr(), a1.data_ptr(),
+              wf.data_ptr(), None, y1.data_ptr(), part1.data_ptr(), s)
     torch.cuda.synchronize()
     assert torch.equal(a0, a1)          # every pixel written exactly once, by the workgroup that owns it
     assert torch.equal(y0, y1) and torch.equal(part0, part1)
     # and against plain torch
     z = (y_in - mean) * invstd * gamma + beta
-    ref_a = torch.where(z > 0, z, z * 0.25) if prelu else z
+    ref_a = torch.where(z > 0, z, z * 0.25) if prelu else z + res
     assert rel_err(a1, ref_a) < 1e-5
     ref_y = torch.nn.functional.conv2d(ref_a.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), padding=1).permute(0, 2, 3, 1)
     assert rel_err(y1.cpu().double(), ref_y) < 1e-5
@@ -1139,7 +1141,7 @@ def test_forward_conv_with_batchnorm_on_its_input(dev, prelu, n, h, w):
     d2 = _lib.Conv2dDesc(1, 100, 100, c, c, c, c, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
     assert L.srx_conv2d_fwd_bn_in_ok(C.byref(d2)) == 0
     rc = L.srx_conv2d_fwd_bn_in(C.byref(d2), y_in.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                None, a1.data_ptr(), wf.data_ptr(), None, y1.data_ptr(), None, s)
+                                None, None, a1.data_ptr(), wf.data_ptr(), None, y1.data_ptr(), None, s)
     assert rc != 0 and 'row tile' in _lib.last_error()
 
 

@@ -91,7 +91,7 @@ _SIGS = {
     'srx_conv2d_fwd_bn_in_ok': (_I, [_D]),
     'srx_conv2d_bwd_data_bn_in_ok': (_I, [_D]),
     'srx_conv2d_bwd_data_bn_in': (_I, [_D] + [_P] * 20),
-    'srx_conv2d_fwd_bn_in': (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'srx_conv2d_fwd_bn_in': (_I, [_D] + [_P] * 13),
     'srx_bn_act_bwd_finish': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _I, _F, _P, _P, _P, _P, _P]),
     'srx_conv2d_bwd_data_ex': (_I, [_D, _P, _P, _P, C.POINTER(DgradEpilogue), _P, _Z, _P]),
     'srx_conv2d_bwd_weight': (_I, [_D, _P, _P, _P, _I, _P, _P, _Z, _P]),

@@ -2147,7 +2147,7 @@ extern "C" int srx_conv2d_bwd_data_bn_in(const srx_conv2d_t* d, const float* dou
                       table ? &bn : nullptr, nullptr, &bnb);
 }
 
-// The forward of a conv whose INPUT is act(BatchNorm(y_in)) of the conv below (training mode, statistics finalised): the
+// The forward of a conv whose INPUT is act(BatchNorm(y_in)) [+ residual] of the conv below (training mode, statistics finalised): the
 // normalise + activate pass runs while the input patch is staged, and act_out receives the tensor that pass would have
 // written.  1: this layer can (the 36-pixel row tile: 3x3, 64 -> 64, stride 1, few pixels); 0: keep srx_bn_act_fwd + srx_conv2d_fwd.
 extern "C" int srx_conv2d_fwd_bn_in_ok(const srx_conv2d_t* d) {
@@ -2156,14 +2156,15 @@ extern "C" int srx_conv2d_fwd_bn_in_ok(const srx_conv2d_t* d) {
 }
 
 extern "C" int srx_conv2d_fwd_bn_in(const srx_conv2d_t* d, const float* y_in, const float* bn_mean, const float* bn_invstd,
-                                    const float* bn_gamma, const float* bn_beta, const float* bn_prelu, float* act_out,
-                                    const float* wpk, const float* bias, float* y, float* bn_partials, void* stream) {
+                                    const float* bn_gamma, const float* bn_beta, const float* bn_prelu, const float* bn_residual,
+                                    float* act_out, const float* wpk, const float* bias, float* y, float* bn_partials, void* stream) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(y_in && bn_mean && bn_invstd && bn_gamma && bn_beta && act_out && wpk && y, "conv2d_fwd_bn_in: null pointer");
-  SRX_REQUIRE(act_out != y_in && act_out != y && y != y_in, "conv2d_fwd_bn_in: y_in, act_out and y must be three tensors");
+  SRX_REQUIRE(act_out != y_in && act_out != y && y != y_in && act_out != bn_residual && y != bn_residual,
+              "conv2d_fwd_bn_in: y_in, act_out, y and the residual must be tensors of their own");
   if (!srx_conv2d_fwd_bn_in_ok(d))
     SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_fwd_bn_in: 3x3 / 64 -> 64 / stride 1 layers on the 36-pixel row tile only (srx_conv2d_fwd_bn_in_ok)");
-  const srx_rt36_bnl_t bnl{bn_mean, bn_invstd, bn_gamma, bn_beta, bn_prelu, act_out};
+  const srx_rt36_bnl_t bnl{bn_mean, bn_invstd, bn_gamma, bn_beta, bn_prelu, bn_residual, act_out};
   return srx_rt36_run(d, y_in, wpk, bias, nullptr, y, bn_partials, d->act, d->slope, srx_stream(stream), nullptr, &bnl);
 }
 

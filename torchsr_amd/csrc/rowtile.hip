@@ -81,8 +81,9 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   const int npix = prows * W2;
   unsigned okm = 0, ownm = 0;  // BNL / BNB: slots that hold an image pixel / one of this workgroup's own 36 pixels
   unsigned zoff[NB * PB];      // BNL / BNB: byte offset of the slot's pixel quad (input and side output have the same shape)
-  f32x4 yb[BNB ? NB * PB : 1];  // BNB: the BatchNorm layer's forward input at the slot
-  const __amdgpu_buffer_rsrc_t rby = srx_rsrc(BNB ? a.bnb.y : a.in, a.in_bytes);
+  f32x4 yb[(BNB || BNL) ? NB * PB : 1];  // BNB: the BatchNorm layer's forward input at the slot; BNL: the addend (or zeros)
+  const bool has_res = BNL && a.bnl.res != nullptr;
+  const __amdgpu_buffer_rsrc_t rby = srx_rsrc(BNB ? a.bnb.y : (has_res ? a.bnl.res : a.in), a.in_bytes);
 #pragma unroll
   for (int u = 0; u < NB * PB; ++u) {
     const int ih = r_first - 1 + pr, iw = pc - 1;
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     const unsigned off = (unsigned)((n * a.H + ih) * a.W + iw) * 256u + quad16;
     v[u] = srx_bload(rin, ok ? off : 0xffffffffu, 0);
     if constexpr (BNB) yb[u] = srx_bload(rby, ok ? off : 0xffffffffu, 0);
+    if constexpr (BNL) yb[u] = srx_bload(rby, (ok && has_res) ? off : 0xffffffffu, 0);  // (no addend: reads 0, touches nothing)
     if constexpr (BNL || BNB) {
       const unsigned q = (unsigned)(ih * a.W + iw - p0);  // (wraps for pixels in front of the tile)
       okm |= (ok ? 1u : 0u) << u;
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
         const float z = (v[u][e] - nmu[e]) * (nis[e] * ngm[e]) + nbt[e];
         o[e] = z > 0.f ? z : z * nsl;
       }
+      if (has_res) o += yb[u];
       v[u] = ((okm >> u) & 1u) ? o : f32x4{0.f, 0.f, 0.f, 0.f};
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[u]), rz,

@@ -68,6 +68,7 @@ struct srx_rt36_bn_t { const float* y; const float* mean; const float* invstd; c
 // their way into LDS; the workgroup also writes the transformed values of its own 36 pixels to z_out -- the tensor the
 // separate normalise pass would have produced, which the backward pass reads (see rowtile.hip)
 struct srx_rt36_bnl_t { const float* mean; const float* invstd; const float* gamma; const float* beta; const float* prelu;
+                        const float* res;  // optional addend behind the activation (a block's skip input), same shape as `in`
                         float* z_out; };
 // the same for a DATA GRADIENT whose input is the gradient arriving at the OUTPUT of a BatchNorm (+ PReLU) layer: the patch
 // pixels become that layer's input gradient (second pass of its backward: dy = gamma * invstd * (dz - sum_dz / M - xhat *

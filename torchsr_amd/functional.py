@@ -657,21 +657,28 @@ class _ResidualTower(Function):
         m = n * h * w
         L, s = _lib.lib(), _stream()
         saved, descs = [], None
-        for block in blocks:
+        # A normalise pass (bn1 + PReLU inside a block, bn2 + skip at its end) is not launched where the NEXT conv can apply it
+        # while staging its input (srx_conv2d_fwd_bn_in: `pending` = (y, mean, invstd, gamma, beta, slope, residual, result));
+        # the result tensor is written by that conv on the side.  Only the last block's bn2 + skip is a launch of its own.
+        pending = None
+        fuse = None
+        for bi, block in enumerate(blocks):
             convs, bns = (block.conv1, block.conv2), (block.bn1, block.bn2)
             inp, ys, stats = x, [], []
-            pending = None  # (y1, mean1, invstd1, gamma1, beta1, slope, a1): bn1 + PReLU left to conv2's input staging
             for i in range(2):
                 st, bn = convs[i]._st, bns[i]
                 d = st.desc(n, h, w)
                 dref = C.byref(d)
+                if fuse is None:
+                    fuse = L.srx_conv2d_fwd_bn_in_ok(dref) == 1
                 st.pack(convs[i].weight, d)
                 y = torch.empty_like(x)
                 part = torch.empty((L.srx_conv2d_stat_rows(dref), c, 2), dtype=torch.float32, device=x.device)
-                if pending is not None:  # conv2 normalises + activates conv1's output while it stages it, and writes a1
-                    y1, mean1, inv1, g1, b1, slope, a1 = pending
-                    call('srx_conv2d_fwd_bn_in', dref, _p(y1), _p(mean1), _p(inv1), _p(g1), _p(b1), _p(slope), _p(a1),
+                if pending is not None:
+                    py, pmean, pinv, pg, pb, pslope, pres, pout = pending
+                    call('srx_conv2d_fwd_bn_in', dref, _p(py), _p(pmean), _p(pinv), _p(pg), _p(pb), _p(pslope), _p(pres), _p(pout),
                          _p(st.wpk_fwd), None, _p(y), _p(part), s)
+                    pending = None
                 else:
                     nws = L.srx_conv2d_fwd_ws_floats(dref)
                     call('srx_conv2d_fwd', dref, _p(inp), _p(st.wpk_fwd), None, _p(y), _p(part), _p(_ws(nws, x)) if nws else None, nws, s)
@@ -680,21 +687,22 @@ class _ResidualTower(Function):
                 out = torch.empty_like(x)
                 momentum = 0.1 if bn.momentum is None else bn.momentum
                 g, b = bn.weight.detach(), bn.bias.detach()
-                if i == 0 and L.srx_conv2d_fwd_bn_in_ok(C.byref(convs[1]._st.desc(n, h, w))):
-                    # BN1: statistics only; the normalise + PReLU pass rides in conv2's launch (srx_conv2d_fwd_bn_in)
+                last = i == 1 and bi == len(blocks) - 1
+                if fuse and not last:  # statistics only; the normalise pass rides in the next conv's launch
                     call('srx_bn_finalize', _p(part), part.shape[0], m, c, bn.eps, momentum, _p(mean), _p(invstd),
                          _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), s)
-                    pending = (y, mean, invstd, g, b, block.prelu.weight.detach(), out)
-                    a1 = inp = out
+                    pending = (y, mean, invstd, g, b, block.prelu.weight.detach(), None, out) if i == 0 else \
+                        (y, mean, invstd, g, b, None, x, out)
                 elif i == 0:   # BN1 + PReLU
                     call('srx_bn_train_fwd', _p(y), _p(part), part.shape[0], m, c, 1, bn.eps, momentum, _p(g), _p(b), None, _p(out),
                          ACT_PRELU, 0.0, _p(block.prelu.weight.detach()), _p(mean), _p(invstd), _p(bn.running_mean),
                          _p(bn.running_var), _p(bn.num_batches_tracked), s)
-                    a1 = inp = out
                 else:        # BN2 + skip connection
                     call('srx_bn_train_fwd', _p(y), _p(part), part.shape[0], m, c, 1, bn.eps, momentum, _p(g), _p(b), _p(x), _p(out),
                          ACT_NONE, 0.0, None, _p(mean), _p(invstd), _p(bn.running_mean), _p(bn.running_var),
                          _p(bn.num_batches_tracked), s)
+                if i == 0:
+                    a1 = inp = out
                 ys.append(y)
                 stats += [mean, invstd]
                 descs = d
