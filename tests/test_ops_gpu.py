@@ -992,7 +992,8 @@ def test_data_gradient_with_bn_backward_reduce_epilogue(dev, prelu):
 
 @pytest.mark.parametrize('prelu', [True, False])
 @pytest.mark.parametrize('below', [True, False])
-def test_data_gradient_with_batchnorm_backward_on_its_input(dev, prelu, below):
+@pytest.mark.parametrize('shape', [(4, 12, 12), (2, 48, 48)])  # (48 wide: two batches of patch loads per thread)
+def test_data_gradient_with_batchnorm_backward_on_its_input(dev, prelu, below, shape):
     """``srx_conv2d_bwd_data_bn_in`` (the apply pass of the BatchNorm (+ PReLU) backward ABOVE a conv formed while the conv's
     data gradient stages its input, the conv's output gradient written on the side; optionally the reduce pass of the
     BatchNorm BELOW in the epilogue) against the separate launches: same dy, same dx, same table to rounding."""
@@ -1000,7 +1001,7 @@ def test_data_gradient_with_batchnorm_backward_on_its_input(dev, prelu, below):
     from torchsr_amd import _lib
     L = _lib.lib()
     s = torch.cuda.current_stream().cuda_stream
-    n, h, w, c = 4, 12, 12, 64
+    (n, h, w), c = shape, 64
     m = n * h * w
     d = _lib.Conv2dDesc(n, h, w, c, c, c, c, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
     assert L.srx_conv2d_bwd_data_bn_in_ok(C.byref(d)) == 1
@@ -1087,7 +1088,7 @@ def test_output_conv_with_bf16_products(dev, k, n, h, w):
 
 
 @pytest.mark.parametrize('prelu', [True, False])
-@pytest.mark.parametrize('n,h,w', [(4, 12, 12), (16, 24, 24), (1, 6, 18)])
+@pytest.mark.parametrize('n,h,w', [(4, 12, 12), (16, 24, 24), (1, 6, 18), (2, 48, 48)])  # (48 wide: two batches of patch loads)
 def test_forward_conv_with_batchnorm_on_its_input(dev, prelu, n, h, w):
     """``srx_conv2d_fwd_bn_in`` (normalise + PReLU of the conv below -- or normalise + skip addend, the end of a residual block --
     applied while this conv stages its input, the result tensor written on the side) against the separate launches
