@@ -41,11 +41,13 @@ def get_device(args: Namespace) -> torch.device:
     count = torch.cuda.device_count()
     if args.local_world_size > count:
         print('More processes per node requested than GPUs found')
-        print('Assuming CPU-only mode...')
+        print('Assuming CPU-only mode... (torchsr_amd has no CPU compute path: train / test need an MI355X and will stop;'
+              ' the CPU restatement of the reference lives in oracle/ for tests only)')
         return torch.device('cpu')
     if count < 1 or not torch.cuda.is_available():
         print('No GPUs found')
-        print('Running in CPU-only mode...')
+        print('Running in CPU-only mode... (torchsr_amd has no CPU compute path: train / test need an MI355X and will stop;'
+              ' the CPU restatement of the reference lives in oracle/ for tests only)')
         return torch.device('cpu')
     return torch.device('cuda')
 
