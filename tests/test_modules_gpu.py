@@ -131,10 +131,13 @@ def test_discriminator_forward_pair_equals_two_calls(dev, kind, n, size):
         assert rel(er, b(real)) < 1e-5 and rel(ef, b(fake)) < 1e-5
 
 
-def test_residual_block_one_node_equals_layer_by_layer(dev):
-    """Under a trainer (gradients accumulate straight into the flat buffers) every ResidualBlock is one autograd node
-    whose conv1 data gradient carries the skip connection's gradient in its epilogue; without one it is five nodes
-    plus autograd's add.  Same kernels otherwise: outputs bit-equal, gradients and BatchNorm state to rounding."""
+@pytest.mark.parametrize('shape', [(2, 12, 12), (16, 24, 24), (1, 48, 48)])  # (48 wide: two batches of patch loads per thread)
+def test_residual_block_one_node_equals_layer_by_layer(dev, shape):
+    """Under a trainer (gradients accumulate straight into the flat buffers) the 16 ResidualBlocks are ONE autograd node
+    (``functional._ResidualTower``): the skip connection's gradient in conv1's data-gradient epilogue, every BatchNorm
+    normalise pass formed while the next conv stages its input, every BatchNorm backward reduced in the producing data
+    gradient's epilogue and applied while the consuming data gradient stages its input.  Without a trainer a block is five
+    nodes plus autograd's add.  Outputs bit-equal, gradients and BatchNorm state to rounding."""
     from torchsr_amd import functional as F
     from torchsr_amd.optim import FlatParams
     from torchsr_amd.srgan.generator import Generator
@@ -142,7 +145,7 @@ def test_residual_block_one_node_equals_layer_by_layer(dev):
     a, b = Generator().to(dev).train(), Generator().to(dev).train()
     b.load_state_dict(a.state_dict())
     flat = FlatParams(a)
-    x = torch.rand(2, 3, 12, 12, device=dev)
+    x = torch.rand(shape[0], 3, shape[1], shape[2], device=dev)
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
     old = F.direct_grads[0]
     try:
@@ -159,7 +162,9 @@ def test_residual_block_one_node_equals_layer_by_layer(dev):
     assert torch.equal(ya, yb)
     assert rel(xa.grad, xb.grad) < 1e-5
     for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-        assert rel(pa.grad, pb.grad) < 1e-5, k
+        # (a PReLU slope's gradient is ONE sum over every activation of its layer, positive and negative terms cancelling to
+        # ~1e-6: the two paths add its partials in different orders)
+        assert rel(pa.grad, pb.grad) < (1e-4 if pa.numel() == 1 else 1e-5), k
     for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         if 'running_' in k or 'num_batches' in k:
             assert torch.equal(va, vb), k
