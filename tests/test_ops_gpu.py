@@ -1064,6 +1064,39 @@ def test_data_gradient_with_batchnorm_backward_on_its_input(dev, prelu, below, s
     assert torch.equal(s_a[:2 * c + 1], s_b[:2 * c + 1])
 
 
+@pytest.mark.parametrize('n,h,w,cin,cout,stride', [(4, 24, 24, 64, 64, 2), (2, 13, 17, 64, 128, 2), (32, 96, 96, 64, 64, 2),
+                                                   (2, 20, 20, 64, 64, 1)])
+def test_strided_data_gradient_with_activation_backward(dev, n, h, w, cin, cout, stride):
+    """``srx_conv2d_bwd_data_act`` on STRIDED layers (the four stride-parity classes of the data gradient each mask their own
+    output pixels): the data gradient followed by the backward of the LeakyReLU that produced the conv's input, against the
+    two separate launches -- bit for bit.  (The discriminators' first conv + LeakyReLU under their stride-2 second conv.)"""
+    import ctypes as C
+    from torchsr_amd import _lib
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    d = _lib.Conv2dDesc(n, h, w, cin, cin, cout, cout, 3, 3, stride, 1, 0, 0, 0.0, 0, 0)
+    g = torch.Generator().manual_seed(3 + h)
+    rnd = lambda *shape: torch.randn(*shape, generator=g).to(dev)  # noqa: E731
+    wt = rnd(cout, cin, 3, 3) * 0.05
+    wf = torch.empty(L.srx_conv2d_packed_fwd_floats(C.byref(d)), device=dev)
+    wb = torch.empty(L.srx_conv2d_packed_bwd_floats(C.byref(d)), device=dev)
+    _lib.call('srx_conv2d_pack', C.byref(d), wt.data_ptr(), wf.data_ptr(), wb.data_ptr(), s)
+    dy, x = rnd(n, ho, wo, cout), rnd(n, h, w, cin)  # x: the activation output the conv read in the forward pass
+    nws = L.srx_conv2d_bwd_data_ws_floats(C.byref(d))
+    ws = torch.empty(max(nws, 4), device=dev)
+    dx0, dx1, dx2 = torch.empty_like(x), torch.empty_like(x), torch.full_like(x, float('nan'))
+    _lib.call('srx_conv2d_bwd_data', C.byref(d), dy.data_ptr(), wb.data_ptr(), dx0.data_ptr(), 0, ws.data_ptr(), nws, s)
+    _lib.call('srx_act_bwd_from_out', dx0.data_ptr(), x.data_ptr(), dx1.data_ptr(), x.numel(), _lib.ACT_LRELU, 0.2, s)
+    _lib.call('srx_conv2d_bwd_data_act', C.byref(d), dy.data_ptr(), wb.data_ptr(), x.data_ptr(), 0.2, 0, cin, 0, dx2.data_ptr(),
+              ws.data_ptr(), nws, s)
+    torch.cuda.synchronize()
+    assert torch.equal(dx1, dx2)
+    ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt.double().cpu(), dy.permute(0, 3, 1, 2).double().cpu(), stride=stride, padding=1)
+    ref = ref * torch.where(x.permute(0, 3, 1, 2).cpu() > 0, 1.0, 0.2)
+    assert rel_err(dx2.permute(0, 3, 1, 2), ref) < 1e-5
+
+
 @pytest.mark.parametrize('k,n,h,w', [(9, 2, 40, 70), (3, 1, 33, 45), (3, 40, 96, 96), (9, 1, 7, 5)])
 def test_output_conv_with_bf16_products(dev, k, n, h, w):
     """``srx_conv2d_t::precision = 2``: the 64 -> 3 output convs (9x9 SRGAN, 3x3 ESRGAN) with bf16-rounded operands on

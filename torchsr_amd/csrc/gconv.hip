@@ -2014,8 +2014,8 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
     SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data_add: stride-1 layers without accumulate only");
   if (accumulate && (d->stride != 1 || srx_thin_dgrad_applicable(d) || rt36))
     SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: accumulate is implemented for stride-1 layers on the generic kernel only");
-  if (act_out && (d->stride != 1 || srx_thin_dgrad_applicable(d)))
-    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data_act: stride-1 layers on the generic kernel only");
+  if (act_out && (srx_thin_dgrad_applicable(d) || (d->stride != 1 && accumulate)))
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data_act: layers on the generic kernel only (strided ones without accumulate)");
   if (act_out) SRX_REQUIRE(c_lo >= 0 && c_lo < c_hi && c_lo % 4 == 0 && (c_hi % 4 == 0 || c_hi >= d->Cin) && c_lo < d->Cin_s,
                            "conv2d_bwd_data_act: the masked channel range must be made of whole quads inside the row");
   hipStream_t st = srx_stream(stream);

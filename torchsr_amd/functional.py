@@ -348,8 +348,13 @@ def bump_pack_epoch() -> None:
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], st: ConvState, want_stats: bool,
-                master: Tensor):
+                master: Tensor, in_act=None, act_bwd_folded: bool = False):
+        # in_act = (act, slope): x is the output of a fused ReLU / LeakyReLU whose backward this conv's data gradient
+        # applies in its epilogue (srx_conv2d_bwd_data_act, mask = x); the producer is then called with act_bwd_folded
+        # and skips the elementwise pass (a read of two tensors and a write of one, 226 MB for the discriminator's first
+        # layer at batch 32).  Only for a producer whose output feeds this conv and nothing else.
         ctx.set_materialize_grads(False)
+        ctx.in_act, ctx.act_bwd_folded = in_act, act_bwd_folded
         x = _chk(x, 'conv2d.input')
         n, h, w, cs = x.shape
         if cs != st.cin_s:
@@ -385,7 +390,7 @@ class _Conv2d(Function):
         x, y = ctx.saved_tensors
         dy = _chk(dy, 'conv2d.grad')
         s = _stream()
-        if st.act != ACT_NONE:
+        if st.act != ACT_NONE and not ctx.act_bwd_folded:
             g = torch.empty_like(dy)
             call('srx_act_bwd_from_out', _p(dy), _p(y), _p(g), dy.numel(), st.act, st.slope, s)
             dy = g
@@ -394,7 +399,11 @@ class _Conv2d(Function):
             dx = torch.empty_like(x)
             nws = L.srx_conv2d_bwd_data_ws_floats(dref)
             ws = _ws(nws, x) if nws else None
-            call('srx_conv2d_bwd_data', dref, _p(dy), _p(ctx.wpk_bwd), _p(dx), 0, _p(ws), nws, s)
+            if ctx.in_act is not None:  # ... and the backward of the activation that produced x
+                slope = 0.0 if ctx.in_act[0] == ACT_RELU else float(ctx.in_act[1])
+                call('srx_conv2d_bwd_data_act', dref, _p(dy), _p(ctx.wpk_bwd), _p(x), slope, 0, st.cin_s, 0, _p(dx), _p(ws), nws, s)
+            else:
+                call('srx_conv2d_bwd_data', dref, _p(dy), _p(ctx.wpk_bwd), _p(dx), 0, _p(ws), nws, s)
         wparam, bparam = ctx.params
         bias_done = False
         if ctx.needs_input_grad[1]:
@@ -439,13 +448,14 @@ class _Conv2d(Function):
                 db = torch.empty(st.cout, dtype=torch.float32, device=dy.device)
                 nws = L.srx_colsum_ws_floats(m, st.cout)
                 call('srx_colsum', _p(dy), _p(db), m, st.cout, st.cout_s, 0, _p(_ws(nws, dy)), nws, s)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], st: ConvState, want_stats: bool = False,
-           master: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
-    """NHWC conv.  Returns ``(y, bn_partials)``; ``bn_partials`` is ``None`` unless requested."""
-    return _Conv2d.apply(x, weight, bias, st, want_stats, weight if master is None else master)
+           master: Optional[Tensor] = None, in_act=None, act_bwd_folded: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """NHWC conv.  Returns ``(y, bn_partials)``; ``bn_partials`` is ``None`` unless requested.  ``in_act`` /
+    ``act_bwd_folded``: see ``_Conv2d.forward`` (a pair of flags for a producer / consumer pair of convs)."""
+    return _Conv2d.apply(x, weight, bias, st, want_stats, weight if master is None else master, in_act, act_bwd_folded)
 
 
 # --------------------------------------------------------------------------- batch norm (+act, +residual)

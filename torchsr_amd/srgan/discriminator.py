@@ -1,4 +1,6 @@
 """SRGAN discriminator -- interface of torchsr/srgan/discriminator.py:26-88."""
+import os
+
 import torch
 from torch import nn, Tensor
 
@@ -30,7 +32,10 @@ class Discriminator(nn.Module):
         """``groups`` > 1: the batch holds that many forward calls of the reference back to back (``forward_pair``);
         every BatchNorm then normalises each call's rows with their own statistics."""
         mods = list(self.features)
-        out = mods[0](x4)
+        # the first conv's LeakyReLU backward rides in the second conv's (strided) data gradient: its output feeds nothing else
+        fold = torch.is_grad_enabled() and mods[0]._st.act == ACT_LRELU and not os.environ.get('SRX_NO_ACT_FOLD')  # (developer switch)
+        out = mods[0](x4, act_bwd_folded=fold)
+        in_act = (ACT_LRELU, mods[0]._st.slope) if fold else None
         i = 2
         while i < len(mods):
             conv, bn = mods[i], mods[i + 1]
@@ -40,7 +45,8 @@ class Discriminator(nn.Module):
                 # own statistics (row blocks of srx_bn_rows_per_block) instead of taking them from the conv epilogue
                 n, h, w, _ = out.shape
                 stats = F.bn_groups_ok(conv._st.out_rows(n, h, w), F.conv_stat_tile_rows(conv._st, n, h, w), groups)
-            y, part = conv(out, want_stats=True) if stats else (conv(out), None)
+            y, part = conv(out, want_stats=True, in_act=in_act) if stats else (conv(out, in_act=in_act), None)
+            in_act = None
             out = bn(y, part, act=ACT_LRELU, slope=0.2, groups=groups)
             i += 3
         out = F.cut_point('d.head', out)  # data parallel: classifier.* gradients are a bucket of their own
