@@ -1,4 +1,7 @@
 """ESRGAN generator (RRDBNet) -- interface of torchsr/esrgan/generator.py:32-81."""
+import os
+
+import torch
 from torch import nn, Tensor
 
 from .. import functional as F
@@ -40,8 +43,10 @@ class Generator(nn.Module):
         out = F.axpby(conv1, conv2, 1.0, 1.0)                       # torch.add, generator.py:72
         out = F.cut_point('g.tail', out)                            # data parallel: upsample* / conv3 / conv4 gradients go out first
         out = self.upsample1(out)                                   # :73-75 (nearest x2 in the conv's gather)
-        out = self.upsample2(out)                                   # :76-78
-        return self.conv4(self.conv3[0](out))                       # :79-80
+        # upsample2's LeakyReLU backward rides in conv3's data gradient (its output feeds conv3 and nothing else)
+        fold = torch.is_grad_enabled() and self.upsample2._st.act == ACT_LRELU and not os.environ.get('SRX_NO_ACT_FOLD')
+        out = self.upsample2(out, act_bwd_folded=fold)              # :76-78
+        return self.conv4(self.conv3[0](out, in_act=(ACT_LRELU, self.upsample2._st.slope) if fold else None))  # :79-80
 
     def forward(self, x: Tensor) -> Tensor:
         return F.to_nchw(self.forward_nhwc(F.to_nhwc(x, 4)), 3)
