@@ -1,6 +1,7 @@
 """Headline benchmark: 96x96 HR crops/sec of the SRGAN GAN train step on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...          (N > 1 outside torchrun: starts its own N ranks as a child process, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -366,21 +367,88 @@ def other_configs(device):
     return out
 
 
-def dp_rehearsal(timeout_s=240):
-    """The data-parallel form of the step on RCCL at world size 1, in a child process (its own process group; a hang
-    in there cannot take the headline with it): ``SRX_BENCH_FORCE_DIST=1 python bench.py``.  Returns the child's
-    ``dp`` object: backend, buckets, segmented vs fused ms per step on the same GPU."""
+def _free_port():
+    import socket
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    return port
+
+
+def self_launch(args, argv):
+    """``python bench.py --gpus N`` with N > 1 and no torchrun environment: this process touches NO GPU call; it starts
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...``
+    as a CHILD (never exec: a process must not be replaced once anything may have initialised the GPU), relays the rank-0
+    JSON line and returns the child's exit code."""
     import subprocess
-    env = dict(os.environ, SRX_BENCH_FORCE_DIST='1')
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print('bench.py: launching ' + ' '.join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:  # the ranks' other output goes on to stderr; the one JSON line is relayed on stdout
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln.rstrip('\n')
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print('bench.py: the ranks exited 0 without a JSON line', file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def _dp_child(extra_env, steps=40, timeout_s=240):
+    """One run of the data-parallel form of the step at world size 1 on RCCL, in a child process (its own process group and
+    its own plans: ``SRX_RESERVED_CUS`` is read when the library loads).  Returns the child's ``dp`` object."""
+    import subprocess
+    env = dict(os.environ, SRX_BENCH_FORCE_DIST='1', **extra_env)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.abspath(__file__), '--steps', '40', '--warmup', '5', '--no-parity', '--no-roofline',
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', '5', '--no-parity', '--no-roofline',
            '--no-cpu-baseline', '--no-other-configs']
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
     if res.returncode != 0:
         raise RuntimeError(f'child exited {res.returncode}: {res.stderr[-400:]}')
     line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
     return json.loads(line)['dp']
+
+
+def dp_rehearsal(contention=(8, 16, 32)):
+    """The data-parallel form of the step on RCCL at world size 1, in a child process (a hang in there cannot take the
+    headline with it): ``SRX_BENCH_FORCE_DIST=1 python bench.py``.  Returns the child's ``dp`` object -- backend, buckets,
+    segmented vs fused ms per step on the same GPU -- plus ``cu_contention``: the segmented step while a side-stream kernel
+    HOLDS k compute units (``srx_occupy_cus``: k workgroups that each claim a CU's whole LDS, so nothing else becomes
+    resident there -- the worst case for RCCL's channel workgroups, which in fact co-reside and mostly wait), with plans cut
+    for the whole chip and with plans told about the k CUs (``SRX_RESERVED_CUS``).  The one-GPU estimate of what the
+    all-reduce's channel kernels cost grids that are cut for exactly 256 CUs; N > 1 itself stays unmeasured."""
+    dp = _dp_child({})
+    table = []
+    for k in contention:
+        row = {'cus_held': k}
+        for name, env in (('plans_for_256', {'SRX_BENCH_OCCUPY_CUS': str(k)}),
+                          ('plans_for_free_cus', {'SRX_BENCH_OCCUPY_CUS': str(k), 'SRX_RESERVED_CUS': str(k)})):
+            try:
+                child = _dp_child(env, steps=30)
+                row[name + '_ms'] = child['segmented_ms_per_step']
+                row.setdefault('plan_cus', {})[name] = child.get('plan_cus')
+            except Exception as exc:  # noqa: BLE001
+                row[name + '_ms'] = None
+                row[name + '_error'] = f'{type(exc).__name__}: {str(exc)[-200:]}'
+        table.append(row)
+    dp['cu_contention'] = {'unheld_segmented_ms': dp['segmented_ms_per_step'], 'rows': table,
+                           'how': 'k whole CUs held by srx_occupy_cus on a side stream for the whole timed region'}
+    return dp
+
+
+def _plan_cus():
+    from torchsr_amd import _lib
+    return int(_lib.lib().srx_plan_cus())
 
 
 def cpu_baseline(states, lr, hr, warmup=3, steps=10, budget_s=60.0):
@@ -433,12 +501,13 @@ def main():
     ap.add_argument('--no-dp-rehearsal', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))  # before anything touches the GPU
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     # SRX_BENCH_ONE_GPU=1 + SRX_BENCH_BACKEND=gloo: rehearse the N>1 control flow with all ranks on one card
     dev_index = 0 if os.environ.get('SRX_BENCH_ONE_GPU') == '1' else local_rank
@@ -449,14 +518,10 @@ def main():
     forced = world == 1 and os.environ.get('SRX_BENCH_FORCE_DIST') == '1'
     distributed = world > 1 or forced
     if forced:
-        import socket
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         if 'MASTER_PORT' not in os.environ:
-            sock = socket.socket()
-            sock.bind(('127.0.0.1', 0))
-            os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
-            sock.close()
+            os.environ['MASTER_PORT'] = str(_free_port())
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('SRX_BENCH_BACKEND', 'nccl')  # 'nccl' is RCCL on ROCm
@@ -488,20 +553,45 @@ def main():
     for _ in range(args.warmup):
         trainer.gan_step(lr, hr)
 
+    # SRX_BENCH_OCCUPY_CUS=k (dp_rehearsal's contention legs): k whole CUs are held by a side-stream kernel for the timed region
+    occupy = int(os.environ.get('SRX_BENCH_OCCUPY_CUS', '0'))
+    side, stop_flag = None, None
+    if occupy > 0:
+        from torchsr_amd import _lib
+        torch.cuda.synchronize()
+        stop_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        side = torch.cuda.Stream()
+        _lib.call('srx_occupy_cus', occupy, 1, stop_flag.data_ptr(), 20000, side.cuda_stream)  # launched on an idle chip
+        time.sleep(0.05)                                                                        # ... and resident before the steps
+
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    if side is None:
+        torch.cuda.synchronize()
+    else:
+        torch.cuda.current_stream().synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = trainer.gan_step(lr, hr)
+    torch.cuda.current_stream().synchronize()
+    own_elapsed = time.perf_counter() - t0  # this rank's steps alone, before it waits for the others
+    if side is not None:
+        stop_flag[0] = 1  # the holder kernel sees the flag and exits (or its own deadline ends it)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = own_elapsed if side is not None else time.perf_counter() - t0
+    rank_ms = None
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([own_elapsed / args.steps * 1e3], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per = [float(v.item()) for v in every]
+        rank_ms = {'min': round(min(per), 3), 'max': round(max(per), 3), 'per_rank': [round(v, 3) for v in per],
+                   'what': "each rank's own ms per step (host clock around its timed steps, before the closing barrier)"}
     gen_loss = float(losses['gan/train-loss'])
     if not (gen_loss == gen_loss):
         sys.exit('bench.py: generator loss is NaN')
@@ -532,6 +622,7 @@ def main():
               'bucket_bytes': {'generator': [int(x.numel()) * 4 for x in trainer.gen_sync.slices],
                                'discriminator': [int(x.numel()) * 4 for x in trainer.disc_sync.slices]},
               'graph_segments': sorted(k for k in trainer._graphs), 'hip_graph': trainer.use_graphs,
+              'cus_held': occupy, 'plan_cus': _plan_cus(),
               'segmented_ms_per_step': round(seg_ms, 3), 'fused_ms_per_step': round(fused_ms, 3),
               'segmentation_overhead': round(seg_ms / fused_ms - 1.0, 4), 'steps': args.steps,
               'what': 'SRGAN GAN step, batch 16, world size 1 on RCCL: 7 hipGraph segments + 4 async all-reduces '
@@ -563,7 +654,9 @@ def main():
                        'vgg19_weights': 'pretrained' if trainer.vgg_loss.pretrained else 'seeded-random',
                        'process_group': describe_group(),
                        'grad_buckets': ({'generator': len(trainer.gen_sync), 'discriminator': len(trainer.disc_sync)}
-                                        if distributed else None)},
+                                        if distributed else None),
+                       'plan_cus': _plan_cus()},
+            'per_rank_ms_per_step': rank_ms,
             'step_tflops': round(value * GF_PER_CROP / 1e3, 2),
             'step_frac_of_fp32_mfma_peak': round(value * GF_PER_CROP / 1e3 / (PEAK_TFLOPS * world), 4),
             'step_ms_spread': spread,

@@ -49,8 +49,23 @@ enum { SRX_ACT_NONE = 0, SRX_ACT_RELU = 1, SRX_ACT_LRELU = 2, SRX_ACT_PRELU = 3 
 int srx_version(void);
 /* copies the calling thread's last error message (NUL terminated) into buf */
 int srx_last_error(char* buf, size_t n);
+/* sha256 (64 hex digits) of the sources this binary was compiled from -- the build's identity: the host refuses (or
+ * rebuilds) a library whose digest differs from the sources lying next to it (torchsr_amd/_lib.py).  No reference counterpart. */
+int srx_build_info(char* buf, size_t n);
 /* number of compute units of the current device (used by the host for launch heuristics) */
 int srx_device_cus(void);
+/* Compute units the launch plans may count on = srx_device_cus() less `k` reserved ones (0..128).  Data-parallel training
+ * overlaps the gradient all-reduce (torchsr/srgan/trainer.py:142-157: DistributedDataParallel) with the backward pass, and
+ * RCCL's channel workgroups then hold CUs: a grid cut for exactly 256 CUs runs two rounds on 248.  Set ONCE, before any
+ * model is built (row counts of BatchNorm partial tables and workspace sizes follow the plans); also SRX_RESERVED_CUS at
+ * load time.  srx_plan_cus() returns the count the plans use. */
+int srx_set_reserved_cus(int k);
+int srx_plan_cus(void);
+/* Measurement aid (bench.py's data-parallel rehearsal; no reference counterpart): occupies `k` compute units -- k workgroups that each
+ * claim a whole CU's LDS, so nothing else becomes resident there (`whole_cu` != 0), or k co-resident workgroups that only
+ * spin (`whole_cu` == 0) -- until *stop_flag (host-visible, 4 bytes) is non-zero or `max_ms` milliseconds have passed on
+ * the device clock, whichever comes first; every wave reaches that exit. */
+int srx_occupy_cus(int k, int whole_cu, const int* stop_flag, int max_ms, void* stream);
 /* Per-launch timing of the convolution kernels (measurement aid for bench.py's roofline leg; no
  * reference counterpart).  Between start and stop every conv kernel is dispatched with its own start /
  * stop HIP events on its stream (hipExtLaunchKernelGGL) -- the main kernel only, not its fix-up / reduce
@@ -287,7 +302,9 @@ size_t srx_rdb_packed_bytes(void);
  * dst: nblk * srx_rdb_packed_bytes() bytes.  One launch for all blocks (after an optimiser step). */
 int srx_rdb_pack(const float* const* w_table_dev, int nblk, void* dst, void* stream);
 /* extra (may be NULL): out = (that) * post_scale + extra -- the `out * 0.2 + x` that ends a ResidualInResidualDenseBlock
- * (esrgan/residual.py:128) in the epilogue of its third dense block; [N][H][W][extra_ld], channels 0..63, not aliasing out */
+ * (esrgan/residual.py:128) in the epilogue of its third dense block; [N][H][W][extra_ld], channels 0..63.  `extra` may be an
+ * OLDER block's buffer but never `out`, and `out` is never `buf` itself (neighbouring tiles read their halo from it while
+ * this one writes): both are refused. */
 int srx_rdb_fwd(int N, int H, int W, float* buf, int ld, const void* wpk, const float* const* bias5, float scale,
                 float slope, float post_scale, const float* extra, int extra_ld, float* out, int out_ld, void* stream);
 /* The block's data-gradient chain (autograd of the five convs and four LeakyReLUs of esrgan/residual.py:81-86 with

@@ -393,6 +393,58 @@ def test_abi_refuses_out_of_range_addends_slices_and_scales_without_a_gpu():
                                               fake, 1 << 40, None)
     assert rc != 0 and 'both convs or neither' in err()
 
+    # the fused dense block: its output never is the block buffer itself, its second addend never the output
+    biases = arr(fake, fake, fake, fake, fake)
+    rc = lib.srx_rdb_fwd(1, 8, 8, fake, 192, fake, biases, 0.2, 0.2, 1.0, None, 0, fake, 192, None)
+    assert rc != 0 and 'alias' in err()
+    rc = lib.srx_rdb_fwd(1, 8, 8, fake, 192, fake, biases, 0.2, 0.2, 0.2, fake + 4096, 192, fake + 4096, 192, None)
+    assert rc != 0 and 'of its own' in err()
+
+
+def test_library_carries_the_digest_of_its_sources(tmp_path):
+    """A build is identified by the sha256 of its sources, compiled into the binary (``srx_build_info``): a stale library
+    next to newer sources is detected by content, not by file times the builder controls."""
+    import ctypes as C
+    from torchsr_amd import _lib
+    want = _lib.source_digest()
+    assert len(want) == 64 and _lib.built_digest() == want
+    buf = C.create_string_buffer(80)
+    assert _lib.lib().srx_build_info(buf, 80) == 0 and buf.value.decode() == want
+    # a binary built from other sources is told apart whatever its mtime
+    blob = open(_lib.LIB_PATH, 'rb').read().replace(want.encode(), b'0' * 64)
+    other = tmp_path / 'libsrx_other.so'
+    other.write_bytes(blob)
+    assert _lib.built_digest(str(other)) == '0' * 64 != want
+
+
+def test_plans_follow_the_reserved_compute_units_without_a_gpu():
+    """``srx_set_reserved_cus``: the residual tower's row tile cuts 16 x 24 x 24 pixels into 256 workgroups of 36 pixels on a
+    free chip and into 192 of 48 once CUs are held by a collective's channel kernels; the generic planner sizes its rounds
+    for the same count.  Plans are host code: no GPU needed (without one the library assumes 256 CUs)."""
+    import ctypes as C
+    from torchsr_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip('plan arithmetic for a 256-CU part; on a GPU box the count is the device\'s')
+    lib = _lib.lib()
+    d = _lib.Conv2dDesc(16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
+    out = (C.c_int * 6)()
+    try:
+        assert lib.srx_plan_cus() == 256
+        assert lib.srx_conv2d_plan(C.byref(d), 0, out) == 0 and (out[0], out[3]) == (36, 256)
+        assert lib.srx_conv2d_stat_rows(C.byref(d)) == 256
+        assert lib.srx_set_reserved_cus(16) == 0 and lib.srx_plan_cus() == 240
+        assert lib.srx_conv2d_plan(C.byref(d), 0, out) == 0 and (out[0], out[3]) == (48, 192)
+        assert lib.srx_conv2d_stat_rows(C.byref(d)) == 192
+        # a VGG layer (M = 18432 pixels, 256 channels): whole rounds of 240 CUs, the rest K-split
+        v = _lib.Conv2dDesc(32, 24, 24, 256, 256, 256, 256, 3, 3, 1, 1, 0, 1, 0.0, 0, 0)
+        assert lib.srx_conv2d_plan(C.byref(v), 0, out) == 0
+        full_rounds = (out[3] // 240) * 240
+        assert out[3] >= full_rounds and out[3] != 256
+        assert lib.srx_set_reserved_cus(500) != 0
+    finally:
+        lib.srx_set_reserved_cus(0)
+    assert lib.srx_plan_cus() == 256
+
 
 def test_vgg_loss_loads_a_torchvision_shaped_state_dict(tmp_path):
     """The pretrained branch of ``VGGLoss.__init__`` (torchsr/srgan/loss.py:30: ``vgg19(pretrained=True)``): the file

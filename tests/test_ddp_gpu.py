@@ -263,3 +263,29 @@ def test_two_rank_esrgan_step_matches_data_parallel_oracle(dev):
         assert rep['loss_gap'] < 1e-4 and rep['param_gap'] < 1e-3, (rank, rep)
         assert {'gan.disc.head', 'gan.disc.body', 'gan.content', 'gan.gen.head', 'gan.gen.body', 'gan.gopt'} <= \
             set(rep['graphs']), rep['graphs']
+
+
+def test_bench_starts_its_own_ranks_from_a_plain_python_call():
+    """``python bench.py --gpus 2`` outside torchrun must not exit with "launch me with torch.distributed.run" (an empty
+    SCALE record the day a multi-GPU node exists): the parent touches no GPU call, starts ``torch.distributed.run`` as a
+    child, relays the rank-0 JSON line and exits with the child's code.  Rehearsed on one GPU: both ranks on ``cuda:0``
+    over gloo (RCCL refuses two ranks on one device)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SRX_BENCH_ONE_GPU='1', SRX_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak'
+    assert out['config']['process_group'] == {'backend': 'gloo', 'world_size': 2, 'rank': 0}
+    assert out['config']['grad_buckets'] == {'generator': 2, 'discriminator': 2}
+    assert out['config']['global_batch'] == 32 and out['value'] > 0
+    per = out['per_rank_ms_per_step']
+    assert len(per['per_rank']) == 2 and per['min'] <= per['max'] <= out['ms_per_step'] * 1.5

@@ -122,7 +122,16 @@ def test_discriminator_forward_pair_equals_two_calls(dev, kind, n, size):
     # any kernel below (worst tensor 1.1-1.9 % over rounds 1-3; 2.3 % on features.8.weight of the ESRGAN case once the
     # first layer got a kernel of its own, everything else at 0.2-0.3 %).
     errs = {k: rel(pa.grad, pb.grad) for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters())}
-    assert max(errs.values()) < 4e-2, max(errs.items(), key=lambda kv: kv[1])
+    # the first layer's kernel computes every pixel independently of the batch size: layer 0 is bit-equal between the two
+    # paths, so no kink flip can start there
+    with torch.no_grad():
+        x4r, x4f = F.to_nhwc(real, 4), F.to_nhwc(fake, 4)
+        la = a.features[0](torch.cat([x4r, x4f]))
+        assert torch.equal(la[:n], b.features[0](x4r)) and torch.equal(la[n:], b.features[0](x4f))
+    # 2e-2 on every tensor; only the one tensor that has been seen above it (a kink flip under features.8's BatchNorm in
+    # the ESRGAN case) gets 4e-2 -- a bound on all tensors could hide a regression in the masked stride-2 data gradient
+    for k, v in errs.items():
+        assert v < (4e-2 if k == 'features.8.weight' else 2e-2), (k, v)
     assert all(v < 2e-5 for k, v in errs.items() if k.startswith('classifier')), errs
     assert sorted(errs.values())[len(errs) // 2] < 2 * TOL, errs
     a.eval(), b.eval()

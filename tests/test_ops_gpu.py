@@ -378,13 +378,14 @@ def test_scaled_grouped_weight_gradient_and_channel_axpby(dev):
         _lib.call('srx_axpby_channels', a.data_ptr(), 192, 160, b.data_ptr(), 96, 0, y.data_ptr(), 64, 0, 64, m, 1.0, 1.0, s)
 
 
-@pytest.mark.parametrize('bf16', [False, True])
-def test_paired_weight_gradient(dev, bf16):
+@pytest.mark.parametrize('bf16,geom', [(False, (2, 16, 16)), (True, (2, 16, 16)),
+                                       (True, (16, 32, 32))])  # config 4's paired problems on the image-row kernel
+def test_paired_weight_gradient(dev, bf16, geom):
     """srx_conv2d_bwd_weight_multi_pair: conv_a (cin_lo -> 32) and conv_b (Cin -> 32) of a dense block read the same
     192-channel buffer and their output gradients are adjacent 32-channel slices of one gradient buffer; issued as ONE
     64-column problem each pair, three pairs in one launch, accumulating into existing gradients, biases riding along."""
     from torchsr_amd import _lib
-    n, h, w, cin_lo, cin, g = 2, 16, 16, 128, 160, 32
+    (n, h, w), cin_lo, cin, g = geom, 128, 160, 32
     d = _lib.Conv2dDesc(n, h, w, cin, 192, 2 * g, 192, 3, 3, 1, 1, 0, 2, 0.2, 0, 1 if bf16 else 0)
     L = _lib.lib()
     s = torch.cuda.current_stream().cuda_stream
@@ -818,7 +819,8 @@ def test_conv2d_random_shapes(dev, case):
     test_conv2d_fwd_bwd(dev, case)
 
 
-@pytest.mark.parametrize('n,h,w', [(2, 16, 16), (1, 13, 21), (3, 8, 8), (1, 5, 40)])
+@pytest.mark.parametrize('n,h,w', [(2, 16, 16), (1, 13, 21), (3, 8, 8), (1, 5, 40),
+                                   (16, 32, 32)])  # BASELINE config 4's own launch: 256 workgroups, one per CU
 def test_fused_dense_block_forward(dev, n, h, w):
     """``srx_rdb_fwd`` (one launch: five convs, intermediates in LDS, bf16 products) against an fp64 evaluation of the same
     arithmetic -- every conv multiplies bf16-rounded inputs and weights, sums exactly, adds the fp32 bias; c1..c4 are kept
@@ -870,7 +872,7 @@ def test_fused_dense_block_forward(dev, n, h, w):
     assert torch.isnan(out[..., 64:]).all() and torch.equal(buf[..., :64].cpu(), x.permute(0, 2, 3, 1))  # nothing else touched
 
 
-@pytest.mark.parametrize('n,h,w', [(2, 16, 16), (1, 13, 21), (1, 5, 40)])
+@pytest.mark.parametrize('n,h,w', [(2, 16, 16), (1, 13, 21), (1, 5, 40), (16, 32, 32)])  # (16, 32, 32): config 4's launch
 def test_fused_dense_block_backward(dev, n, h, w):
     """``srx_rdb_bwd`` (the data-gradient chain of a dense block in one launch, bf16 products) against fp64: the slice
     gradients g4..g1 and the input gradient, stage by stage on the device's own earlier stages (see
@@ -1179,7 +1181,8 @@ def test_forward_conv_with_batchnorm_on_its_input(dev, prelu, n, h, w):
     assert rc != 0 and 'row tile' in _lib.last_error()
 
 
-@pytest.mark.parametrize('n,h,w,cin', [(2, 32, 32, 192), (3, 7, 32, 96), (1, 5, 16, 64)])
+@pytest.mark.parametrize('n,h,w,cin', [(2, 32, 32, 192), (3, 7, 32, 96), (1, 5, 16, 64),
+                                       (16, 32, 32, 192)])  # BASELINE config 4: 16 384 rows per problem
 def test_bf16_weight_gradient_on_image_rows(dev, n, h, w, cin):
     """The image-row bf16 weight-gradient kernel (3x3 / stride 1 / 64 output columns / rows of 16 or 32 pixels: ESRGAN's dense
     blocks) through ``srx_conv2d_bwd_weight_multi_scaled``: two problems with their own multipliers, bias gradients riding

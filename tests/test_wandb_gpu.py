@@ -128,3 +128,34 @@ def test_loss_ring_delivers_every_steps_loss(dev, monkeypatch):
     t._flush_losses()
     tail = [(c['psnr/train-loss'], s, c['psnr/epoch']) for c, s in stub.logs[11:]]
     assert tail == [(truth[11 + i], 200 + i, 1) for i in range(3)]
+
+
+def test_loss_ring_survives_steps_called_without_a_note(dev, monkeypatch):
+    """``gan_step`` called directly (bench, tests, user code) pushes a record nobody notes: the next flush must not
+    hand every later wandb sample another step's loss -- the ring resynchronises from the device counter."""
+    import torchsr_amd.srgan.trainer as trainer_mod
+    stub = install(monkeypatch)
+    stub.init(name='t')
+    monkeypatch.setattr(trainer_mod.SRGANTrainer, 'wandb_flush_every', 4)
+    args = Namespace(disable_amp=True, batch_size=2, epochs=8, gan_checkpoint=None, local_rank=0, pretrain_epochs=1,
+                     psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1, use_graphs=True, vgg_weights='random')
+    torch.manual_seed(0)
+    t = trainer_mod.SRGANTrainer(dev, args, [], [], 2, 2)
+    lr, hr = torch.rand(2, 3, 24, 24, device=dev), torch.rand(2, 3, 96, 96, device=dev)
+    for _ in range(3):
+        t.gan_step(lr, hr)  # three pushes, no note
+    t._flush_losses()       # nothing to deliver; the three records are skipped
+    assert stub.logs == [] and t._ring.unnoted == 3
+    truth = []
+    for step in range(6):
+        if step == 2:
+            t.gan_step(lr, hr)  # a stray direct call in the middle of a loop's window
+        t._gan_loop(lr, hr, 300 + step)
+        truth.append(t._losses['gan/train-loss'].item())
+    t._flush_losses()
+    got = [(c['gan/train-loss'], s) for c, s in stub.logs]
+    assert [s for _, s in got] == list(range(300, 306))
+    # the flush of steps 300..303 happened with one un-noted record in its window: the LAST four records are the noted ones
+    # except for the sample in front of the stray call; everything after that flush is exact again
+    assert [v for v, _ in got][4:] == truth[4:]
+    assert [v for v, _ in got][2:4] == truth[2:4]

@@ -1,0 +1,12 @@
+"""Developer switches (same-box A/B runs): read from the environment ONCE, at import -- never per forward call.
+The release behaviour is every switch off."""
+import os
+
+
+def _on(name: str) -> bool:
+    return os.environ.get(name, '') not in ('', '0')
+
+
+NO_ACT_FOLD = _on('SRX_NO_ACT_FOLD')            # keep the first LeakyReLU backward of the discriminators a pass of its own
+NO_BN_DGRAD_FUSE = _on('SRX_NO_BN_DGRAD_FUSE')  # residual tower: separate BatchNorm-backward reduce launches
+NO_RDB_FUSED = _on('SRX_NO_RDB_FUSED')          # ESRGAN dense blocks: five conv launches instead of srx_rdb_fwd / srx_rdb_bwd

@@ -37,19 +37,82 @@ class DgradEpilogue(C.Structure):
     ]
 
 
+def source_digest() -> str:
+    """sha256 over every source of the library (names + bytes, fixed order): the identity of a build."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in SOURCES + ['srx_common.h', os.path.join('..', '..', 'include', 'srx.h')]:
+        h.update(os.path.basename(name).encode() + b'\0')
+        with open(os.path.join(CSRC, name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def built_digest(path: str = None):
+    """The source digest a built library carries (``srx_build_info``), or None when it cannot be read."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path, 'rb') as f:
+            blob = f.read()
+    except OSError:
+        return None
+    tag = b'srx-build-sources-sha256:'
+    at = blob.find(tag)
+    if at < 0:
+        return None
+    return blob[at + len(tag):at + len(tag) + 64].decode('ascii', 'replace')
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into ``csrc/libsrx_hip.so`` (in-tree)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, 'srx_common.h'), os.path.join(_HERE, '..', 'include', 'srx.h')]
-    if not force and os.path.exists(LIB_PATH):
-        newest = max(os.path.getmtime(d) for d in deps)
-        if os.path.getmtime(LIB_PATH) >= newest:
-            return LIB_PATH
+    """Compile every HIP source for gfx950 into ``csrc/libsrx_hip.so`` (in-tree).
+
+    A build is identified by the sha256 of its sources, compiled into the library (``srx_build_info``): an existing
+    library is reused only when it carries the digest of the sources lying next to it -- never by file times.
+    ``force`` (or ``SRX_FORCE_BUILD=1``) recompiles every translation unit.  Objects are compiled in parallel into
+    ``csrc/build/`` and cached per source digest, so an edit recompiles one file."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    force = force or os.environ.get('SRX_FORCE_BUILD') == '1'
+    digest = source_digest()
+    if not force and built_digest(LIB_PATH) == digest:
+        return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB_PATH] + srcs
+    objdir = os.path.join(CSRC, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+    with open(os.path.join(CSRC, 'srx_common.h'), 'rb') as f:
+        hdr = f.read()
+    with open(os.path.join(_HERE, '..', 'include', 'srx.h'), 'rb') as f:
+        hdr += f.read()
+
+    def compile_one(name):
+        src = os.path.join(CSRC, name)
+        extra = ['-DSRX_SOURCES_SHA256="%s"' % digest] if name == 'api.cpp' else []
+        with open(src, 'rb') as f:
+            key = hashlib.sha256(hdr + f.read() + ' '.join(flags + extra).encode()).hexdigest()[:24]
+        obj = os.path.join(objdir, f'{os.path.splitext(name)[0]}.{key}.o')
+        if force or not os.path.exists(obj):
+            for stale in os.listdir(objdir):
+                if stale.startswith(os.path.splitext(name)[0] + '.') and stale.endswith('.o'):
+                    os.unlink(os.path.join(objdir, stale))
+            cmd = [hipcc] + flags + extra + ['-c', src, '-o', obj + '.tmp']
+            if verbose:
+                print(' '.join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True, cwd=CSRC)
+            os.replace(obj + '.tmp', obj)
+        return obj
+
+    jobs = max(1, min(len(SOURCES), int(os.environ.get('SRX_BUILD_JOBS', str(min(8, os.cpu_count() or 1))))))
+    with ThreadPoolExecutor(jobs) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB_PATH + '.tmp'] + objs
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    os.replace(LIB_PATH + '.tmp', LIB_PATH)
+    assert built_digest(LIB_PATH) == digest, 'the built library does not carry its source digest'
     return LIB_PATH
 
 
@@ -65,6 +128,10 @@ _SIGS = {
     'srx_version': (_I, []),
     'srx_last_error': (_I, [C.c_char_p, _Z]),
     'srx_device_cus': (_I, []),
+    'srx_build_info': (_I, [C.c_char_p, _Z]),
+    'srx_set_reserved_cus': (_I, [_I]),
+    'srx_plan_cus': (_I, []),
+    'srx_occupy_cus': (_I, [_I, _I, _P, _I, _P]),
     'srx_prof_start': (_I, [_I]),
     'srx_prof_stop': (_I, []),
     'srx_prof_get': (_I, [_I, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
@@ -152,7 +219,7 @@ _SIGS = {
     'srx_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
 }
 # functions whose int return value is data, not a status
-_UNCHECKED = {'srx_conv2d_bwd_data_bn_rows', 'srx_conv2d_fwd_bn_in_ok', 'srx_conv2d_bwd_data_bn_in_ok', 'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows', 'srx_bn_rows_per_block'}
+_UNCHECKED = {'srx_conv2d_bwd_data_bn_rows', 'srx_conv2d_fwd_bn_in_ok', 'srx_conv2d_bwd_data_bn_in_ok', 'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_plan_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows', 'srx_bn_rows_per_block'}
 
 EXPORTS = tuple(_SIGS.keys())
 
@@ -169,6 +236,27 @@ def load_handle(path: str) -> C.CDLL:
     return C.CDLL(path)
 
 
+def _ensure_fresh():
+    """The library must carry the digest of the sources next to it.  A stale one is rebuilt (under a file lock: test
+    runs start several processes) when hipcc is there; otherwise loading fails loudly -- never a silent old binary."""
+    want = source_digest()
+    if built_digest(LIB_PATH) == want:
+        return
+    import fcntl
+    with open(os.path.join(CSRC, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if built_digest(LIB_PATH) == want:
+            return
+        have = built_digest(LIB_PATH)
+        print(f'torchsr_amd: {LIB_PATH} was built from other sources ({have and have[:12]} != {want[:12]}); rebuilding',
+              file=sys.stderr)
+        try:
+            build()
+        except (OSError, subprocess.CalledProcessError) as exc:
+            raise RuntimeError(f'{LIB_PATH} is stale (built from sources {have and have[:12]}, the tree has {want[:12]}) and '
+                               f'could not be rebuilt: {exc}.  Run `python -c "import __graft_entry__ as g; g.build()"`.') from exc
+
+
 def lib() -> C.CDLL:
     """Load the shared library (once).  Raises if it has not been built."""
     global _lib
@@ -178,6 +266,8 @@ def lib() -> C.CDLL:
                 f'{LIB_PATH} is missing: the MI355X HIP extension has not been built. '
                 'Run `python -c "import __graft_entry__ as g; g.build()"` (needs hipcc). '
                 'There is no CPU fallback for the product path.')
+        if not os.environ.get('SRX_LIB') and os.environ.get('SRX_ALLOW_STALE') != '1':
+            _ensure_fresh()
         handle = load_handle(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             try:

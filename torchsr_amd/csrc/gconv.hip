@@ -1370,11 +1370,7 @@ int bwd_classes(const srx_conv2d_t* d, BwdClass* cls, size_t& total_floats) {
 // unless they leave the chip under-filled.
 struct Plan { int BM, BN, mtiles, ntiles, tiles, full, tail, split, kc_per_split, ks; float cost; };
 
-int device_cus() {
-  static int cus = 0;
-  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
-  return cus;
-}
+int device_cus() { return srx_plan_cus(); }  // the device's CUs less the reserved ones (api.cpp)
 
 Plan make_plan(int M, int Cnp, int kchunks, bool can_split, bool bf16 = false) {
   const int P = device_cus();
@@ -1418,9 +1414,9 @@ Plan make_plan(int M, int Cnp, int kchunks, bool can_split, bool bf16 = false) {
     if (p.cost < best.cost) best = p;
   }
   // developer override for tile experiments: SRX_FORCE_PLAN="BM,BN,split,ks" (split: K-split of ALL tiles)
-  if (const char* f = getenv("SRX_FORCE_PLAN")) {
-    int bm = 0, bn = 0, sp = 1, ks = 1;
-    if (sscanf(f, "%d,%d,%d,%d", &bm, &bn, &sp, &ks) == 4 && Cnp % bn == 0) {
+  if (srx_dev().force_plan) {
+    const int bm = srx_dev().plan[0], bn = srx_dev().plan[1], sp = srx_dev().plan[2], ks = srx_dev().plan[3];
+    if (bn > 0 && Cnp % bn == 0) {
       Plan p{};
       p.BM = bm; p.BN = bn; p.mtiles = (int)srx_cdiv(M, bm); p.ntiles = Cnp / bn; p.tiles = p.mtiles * p.ntiles;
       if (sp > 1 && can_split) { p.full = 0; p.tail = p.tiles; p.kc_per_split = (int)srx_cdiv(kchunks, sp); p.split = (int)srx_cdiv(kchunks, p.kc_per_split); }
@@ -1646,8 +1642,7 @@ extern "C" size_t srx_conv2d_bwd_data_ws_floats(const srx_conv2d_t* d) {
 // above a whole round of resident workgroups leave a nearly empty last round.  Calibrated on the SRGAN layer shapes
 // (bf16: tools/bench_kernels.py --graph, round 1; fp32: tools/wgrad_sweep.sh, round 3); SRX_WGRAD_NSPLIT overrides for experiments.
 static int wgrad_nsplit(int M, int64_t tiles, int nprob, int Cnw, int Kw, int precision) {
-  static int cus = 0;
-  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
+  const int cus = srx_plan_cus();
   const int max_by_rows = (int)srx_cdiv(M, 128);  // at least 128 rows per split
   int nsplit = 1;
   float best_cost = 1e30f;
@@ -1669,7 +1664,7 @@ static int wgrad_nsplit(int M, int64_t tiles, int nprob, int Cnw, int Kw, int pr
     }
     if (cost < best_cost) { best_cost = cost; nsplit = ns; }
   }
-  if (const char* e = getenv("SRX_WGRAD_NSPLIT")) { const int v = atoi(e); if (v > 0 && v <= 64 && v <= max_by_rows) nsplit = v; }
+  if (const int v = srx_dev().wgrad_nsplit; v > 0 && v <= 64 && v <= max_by_rows) nsplit = v;
   const int rps = (int)srx_roundup(srx_cdiv(M, nsplit), 32);
   return (int)srx_cdiv(M, rps);
 }
@@ -1677,14 +1672,12 @@ static int wgrad_nsplit(int M, int64_t tiles, int nprob, int Cnw, int Kw, int pr
 // bf16 products, 3x3 / stride 1 / pad 1, 64 output columns, whole 32-channel groups, image rows of 16 or 32 pixels (ESRGAN's
 // dense blocks at the training crop size): the image-row kernel (wgrad_rows_bf16_kernel)
 static bool wgrad_rows_ok(const srx_conv2d_t* d) {
-  static const bool off = getenv("SRX_NO_WGRAD_ROWS") != nullptr;  // developer switch (A/B runs)
-  if (off || !d->precision || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->shuffle || d->up == 2) return false;
+  if (srx_dev().no_wgrad_rows || !d->precision || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->shuffle || d->up == 2) return false;
   return d->Cout == 64 && srx_roundup(d->Cin, 4) % 32 == 0 && (d->W == 32 || d->W == 16);
 }
 // row splits of the image-row kernel: workgroups = channel groups x problems x splits, four resident per CU
 static int wgrad_rows_nsplit(const srx_conv2d_t* d, int nprob) {
-  static int cus = 0;
-  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
+  const int cus = srx_plan_cus();
   const int groups = (int)srx_roundup(d->Cin, 4) / 32, rows = d->N * d->H;
   int best = 1;
   float best_cost = 1e30f;
@@ -1695,7 +1688,7 @@ static int wgrad_rows_nsplit(const srx_conv2d_t* d, int nprob) {
     const float cost = rounds * (rps + 8.0f) + 0.25f * ns;  // (+ the slab reduction grows with the splits)
     if (cost < best_cost) { best_cost = cost; best = ns; }
   }
-  if (const char* e = getenv("SRX_WGRAD_ROWS_NSPLIT")) { const int v = atoi(e); if (v > 0 && v <= 64 && v <= rows) best = v; }
+  if (const int v = srx_dev().wgrad_rows_nsplit; v > 0 && v <= 64 && v <= rows) best = v;
   const int rps = (int)srx_cdiv(rows, best);
   return (int)srx_cdiv(rows, rps);
 }
@@ -1727,7 +1720,8 @@ extern "C" int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out) {
   Plan p;
   int multi = 0;
   if (srx_rt36_applicable(d)) {  // 36-pixel row tiles (rowtile.hip), forward and data gradient alike
-    out[0] = 36; out[1] = 64; out[2] = 1; out[3] = srx_rt36_rows(d); out[4] = 1; out[5] = 0;
+    const int rows = srx_rt36_rows(d);
+    out[0] = (int)((int64_t)d->N * d->H * d->W / rows); out[1] = 64; out[2] = 1; out[3] = rows; out[4] = 1; out[5] = 0;
     return SRX_OK;
   }
   if (which == 0) {
@@ -2121,8 +2115,7 @@ extern "C" int srx_conv2d_bwd_data_bn(const srx_conv2d_t* d, const float* dy, co
 // backward (sums finalised: srx_bn_act_bwd_finish with dy = NULL) runs while the patch is staged, dy_out receives the conv's
 // output gradient for its weight gradient.  table == NULL: no BatchNorm below (plain data gradient + addend).
 extern "C" int srx_conv2d_bwd_data_bn_in_ok(const srx_conv2d_t* d) {
-  static const bool off = getenv("SRX_NO_BN_BWD_FUSE") != nullptr;  // developer switch (A/B runs)
-  return (!off && srx_conv2d_bwd_data_bn_rows(d) != 0) ? 1 : 0;
+  return (!srx_dev().no_bn_bwd_fuse && srx_conv2d_bwd_data_bn_rows(d) != 0) ? 1 : 0;
 }
 
 extern "C" int srx_conv2d_bwd_data_bn_in(const srx_conv2d_t* d, const float* dout, const float* in_y, const float* in_mean,
@@ -2151,8 +2144,7 @@ extern "C" int srx_conv2d_bwd_data_bn_in(const srx_conv2d_t* d, const float* dou
 // normalise + activate pass runs while the input patch is staged, and act_out receives the tensor that pass would have
 // written.  1: this layer can (the 36-pixel row tile: 3x3, 64 -> 64, stride 1, few pixels); 0: keep srx_bn_act_fwd + srx_conv2d_fwd.
 extern "C" int srx_conv2d_fwd_bn_in_ok(const srx_conv2d_t* d) {
-  static const bool off = getenv("SRX_NO_BN_FWD_FUSE") != nullptr;  // developer switch (A/B runs)
-  return (!off && check_desc(d) == SRX_OK && srx_rt36_applicable(d)) ? 1 : 0;
+  return (!srx_dev().no_bn_fwd_fuse && check_desc(d) == SRX_OK && srx_rt36_applicable(d)) ? 1 : 0;
 }
 
 extern "C" int srx_conv2d_fwd_bn_in(const srx_conv2d_t* d, const float* y_in, const float* bn_mean, const float* bn_invstd,

@@ -493,6 +493,9 @@ extern "C" int srx_rdb_fwd(int N, int H, int W, float* buf, int ld, const void* 
                            float slope, float post_scale, const float* extra, int extra_ld, float* out, int out_ld,
                            void* stream) {
   SRX_REQUIRE(buf && wpk && bias5 && out, "rdb_fwd: null pointer");
+  // other workgroups read the x channels of `buf` (with their halo) while this one writes `out`: `out` is never the block
+  // buffer itself; `extra` may be an OLDER block's buffer but never `out`
+  SRX_REQUIRE(out != buf, "rdb_fwd: out must not alias the block buffer (neighbouring tiles read their halo from it)");
   SRX_REQUIRE(N > 0 && H > 0 && W > 0 && ld >= 192 && ld % 4 == 0 && out_ld >= 64 && out_ld % 4 == 0,
               "rdb_fwd: the block buffer needs >= 192 channels per pixel (x, c1..c4), the output >= 64, in whole quads");
   SRX_REQUIRE((int64_t)N * H * W < (1 << 24) && (int64_t)N * H * W * ld < (1LL << 40), "rdb_fwd: more than 2^24 pixels; tile the image");

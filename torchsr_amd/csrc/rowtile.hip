@@ -25,7 +25,8 @@
 
 namespace {
 
-constexpr int RT = 36;     // pixels per workgroup
+constexpr int RT36 = 36;   // pixels per workgroup: 32 + 4 (9216 pixels = 256 workgroups), or
+constexpr int RT48 = 48;   // 32 + 4 x 4 (192 workgroups) when fewer than 256 CUs are free (srx_plan_cus: RCCL holds some)
 constexpr int PSTR = 68;   // floats per patch pixel (64 channels + 4 pad)
 constexpr int KTOT = 576;  // 9 taps x 64 channels
 constexpr int PF = 8;      // weight fragments in flight per wave
@@ -57,8 +58,10 @@ struct RtArgs {
 // NB = batches of PB patch loads per thread (1 up to 2048 b128 slots, 2 up to the 64 KB LDS limit): a
 // compile-time count, so that ALL input loads and the first weight fragments are in flight together
 // and the compiler can wait on them with exact vmcnt values (a runtime loop drains the queue per trip).
-template <int NB, bool BNR = false, bool BNL = false, bool BNB = false>
+template <int NB, bool BNR = false, bool BNL = false, bool BNB = false, int RT = RT36>
 __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
+  constexpr int XB = (RT - 32) / 4;  // 4-pixel blocks behind the 32-pixel block
+  constexpr int FR = 16 + 4 * XB;    // accumulator rows a lane holds / folds
   extern __shared__ __attribute__((aligned(16))) float patch[];
   const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
   const int j = wave & 1, hk = wave >> 1;
@@ -177,21 +180,26 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   };
   const int choff = 32 * hk + 4 * h2;
   const float* a32 = patch + slot(p0 + i31) + choff;
-  const float* a4 = patch + slot(p0 + 32 + (lane & 3)) + choff;
+  const float* a4[XB];
+#pragma unroll
+  for (int b = 0; b < XB; ++b) a4[b] = patch + slot(p0 + 32 + 4 * b + (lane & 3)) + choff;
   const int rowoff = W2 * PSTR;
 
   // two accumulator chains: with one wave per SIMD a single dependent MFMA chain leaves issue gaps
   f32x16 acc, accb;
-  f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc4[XB];
+#pragma unroll
+  for (int b = 0; b < XB; ++b) acc4[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
 
-  f32x4 fa[2], fb[2];  // A fragments of step it+1 are read while the MFMAs of step it run
+  f32x4 fa[2], fb[2][XB];  // A fragments of step it+1 are read while the MFMAs of step it run
   auto frag = [&](int it, int set) {
     const int tap = it >> 2, th = tap / 3, tw = tap - 3 * th;
     const int off = th * rowoff + tw * PSTR + 8 * (it & 3);
     fa[set] = *reinterpret_cast<const f32x4*>(a32 + off);
-    fb[set] = *reinterpret_cast<const f32x4*>(a4 + off);
+#pragma unroll
+    for (int b = 0; b < XB; ++b) fb[set][b] = *reinterpret_cast<const f32x4*>(a4[b] + off);
   };
   frag(0, 0);
 #pragma unroll
@@ -207,7 +215,8 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     for (int e = 0; e < 4; ++e) {
       if (e & 1) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[it & 1][e], b[e], accb, 0, 0, 0);
       else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[it & 1][e], b[e], acc, 0, 0, 0);
-      acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(fb[it & 1][e], b[e], acc4, 0, 0, 0);
+#pragma unroll
+      for (int xb = 0; xb < XB; ++xb) acc4[xb] = __builtin_amdgcn_mfma_f32_4x4x1f32(fb[it & 1][xb][e], b[e], acc4[xb], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
   }
@@ -215,23 +224,25 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   for (int r = 0; r < 16; ++r) acc[r] += accb[r];
   // even / odd channel halves of the 4-pixel block live in lanes l and l+32
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc4[i] += __shfl_xor(acc4[i], 32, 64);
+  for (int b = 0; b < XB; ++b)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc4[b][i] += __shfl_xor(acc4[b][i], 32, 64);
 
   // ---- fold the two input-channel halves (the patch is dead now)
   __syncthreads();
-  float* fold = patch;  // [j][20][64]
+  float* fold = patch;  // [j][FR][64]
   if (hk == 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) fold[(j * 20 + r) * 64 + lane] = acc[r];
+    for (int r = 0; r < 16; ++r) fold[(j * FR + r) * 64 + lane] = acc[r];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fold[(j * 20 + 16 + i) * 64 + lane] = acc4[i];
+    for (int i = 0; i < 4 * XB; ++i) fold[(j * FR + 16 + i) * 64 + lane] = acc4[i >> 2][i & 3];
   }
   __syncthreads();
   if (hk == 1) return;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] += fold[(j * 20 + r) * 64 + lane];
+  for (int r = 0; r < 16; ++r) acc[r] += fold[(j * FR + r) * 64 + lane];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc4[i] += fold[(j * 20 + 16 + i) * 64 + lane];
+  for (int i = 0; i < 4 * XB; ++i) acc4[i >> 2][i & 3] += fold[(j * FR + 16 + i) * 64 + lane];
 
   // ---- epilogue.  32x32 accumulator: col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5);
   //      4x4 accumulator: row 32+i, col = lane&31 (both lane halves hold the folded sum; half 0 stores)
@@ -246,15 +257,15 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   const unsigned obase4 = h2 == 0 ? ((unsigned)m0 * 64u + (unsigned)col) * 4u : 0xffffffffu;  // half 0 stores
   // the addend (eval-mode skip input, or the skip connection's gradient when this is a data gradient) is requested for
   // all 20 rows before the first store: a load issued behind a store cannot be consumed until that store has landed
-  float rv[16], rv4[4];
+  float rv[16], rv4[4 * XB];
 #pragma unroll
   for (int r = 0; r < 16; ++r)
     rv[r] = a.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)obase, ((r & 3) + 8 * (r >> 2)) * 256, 0)) : 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4 * XB; ++i)
     rv4[i] = a.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)obase4, (32 + i) * 256, 0)) : 0.f;
   // BNR: the BatchNorm input at this lane's 20 (row, column) positions, and the layer's per-channel constants
-  float yv[16], yv4[4];
+  float yv[16], yv4[4 * XB];
   float bmu = 0.f, bis = 0.f, bgm = 0.f, bbt = 0.f, bsl = 1.f, t1 = 0.f, t2 = 0.f, tp = 0.f;
   if constexpr (BNR) {
     const __amdgpu_buffer_rsrc_t rbn = srx_rsrc(a.bn.y, a.out_bytes);
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     for (int r = 0; r < 16; ++r)
       yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbn, (int)obase, ((r & 3) + 8 * (r >> 2)) * 256, 0));
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4 * XB; ++i)
       yv4[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbn, (int)obase4, (32 + i) * 256, 0));
     bmu = a.bn.mean[col]; bis = a.bn.invstd[col]; bgm = a.bn.gamma[col]; bbt = a.bn.beta[col];
     if (a.bn.prelu) bsl = a.bn.prelu[0];
@@ -286,8 +297,8 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rout, obase, ((r & 3) + 8 * (r >> 2)) * 256, 0);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float v = acc4[i] + bv;
+  for (int i = 0; i < 4 * XB; ++i) {
+    const float v = acc4[i >> 2][i & 3] + bv;
     if (h2 == 0) { s1 += v; s2 += v * v; }
     const float o = (v > 0.f ? v : v * a.slope) + rv4[i];
     if constexpr (BNR) { if (h2 == 0) bn_acc(o, yv4[i]); }
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   }
 }
 
-int patch_rows_max(int W) {  // tiles start at columns (36 t) mod W only
+int patch_rows_max(int W, int RT) {  // tiles start at columns (RT t) mod W only
   int rows = 0;
   for (int t = 0; t < W; ++t) {
     const int r = ((RT * t) % W + RT - 1) / W + 3;
@@ -320,32 +331,40 @@ int patch_rows_max(int W) {  // tiles start at columns (36 t) mod W only
   return rows;
 }
 
-int patch_batches(int W) { return (int)srx_cdiv((int64_t)patch_rows_max(W) * (W + 2) * 16, 256 * PB); }
+int patch_batches(int W, int RT) { return (int)srx_cdiv((int64_t)patch_rows_max(W, RT) * (W + 2) * 16, 256 * PB); }
 
-size_t lds_bytes(int W) {  // every thread stores all its NB * PB slots: size for the rounded-up slot count
-  const size_t patch = (size_t)patch_batches(W) * (256 * PB / 16) * PSTR * sizeof(float);
-  const size_t fold = 2 * 20 * 64 * sizeof(float);
+size_t lds_bytes(int W, int RT) {  // every thread stores all its NB * PB slots: size for the rounded-up slot count
+  const size_t patch = (size_t)patch_batches(W, RT) * (256 * PB / 16) * PSTR * sizeof(float);
+  const size_t fold = 2 * (RT - 16) * 64 * sizeof(float);
   return patch > fold ? patch : fold;
+}
+
+bool tile_fits(const srx_conv2d_t* d, int RT) {
+  const int64_t hw = (int64_t)d->H * d->W;
+  return hw % RT == 0 && d->W >= 3 && patch_batches(d->W, RT) <= 2 && lds_bytes(d->W, RT) <= 80 * 1024;
+}
+
+// Pixels per workgroup.  36 cuts the reference batch (16 x 24 x 24) into exactly 256 workgroups, one per CU; when the plan may
+// not count on every CU (srx_plan_cus() < workgroups: a gradient all-reduce's channel kernels hold some) a second round of
+// 36-pixel tiles on a few CUs would double the launch, and 48-pixel tiles (192 workgroups, 4/3 of the work each) are the
+// better cut.  0: the layer does not run on this kernel.
+int tile_pixels(const srx_conv2d_t* d) {
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->shuffle || d->up || d->precision) return 0;
+  if (d->Cin != 64 || d->Cout != 64 || d->Cin_s != 64 || d->Cout_s != 64) return 0;
+  if (srx_dev().no_rt36) return 0;  // developer switch (read at load time): force the generic kernel
+  const int64_t m = (int64_t)d->N * d->H * d->W;
+  const int cus = srx_plan_cus();
+  // small problems only: above ~2 rounds of the chip the generic 128-row tiles re-read far less input
+  if (!tile_fits(d, RT36) || m / RT36 > 2 * cus) return 0;
+  if (m / RT36 > cus && tile_fits(d, RT48) && m / RT48 <= cus) return RT48;
+  return RT36;
 }
 
 }  // namespace
 
-extern "C" int srx_device_cus(void);
+bool srx_rt36_applicable(const srx_conv2d_t* d) { return tile_pixels(d) != 0; }
 
-bool srx_rt36_applicable(const srx_conv2d_t* d) {
-  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->shuffle || d->up || d->precision) return false;
-  if (d->Cin != 64 || d->Cout != 64 || d->Cin_s != 64 || d->Cout_s != 64) return false;
-  const int64_t hw = (int64_t)d->H * d->W, m = hw * d->N;
-  if (hw % RT != 0 || d->W < 3) return false;
-  if (patch_batches(d->W) > 2 || lds_bytes(d->W) > 80 * 1024) return false;
-  // small problems only: above ~2 rounds of the chip the generic 128-row tiles re-read far less input
-  static int cus = 0;
-  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
-  if (getenv("SRX_NO_RT36")) return false;  // developer switch: force the generic kernel
-  return m / RT <= 2 * cus;
-}
-
-int srx_rt36_rows(const srx_conv2d_t* d) { return (int)((int64_t)d->N * d->H * d->W / RT); }
+int srx_rt36_rows(const srx_conv2d_t* d) { const int rt = tile_pixels(d); return rt ? (int)((int64_t)d->N * d->H * d->W / rt) : 0; }
 
 int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, const float* residual,
                  float* out, float* part, int act, float slope, hipStream_t st, const srx_rt36_bn_t* bn,
@@ -360,49 +379,36 @@ int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const
   a.in_bytes = (unsigned)((size_t)a.M * 64 * sizeof(float));
   a.out_bytes = a.in_bytes;
   a.step_r = 16 / (d->W + 2); a.step_c = 16 % (d->W + 2);
-  const size_t lds = lds_bytes(d->W);
-  static std::once_flag once;
-  std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<1, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<1, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<1, true, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2, true, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<1, false, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<2, false, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-  });
-  const int nb = patch_batches(d->W);
+  const int RT = tile_pixels(d);
+  if (RT == 0) SRX_FAIL(SRX_E_UNSUPPORTED, "rt36: the layer does not run on the row-tile kernel");
+  const size_t lds = lds_bytes(d->W, RT);
+  const int nb = patch_batches(d->W, RT);
   const double fl = 2.0 * a.M * 64 * KTOT;
   const dim3 grid((unsigned)(a.M / RT));
   char nm[112];
   if (srx_prof_on()) snprintf(nm, sizeof(nm), "rt36_conv3x3_c64_kernel<%d> MxNxK=%dx64x%d", nb, a.M, KTOT);
-  if (bnb && bn) {
-    if (nb == 1) SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<1, true, false, true>), grid, dim3(256), lds, st, a);
-    else SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<2, true, false, true>), grid, dim3(256), lds, st, a);
-  } else if (bnb) {
-    if (nb == 1) SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<1, false, false, true>), grid, dim3(256), lds, st, a);
-    else SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<2, false, false, true>), grid, dim3(256), lds, st, a);
-  } else if (bnl) {
-    if (nb == 1) SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<1, false, true>), grid, dim3(256), lds, st, a);
-    else SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<2, false, true>), grid, dim3(256), lds, st, a);
-  } else if (bn) {
-    if (nb == 1) SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<1, true>), grid, dim3(256), lds, st, a);
-    else SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<2, true>), grid, dim3(256), lds, st, a);
-  } else if (nb == 1) SRX_LAUNCH_PROF(nm, fl, rt36_conv3x3_c64_kernel<1>, grid, dim3(256), lds, st, a);
-  else SRX_LAUNCH_PROF(nm, fl, rt36_conv3x3_c64_kernel<2>, grid, dim3(256), lds, st, a);
+  // one instance per (patch batches, BatchNorm modes, tile pixels); each raises its LDS limit once
+#define RT_LAUNCH(NB_, R_, L_, B_, T_)                                                                                    \
+  do {                                                                                                                    \
+    static std::once_flag once_;                                                                                          \
+    std::call_once(once_, [] {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<NB_, R_, L_, B_, T_>),             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                                   \
+    });                                                                                                                   \
+    SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<NB_, R_, L_, B_, T_>), grid, dim3(256), lds, st, a);                 \
+  } while (0)
+#define RT_MODES(NB_, T_)                                              \
+  do {                                                                 \
+    if (bnb && bn) RT_LAUNCH(NB_, true, false, true, T_);              \
+    else if (bnb) RT_LAUNCH(NB_, false, false, true, T_);              \
+    else if (bnl) RT_LAUNCH(NB_, false, true, false, T_);              \
+    else if (bn) RT_LAUNCH(NB_, true, false, false, T_);               \
+    else RT_LAUNCH(NB_, false, false, false, T_);                      \
+  } while (0)
+  if (RT == RT36) { if (nb == 1) RT_MODES(1, RT36); else RT_MODES(2, RT36); }
+  else { if (nb == 1) RT_MODES(1, RT48); else RT_MODES(2, RT48); }
+#undef RT_MODES
+#undef RT_LAUNCH
   SRX_CHECK_LAUNCH("rt36_conv3x3_c64_kernel");
   return SRX_OK;
 }

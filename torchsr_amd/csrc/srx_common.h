@@ -29,6 +29,16 @@ void srx_set_error(const char* fmt, ...);
     if (e__ != hipSuccess) SRX_FAIL(SRX_E_HIP, "%s: %s", name, hipGetErrorString(e__)); \
   } while (0)
 
+// api.cpp: developer switches, read from the environment once at load time (never on a launch path)
+struct SrxDevSwitches {
+  bool no_rt36, no_wgrad_rows, no_bn_bwd_fuse, no_bn_fwd_fuse, no_first3, no_c64, force_plan;
+  int wgrad_nsplit, wgrad_rows_nsplit, first3_wgs_per_cu, thin_fwd_rows, reserved_cus;
+  int plan[4];  // SRX_FORCE_PLAN = "BM,BN,split,ks"
+};
+const SrxDevSwitches& srx_dev();
+// compute units the launch plans size their grids for (device CUs less srx_set_reserved_cus)
+extern "C" int srx_plan_cus(void);
+
 // api.cpp: optional per-launch event timing (srx_prof_start / srx_prof_stop / srx_prof_get)
 bool srx_prof_on();
 bool srx_prof_take(const char* name, double flops, hipEvent_t* e0, hipEvent_t* e1);

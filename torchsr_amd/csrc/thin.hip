@@ -455,8 +455,7 @@ __global__ void thin_pack_kernel(const float* __restrict__ w, float* __restrict_
 }
 
 int thin_ranges(int nseg, int groups) {
-  int cus = srx_device_cus();
-  if (cus <= 0) cus = 256;
+  const int cus = srx_plan_cus();
   int ranges = (cus * 8) / groups;  // about two waves per SIMD: one's loads hide under the other's MFMAs
   if (ranges > nseg) ranges = nseg;
   if (ranges < 1) ranges = 1;
@@ -553,7 +552,7 @@ static int launch_thin_fwd2(const ThinF& a, hipStream_t st) {
 
 // in: [N][H][W][64], out: [N][H][W][4]; wpk from srx_thin_pack; n_out = real output channels
 bool srx_first3_fwd_applicable(const srx_conv2d_t* d) {
-  static const bool off = getenv("SRX_NO_FIRST3") != nullptr;  // developer switch (A/B runs)
+  const bool off = srx_dev().no_first3;  // developer switch (A/B runs), read at load time
   return !off && thin_geom_ok(d) && d->KH == 3 && d->Cin <= 4 && d->Cin_s == 4 && d->Cout == 64 && d->Cout_s == 64 &&
          (int64_t)d->N * d->H * d->W < (1 << 24);
 }
@@ -569,10 +568,8 @@ int srx_first3_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, int
   a.in_bytes = (unsigned)((size_t)a.M * 4 * sizeof(float));
   a.out_bytes = (unsigned)((size_t)a.M * 64 * sizeof(float));
   // three workgroups per CU, each wave walking its share of the tiles: the weight prologue is paid 768 times, not 2304
-  static int cus = 0;
-  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
-  static const char* gdev = getenv("SRX_FIRST3_WGS_PER_CU");
-  const unsigned grid = (unsigned)std::min<int64_t>(srx_cdiv(a.ntiles, 4), (int64_t)cus * (gdev ? atoi(gdev) : 3));
+  const int cus = srx_plan_cus(), gdev = srx_dev().first3_wgs_per_cu;
+  const unsigned grid = (unsigned)std::min<int64_t>(srx_cdiv(a.ntiles, 4), (int64_t)cus * (gdev > 0 ? gdev : 3));
   char nm[64];
   if (srx_prof_on()) snprintf(nm, sizeof(nm), "first3x3_fwd_kernel<%d> MxNxK=%dx64x36", d->precision ? 1 : 0, a.M);
   if (d->precision) SRX_LAUNCH_PROF(nm, 2.0 * a.M * 64 * 27, first3x3_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
@@ -607,11 +604,9 @@ int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const
   a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * 64 * sizeof(float));
   // rows per lane: 6 reads LDS least (23 b128 per 216 MFMAs) and wins whenever there are plenty of tiles; small
   // images balance better over the CUs with 12-row tiles (R = 3).  SRX_THIN_FWD_ROWS overrides (3, 4, 6).
-  static const char* dev = getenv("SRX_THIN_FWD_ROWS");
-  static int cus = 0;
-  if (cus <= 0) { cus = srx_device_cus(); if (cus <= 0) cus = 256; }
+  const int dev = srx_dev().thin_fwd_rows, cus = srx_plan_cus();
   const int64_t big_tiles = (int64_t)d->N * srx_cdiv(d->H, 24) * a.tiles_w;
-  const int R = dev ? atoi(dev) : (big_tiles >= 4 * cus ? 6 : 3);
+  const int R = dev > 0 ? dev : (big_tiles >= 4 * cus ? 6 : 3);
   a.tiles_h = (int)srx_cdiv(d->H, 4 * R);
   if (d->precision == 2) {  // bf16 products in the 3-channel layer too (inference)
     if (d->KH == 9) return R == 3 ? launch_thin_fwd2_bf16<9, 3>(a, st) : launch_thin_fwd2_bf16<9, 6>(a, st);

@@ -1,9 +1,9 @@
 """ESRGAN generator (RRDBNet) -- interface of torchsr/esrgan/generator.py:32-81."""
-import os
 
 import torch
 from torch import nn, Tensor
 
+from .. import _dev
 from .. import functional as F
 from ..layers import ACT_LRELU, Conv2d, Marker
 from .residual import ResidualInResidualDenseBlock
@@ -44,9 +44,10 @@ class Generator(nn.Module):
         out = F.cut_point('g.tail', out)                            # data parallel: upsample* / conv3 / conv4 gradients go out first
         out = self.upsample1(out)                                   # :73-75 (nearest x2 in the conv's gather)
         # upsample2's LeakyReLU backward rides in conv3's data gradient (its output feeds conv3 and nothing else)
-        fold = torch.is_grad_enabled() and self.upsample2._st.act == ACT_LRELU and not os.environ.get('SRX_NO_ACT_FOLD')
-        out = self.upsample2(out, act_bwd_folded=fold)              # :76-78
-        return self.conv4(self.conv3[0](out, in_act=(ACT_LRELU, self.upsample2._st.slope) if fold else None))  # :79-80
+        fold = torch.is_grad_enabled() and self.upsample2._st.act == ACT_LRELU and not _dev.NO_ACT_FOLD
+        token = F.ActFold(ACT_LRELU, self.upsample2._st.slope) if fold else None  # producer skips, consumer masks
+        out = self.upsample2(out, act_bwd_folded=token)             # :76-78
+        return self.conv4(self.conv3[0](out, in_act=token))         # :79-80
 
     def forward(self, x: Tensor) -> Tensor:
         return F.to_nchw(self.forward_nhwc(F.to_nhwc(x, 4)), 3)

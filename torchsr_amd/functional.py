@@ -15,7 +15,7 @@ import torch
 from torch import Tensor
 from torch.autograd import Function
 
-from . import _lib
+from . import _dev, _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, Conv2dDesc, call
 
 import ctypes as C
@@ -307,6 +307,8 @@ class PackTable:
         self.convs = list(convs)
         self.table = None
         self.nrec, self.maxn = 0, 0
+        self.fused_sig = None
+        self.generation = 0  # bumped by every (re)build
 
     def _build(self) -> bool:
         # (convs whose packed fp32 copies nothing reads -- dense blocks running as fused bf16 launches, RDBPack -- are left out)
@@ -324,10 +326,22 @@ class PackTable:
         call('srx_pack_table_build', descs, n, w, f, b, host.data_ptr(), C.byref(nrec), C.byref(maxn))
         self.table = host.to(items[0][1].device)
         self.items, self.nrec, self.maxn = items, nrec.value, maxn.value
+        self.fused_sig = self._fused_signature()
+        self.generation += 1
         return True
+
+    def _fused_signature(self):
+        return tuple(bool(c._st.fused_only) for c in self.convs)
 
     def run(self) -> bool:
         """False (and nothing done) until every layer is ready: the lazy per-layer path still covers that."""
+        # ``fused_only`` is re-decided per forward (precision, developer switch): a table built while the dense blocks ran
+        # fused leaves their convs out, and would leave their fp32 packs stale after an optimiser step once they run unfused
+        if self.table is not None and self.fused_sig != self._fused_signature():
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('PackTable: the set of fused-only convs changed inside a hipGraph capture; run one eager step '
+                                   'after switching precision / SRX_NO_RDB_FUSED')
+            self.table = None  # rebuilt below; ``generation`` tells holders of captured graphs to drop them
         if self.table is None and (torch.cuda.is_current_stream_capturing() or not self._build()):
             return False
         call('srx_pack_table_run', self.table.data_ptr(), self.nrec, self.maxn, _stream())
@@ -345,15 +359,35 @@ def bump_pack_epoch() -> None:
     _pack_epoch[0] += 1
 
 
+class ActFold:
+    """Token that pairs a PRODUCER conv whose fused ReLU / LeakyReLU backward is skipped (``act_bwd_folded=token``) with the
+    ONE consumer conv whose data gradient applies it instead (``in_act=token``: ``srx_conv2d_bwd_data_act``, mask = the
+    consumer's input).  The consumer's backward marks the token; the producer's backward refuses to run with an unmarked
+    one -- a producer output that reached another consumer, a consumer without an input gradient, or a consumer on a kernel
+    without the masked epilogue would otherwise give silently wrong gradients."""
+    __slots__ = ('act', 'slope', 'masked', 'consumers')
+
+    def __init__(self, act: int, slope: float):
+        self.act, self.slope, self.masked, self.consumers = act, float(slope), False, 0
+
+
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], st: ConvState, want_stats: bool,
-                master: Tensor, in_act=None, act_bwd_folded: bool = False):
-        # in_act = (act, slope): x is the output of a fused ReLU / LeakyReLU whose backward this conv's data gradient
-        # applies in its epilogue (srx_conv2d_bwd_data_act, mask = x); the producer is then called with act_bwd_folded
+                master: Tensor, in_act: Optional[ActFold] = None, act_bwd_folded: Optional[ActFold] = None):
+        # in_act: x is the output of a fused ReLU / LeakyReLU whose backward this conv's data gradient applies in its
+        # epilogue (srx_conv2d_bwd_data_act, mask = x); the producer is called with the SAME token as act_bwd_folded
         # and skips the elementwise pass (a read of two tensors and a write of one, 226 MB for the discriminator's first
-        # layer at batch 32).  Only for a producer whose output feeds this conv and nothing else.
+        # layer at batch 32).  Only for a producer whose output feeds this conv and nothing else (see ActFold).
         ctx.set_materialize_grads(False)
+        if in_act is not None:
+            if not isinstance(in_act, ActFold):
+                raise TypeError('conv2d: in_act must be the ActFold token the producer was called with')
+            in_act.consumers += 1
+            if in_act.consumers > 1:
+                raise RuntimeError('conv2d: an ActFold token has one consumer; this producer output feeds a second conv')
+        if act_bwd_folded is not None and not isinstance(act_bwd_folded, ActFold):
+            raise TypeError('conv2d: act_bwd_folded must be an ActFold token shared with the consumer')
         ctx.in_act, ctx.act_bwd_folded = in_act, act_bwd_folded
         x = _chk(x, 'conv2d.input')
         n, h, w, cs = x.shape
@@ -390,7 +424,10 @@ class _Conv2d(Function):
         x, y = ctx.saved_tensors
         dy = _chk(dy, 'conv2d.grad')
         s = _stream()
-        if st.act != ACT_NONE and not ctx.act_bwd_folded:
+        if ctx.act_bwd_folded is not None and not ctx.act_bwd_folded.masked:
+            raise RuntimeError('conv2d: this layer\'s activation backward was handed to a consumer (ActFold) whose data '
+                               'gradient never ran with the mask: the gradients would be wrong')
+        if st.act != ACT_NONE and ctx.act_bwd_folded is None:
             g = torch.empty_like(dy)
             call('srx_act_bwd_from_out', _p(dy), _p(y), _p(g), dy.numel(), st.act, st.slope, s)
             dy = g
@@ -400,8 +437,9 @@ class _Conv2d(Function):
             nws = L.srx_conv2d_bwd_data_ws_floats(dref)
             ws = _ws(nws, x) if nws else None
             if ctx.in_act is not None:  # ... and the backward of the activation that produced x
-                slope = 0.0 if ctx.in_act[0] == ACT_RELU else float(ctx.in_act[1])
+                slope = 0.0 if ctx.in_act.act == ACT_RELU else ctx.in_act.slope
                 call('srx_conv2d_bwd_data_act', dref, _p(dy), _p(ctx.wpk_bwd), _p(x), slope, 0, st.cin_s, 0, _p(dx), _p(ws), nws, s)
+                ctx.in_act.masked = True
             else:
                 call('srx_conv2d_bwd_data', dref, _p(dy), _p(ctx.wpk_bwd), _p(dx), 0, _p(ws), nws, s)
         wparam, bparam = ctx.params
@@ -452,9 +490,10 @@ class _Conv2d(Function):
 
 
 def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], st: ConvState, want_stats: bool = False,
-           master: Optional[Tensor] = None, in_act=None, act_bwd_folded: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+           master: Optional[Tensor] = None, in_act: Optional[ActFold] = None,
+           act_bwd_folded: Optional[ActFold] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """NHWC conv.  Returns ``(y, bn_partials)``; ``bn_partials`` is ``None`` unless requested.  ``in_act`` /
-    ``act_bwd_folded``: see ``_Conv2d.forward`` (a pair of flags for a producer / consumer pair of convs)."""
+    ``act_bwd_folded``: ONE shared ``ActFold`` token for a producer / consumer pair of convs (see ``_Conv2d.forward``)."""
     return _Conv2d.apply(x, weight, bias, st, want_stats, weight if master is None else master, in_act, act_bwd_folded)
 
 
@@ -733,8 +772,7 @@ class _ResidualTower(Function):
         queue = wgrad_queue[0]
         dref = C.byref(d)
         rows = L.srx_conv2d_bwd_data_bn_rows(dref)  # 0: the layers do not run on the row-tile kernel at this size
-        import os
-        if os.environ.get('SRX_NO_BN_DGRAD_FUSE') == '1':  # developer switch (A/B runs): separate reduce launches
+        if _dev.NO_BN_DGRAD_FUSE:  # developer switch (A/B runs): separate reduce launches
             rows = 0
         W = 2 * c + 4
         nws_d = L.srx_conv2d_bwd_data_ws_floats(dref)
@@ -1583,8 +1621,7 @@ class RDBPack:
 def rdb_fused_ok(states, wb_row, c0: int) -> bool:
     """The one-launch dense block applies to the reference's geometry (64 + 4 x 32 channels, 3x3 / stride 1 / pad 1,
     LeakyReLU on conv1..4, biases) with bf16 products; ``SRX_NO_RDB_FUSED=1`` keeps the per-conv launches (A/B runs)."""
-    import os
-    if os.environ.get('SRX_NO_RDB_FUSED') == '1' or c0 != 64 or len(states) != 5:
+    if _dev.NO_RDB_FUSED or c0 != 64 or len(states) != 5:
         return False
     for k, st in enumerate(states):
         if (st.precision != 1 or st.k != 3 or st.stride != 1 or st.pad != 1 or st.shuffle or st.up or st.cin != 64 + 32 * k

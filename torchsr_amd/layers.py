@@ -54,7 +54,7 @@ class Conv2d(nn.Conv2d):
         self._st = F.ConvState(in_channels, out_channels, kernel_size, stride, padding, shuffle=shuffle, act=act,
                                slope=slope, up=up)
 
-    def forward(self, x: Tensor, want_stats: bool = False, in_act=None, act_bwd_folded: bool = False):
+    def forward(self, x: Tensor, want_stats: bool = False, in_act=None, act_bwd_folded=None):
         """``in_act`` / ``act_bwd_folded``: a consumer / producer pair of flags that moves the backward of the producer's
         fused activation into the consumer's data gradient (``functional._Conv2d.forward``)."""
         y, part = F.conv2d(x, _w(self.weight), _w(self.bias), self._st, want_stats, self.weight, in_act, act_bwd_folded)

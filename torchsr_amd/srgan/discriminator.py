@@ -1,9 +1,9 @@
 """SRGAN discriminator -- interface of torchsr/srgan/discriminator.py:26-88."""
-import os
 
 import torch
 from torch import nn, Tensor
 
+from .. import _dev
 from .. import functional as F
 from ..layers import ACT_LRELU, BatchNorm2d, Conv2d, Linear, Marker
 
@@ -33,9 +33,9 @@ class Discriminator(nn.Module):
         every BatchNorm then normalises each call's rows with their own statistics."""
         mods = list(self.features)
         # the first conv's LeakyReLU backward rides in the second conv's (strided) data gradient: its output feeds nothing else
-        fold = torch.is_grad_enabled() and mods[0]._st.act == ACT_LRELU and not os.environ.get('SRX_NO_ACT_FOLD')  # (developer switch)
-        out = mods[0](x4, act_bwd_folded=fold)
-        in_act = (ACT_LRELU, mods[0]._st.slope) if fold else None
+        fold = torch.is_grad_enabled() and mods[0]._st.act == ACT_LRELU and not _dev.NO_ACT_FOLD  # (developer switch)
+        in_act = F.ActFold(ACT_LRELU, mods[0]._st.slope) if fold else None  # one token: producer skips, consumer masks
+        out = mods[0](x4, act_bwd_folded=in_act)
         i = 2
         while i < len(mods):
             conv, bn = mods[i], mods[i + 1]

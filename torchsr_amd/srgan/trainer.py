@@ -66,10 +66,14 @@ class LossRing:
 
     def __init__(self, device, cap: int = 50):
         self.cap = cap
-        self.ring = torch.zeros(cap * 4, dtype=torch.float32, device=device)
-        self.counter = torch.zeros(1, dtype=torch.int32, device=device)
-        self.read = 0        # records already flushed
+        # ring and counter share ONE buffer so that a flush reads both in the same copy: the counter says which slots the
+        # device wrote last, whatever the host believes
+        self._buf = torch.zeros(cap * 4 + 4, dtype=torch.float32, device=device)
+        self.ring = self._buf[:cap * 4]
+        self.counter = self._buf[cap * 4:cap * 4 + 1].view(torch.int32)
+        self.read = 0        # device records accounted for (flushed or skipped)
         self.pending = []    # [(key, step, other contents)] in push order
+        self.unnoted = 0     # pushes that never got a note (direct step calls outside the training loops)
 
     def push(self, loss: Tensor) -> None:
         """Device side (captured into the step's hipGraph)."""
@@ -82,12 +86,25 @@ class LossRing:
         return len(self.pending) >= self.cap
 
     def flush(self, log) -> None:
-        if not self.pending:
-            return
-        values = self.ring.view(self.cap, 4)[:, 0].cpu()  # the one sync
+        """Deliver the pending samples.  The device counter (read in the same copy as the ring) is the truth about how many
+        records exist: a ``gan_step`` / ``pretrain_step`` called directly (bench, tests, user code) pushes without a note, and a
+        step that raises between its push and its note does too -- the pending notes are then the LAST ``len(pending)`` records
+        (the training loops note right after their push), never a slot counted from a host-side guess, and ``read`` is
+        resynchronised from the counter."""
+        host = self._buf.cpu()  # the one sync
+        count = int(host[self.cap * 4:self.cap * 4 + 1].view(torch.int32)[0])
+        n = len(self.pending)
+        extra = count - self.read - n
+        if extra < 0:
+            raise RuntimeError(f'LossRing: {n} samples noted but the device pushed only {count - self.read} records')
+        self.unnoted += extra
+        if n > self.cap:
+            raise RuntimeError(f'LossRing: {n} samples pending in a ring of {self.cap} slots (flush when note() says so)')
+        values = host[:self.cap * 4].view(self.cap, 4)[:, 0]
+        first = count - n
         for i, (key, step, contents) in enumerate(self.pending):
-            log({**contents, key: float(values[(self.read + i) % self.cap])}, step=step)
-        self.read += len(self.pending)
+            log({**contents, key: float(values[(first + i) % self.cap])}, step=step)
+        self.read = count
         self.pending = []
 
 
