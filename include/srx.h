@@ -150,6 +150,32 @@ int srx_pack_table_run(const void* dev_table, int n_records, long long max_elems
  * follows (srgan/residual.py:65,68; srgan/discriminator.py:36-60). */
 int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float* wpk_fwd, const float* bias,
                    float* y, float* bn_partials, float* ws, size_t ws_floats, void* stream);
+/* ---------------------------------------------------------------- bf16-native inference chain (round 4) */
+/* `torchsr test` (torchsr/test.py:57-62) with --precision bf16: from the first conv's output to the last conv's input the
+ * generator's activations are STORED as bf16 NHWC (128 bytes per 64-channel pixel).  Entry points take `void*` bf16 tensors.
+ *
+ * srx_conv3x3_c64_bf16_*: nn.Conv2d(64, Cout, 3, 1, 1) with Cout a multiple of 64 -- the residual blocks' convs with the
+ * eval-mode BatchNorm folded in (srgan/residual.py:64-68,86-91), the generator's conv2 (srgan/generator.py:48,76-78) and
+ * the sub-pixel layers (srgan/residual.py:27-29, Cout = 256 with PixelShuffle(2) in the store).
+ *   pack: w OIHW fp32 [Cout][64][3][3], bias [Cout] or NULL, out_scale [Cout] or NULL (multiplies the weights of each
+ *         output channel: the folded BatchNorm's gamma / sqrt(var + eps)); wpk: srx_conv3x3_c64_bf16_packed_bytes(Cout) bytes.
+ *   fwd:  y = act(conv(x) + bias) [+ residual], act(v) = v > 0 ? v : v * slope (none: slope = 1, PReLU: its parameter);
+ *         x: bf16 [N][H][W][64]; y: bf16 [N][H][W][y_cs] (shuffle = 2: [N][2H][2W][y_cs], channels 0..63), y_cs a multiple of
+ *         8; residual: bf16 laid out like y, a tensor of its own, not with shuffle.  Any H, W; tensors above 4 GiB are fine
+ *         (64-bit row bases). */
+size_t srx_conv3x3_c64_bf16_packed_bytes(int Cout);
+int srx_conv3x3_c64_bf16_pack(const float* w, const float* bias, const float* out_scale, int Cout, int shuffle, void* wpk,
+                              void* stream);
+int srx_conv3x3_c64_bf16_fwd(int N, int H, int W, int Cout, int shuffle, const void* x, const void* wpk, float slope,
+                             const void* residual, void* y, int y_cs, void* stream);
+/* fp32 <-> bf16 (round to nearest even), n elements, a multiple of 4: the two ends of the chain */
+int srx_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+int srx_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
+/* The generator's output conv (nn.Conv2d(64, 3, 9, 1, 4), srgan/generator.py:58,80) reading a bf16 input: d->precision
+ * must be 2 (bf16 products in the 64 -> 3 layer); y is fp32 [N][H][W][4]. */
+int srx_conv2d_fwd_bf16in(const srx_conv2d_t* d, const void* x_bf16, const float* wpk_fwd, const float* bias, float* y,
+                          void* stream);
+
 /* y = act(conv(x, W) + bias) * out_scale + residual, residual laid out like y (not for shuffle layers).
  * With the eval-mode BatchNorm folded into W and bias by the host this is a whole `x + BN(conv(.))` of the
  * residual block (srgan/residual.py:86-91, srgan/generator.py:77-78) in one kernel; with out_scale = 0.2 it

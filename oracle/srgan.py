@@ -31,20 +31,30 @@ State = Dict[str, Tensor]
 # the same recipe so that an autocast step can be pinned at ~1e-3 instead of "within bf16 rounding of the fp32 step".
 _BF16 = [False]
 _BF16_THIN_OUT = [False]  # inference (test.upscale(precision='bf16')): the 64 -> 3 output conv rounds its operands too
+# inference, round 4: between the generator's first and last conv the product STORES its 64-channel activations as bf16
+# (csrc/c64.hip).  For a conv's own operands that is the rounding it applied anyway; what changes is that the skip inputs
+# (`x + ...` of a residual block, `conv1 + conv2` of the generator) are rounded too.  ``storage=True`` rounds every such
+# tensor where the product writes it.
+_BF16_STORAGE = [False]
 
 
 @contextlib.contextmanager
-def bf16_products(thin_out: bool = False):
-    old = _BF16[0], _BF16_THIN_OUT[0]
-    _BF16[0], _BF16_THIN_OUT[0] = True, thin_out
+def bf16_products(thin_out: bool = False, storage: bool = False):
+    old = _BF16[0], _BF16_THIN_OUT[0], _BF16_STORAGE[0]
+    _BF16[0], _BF16_THIN_OUT[0], _BF16_STORAGE[0] = True, thin_out, storage
     try:
         yield
     finally:
-        _BF16[0], _BF16_THIN_OUT[0] = old
+        _BF16[0], _BF16_THIN_OUT[0], _BF16_STORAGE[0] = old
 
 
 def _r(t: Tensor) -> Tensor:
     return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _stored(t: Tensor) -> Tensor:
+    """An activation the bf16-native inference chain writes to HBM (identity outside ``bf16_products(storage=True)``)."""
+    return _r(t) if (_BF16[0] and _BF16_STORAGE[0]) else t
 
 
 class _ConvBF16(torch.autograd.Function):
@@ -97,29 +107,29 @@ def residual_block(sd: State, p: str, x: Tensor, training: bool) -> Tensor:
     """ResidualBlock.forward, torchsr/srgan/residual.py:70-92."""
     out = conv2d(x, sd[p + 'conv1.weight'], None, 1, 1)          # :86
     out = _bn(sd, p + 'bn1.', out, training)                       # :87
-    out = F.prelu(out, sd[p + 'prelu.weight'])                     # :88
+    out = _stored(F.prelu(out, sd[p + 'prelu.weight']))            # :88
     out = conv2d(out, sd[p + 'conv2.weight'], None, 1, 1)        # :89
     out = _bn(sd, p + 'bn2.', out, training)                       # :90
-    return out + x                                                 # :91
+    return _stored(out + x)                                        # :91
 
 
 def subpixel_layer(sd: State, p: str, x: Tensor) -> Tensor:
     """SubpixelConvolutionLayer.forward, torchsr/srgan/residual.py:31-48."""
     out = conv2d(x, sd[p + 'conv.weight'], sd[p + 'conv.bias'], 1, 1)  # :45
     out = F.pixel_shuffle(out, 2)                                        # :46
-    return F.prelu(out, sd[p + 'prelu.weight'])                          # :47
+    return _stored(F.prelu(out, sd[p + 'prelu.weight']))                 # :47
 
 
 def generator_forward(sd: State, x: Tensor, training: bool = True, prefix: str = '') -> Tensor:
     """Generator.forward, torchsr/srgan/generator.py:60-81."""
     p = prefix
-    conv1 = F.prelu(conv2d(x, sd[p + 'conv1.0.weight'], sd[p + 'conv1.0.bias'], 1, 4), sd[p + 'conv1.1.weight'])
+    conv1 = _stored(F.prelu(conv2d(x, sd[p + 'conv1.0.weight'], sd[p + 'conv1.0.bias'], 1, 4), sd[p + 'conv1.1.weight']))
     block = conv1
     for i in range(NUM_RESIDUAL):                                  # :76
         block = residual_block(sd, f'{p}blocks.{i}.', block, training)
     conv2 = conv2d(block, sd[p + 'conv2.0.weight'], None, 1, 1)  # :77
     conv2 = _bn(sd, p + 'conv2.1.', conv2, training)
-    out = torch.add(conv1, conv2)                                  # :78
+    out = _stored(torch.add(conv1, conv2))                         # :78
     n_up = len({k.split('.')[1] for k in sd if k.startswith(p + 'conv_layers.')})
     for u in range(n_up):                                          # :79
         out = subpixel_layer(sd, f'{p}conv_layers.{u}.', out)

@@ -157,7 +157,9 @@ def test_1080p_inference_bf16_products_vs_oracle(dev):
         with torch.no_grad():
             exact = crop(O.generator_forward(sd, cut, training=False))
             same = crop(O.generator_forward(folded, cut, training=False))
-            with O.bf16_products(thin_out=True):  # inference: the 64 -> 3 output conv rounds its operands too
+            # inference: the 64 -> 3 output conv rounds its operands too, and (round 4) the 64-channel activations between
+            # the first and the last conv are stored as bf16
+            with O.bf16_products(thin_out=True, storage=True):
                 ref = crop(O.generator_forward(folded, cut, training=False))
         assert (exact - same).abs().max().item() <= 2e-5 * exact.abs().max().item()  # the folding itself changes nothing
         got = out[:, :, 4 * y0:4 * (y0 + win), 4 * x0:4 * (x0 + win)].cpu()

@@ -1211,3 +1211,56 @@ def test_bf16_weight_gradient_on_image_rows(dev, n, h, w, cin):
         assert rel_err(gw[i].cpu(), want.float()) < 2e-5, (i, rel_err(gw[i].cpu(), want.float()))
         want_b = scales[i] * dys[i].double().sum((0, 2, 3)) - 1.0
         assert rel_err(gb[i].cpu(), want_b.float()) < 2e-5, i
+
+
+@pytest.mark.parametrize('n,h,w,cout,shuffle,res', [
+    (1, 40, 150, 64, 0, True),      # wide image, ragged last strip (150 = 128 + 22): four 32-pixel segments side by side
+    (2, 24, 24, 64, 0, True),       # narrow image: the waves take rows (W <= 32)
+    (1, 37, 64, 64, 0, False),      # 2 x 2 segments (W <= 64), odd row count
+    (3, 9, 33, 128, 0, False),      # two channel groups written into 128-channel pixels
+    (1, 20, 45, 256, 2, False),     # sub-pixel layer: 256 channels, PixelShuffle(2) in the store
+    (1, 300, 200, 64, 0, True),     # several row chunks per column strip (persistent workgroups walk more than one item)
+])
+def test_bf16_native_conv3x3_c64(dev, n, h, w, cout, shuffle, res):
+    """``srx_conv3x3_c64_bf16_fwd`` (bf16 tensors in HBM, weights resident in registers, a rolling window of image rows in
+    LDS) through the C ABI against fp64 of the same operands: y = bf16(act(conv(x, bf16(W)) + b) [+ skip]).  The kernel sums
+    in fp32 and rounds ONCE, so every output is within half a bf16 ulp (8 significant bits: at most 2^-8 relative) plus the
+    fp32 summation error of the fp64 value."""
+    from torchsr_amd import _lib
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(1000 * h + w + cout)
+    x = (torch.rand(n, 64, h, w, generator=g) - 0.5).bfloat16()
+    wt = torch.randn(cout, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    slope = 0.25
+    oh, ow, oc = (2 * h, 2 * w, 64) if shuffle else (h, w, cout)
+    skip = (torch.rand(n, oc, oh, ow, generator=g) - 0.5).bfloat16() if res else None
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd, bd = wt.to(dev), b.to(dev)
+    pk = torch.empty(L.srx_conv3x3_c64_bf16_packed_bytes(cout), dtype=torch.uint8, device=dev)
+    _lib.call('srx_conv3x3_c64_bf16_pack', wd.data_ptr(), bd.data_ptr(), None, cout, shuffle, pk.data_ptr(), s)
+    y = torch.full((n, oh, ow, oc), float('nan'), dtype=torch.bfloat16, device=dev)
+    sd = None if skip is None else skip.permute(0, 2, 3, 1).contiguous().to(dev)
+    _lib.call('srx_conv3x3_c64_bf16_fwd', n, h, w, cout, shuffle, xd.data_ptr(), pk.data_ptr(), slope,
+              None if sd is None else sd.data_ptr(), y.data_ptr(), oc, s)
+    torch.cuda.synchronize()
+    z = TF.conv2d(x.double(), wt.bfloat16().double(), b.double(), 1, 1)
+    if shuffle:
+        z = TF.pixel_shuffle(z, 2)
+    z = torch.where(z > 0, z, z * slope)
+    if skip is not None:
+        z = z + skip.double()
+    got = y.permute(0, 3, 1, 2).float().cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - z).abs()
+    bound = z.abs() * (2.0 ** -8 * 1.001) + 2e-6 * z.abs().max()
+    assert (err <= bound).all(), ((err - bound).max().item(), err.max().item())
+    # ... and it IS a rounding of the right value: re-rounding the fp64 result gives the same bf16 on nearly every element
+    same = (z.float().bfloat16().double() == got).double().mean().item()
+    assert same > 0.995, same
+    # refusals: in place, a shuffled layer with an addend, a channel stride that cannot hold the channels
+    with pytest.raises(RuntimeError, match='in place'):
+        _lib.call('srx_conv3x3_c64_bf16_fwd', n, h, w, cout, shuffle, xd.data_ptr(), pk.data_ptr(), slope, None, xd.data_ptr(), oc, s)
+    with pytest.raises(RuntimeError, match='channel stride'):
+        _lib.call('srx_conv3x3_c64_bf16_fwd', n, h, w, cout, shuffle, xd.data_ptr(), pk.data_ptr(), slope, None, y.data_ptr(), 60, s)

@@ -1,0 +1,443 @@
+// 3x3 / stride 1 / pad 1 convolution of a 64-channel bf16 NHWC tensor, bf16 out (round 4): the bf16-NATIVE path.
+//
+// gconv_kernel<.., PR = 1> multiplies bf16 but lives on fp32: it reads fp32 activations from HBM, rounds them in the VALU
+// on their way into LDS and re-reads both operands from LDS for every MFMA -- 264 TFLOP/s on the 64 -> 64 trunk convs of
+// the SRGAN generator at 1080p, three times their HBM floor.  Here activations are STORED as bf16
+// (128 bytes per pixel, half the HBM traffic), arrive in LDS without a conversion, and the weights never touch LDS:
+//
+//   * K = 9 taps x 64 channels = 36 MFMA k-steps of 16.  A wave keeps the weight matrix of 32 output channels in
+//     registers -- 36 k-steps x 4 VGPRs = 144 -- loaded once per workgroup and reused for every pixel the (persistent)
+//     workgroup ever computes.  (All 64 channels per wave, 288 registers, was the first form: past 256 the compiler parks
+//     the surplus in AGPRs and copies four back in front of every MFMA.)
+//   * The MFMA is v_mfma_f32_32x32x16_bf16 with the WEIGHTS as the A operand (rows = output channels) and 32 consecutive
+//     pixels of an image row as the B operand (columns = pixels): a tap is an address offset into a rolling window of
+//     image rows in LDS, a B fragment is ONE ds_read_b128 (8 channels of one pixel), and a wave multiplies its weights
+//     with TWO pixel segments per k-step: one LDS read per MFMA, half the LDS bandwidth, where the generic tile saturates
+//     it.  Waves 2p and 2p + 1 own the two channel halves of pixel group p (64 pixels).
+//   * The window: rows of (32 CW + 2) pixels x 128 bytes, 16-byte chunk c of pixel p stored at chunk c ^ ((p >> 1) & 7):
+//     16 consecutive pixels then sit on 16 different 4-bank groups whatever the tap shift (conflict-free b128 reads).
+//     A workgroup (4 waves = RW rows x CW column segments of 32 pixels) walks DOWN a column strip: per step it requests RW
+//     new rows by LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS with no register in between; the swizzle sits on the
+//     per-lane SOURCE address, the destination is lane-linear; out-of-image pixels fail the buffer descriptor's range check
+//     and land as zeros -- probed, tools/probe/lds_dma_oob.hip), one barrier, and computes 128 pixels x 64 channels: 72 MFMAs
+//     per wave and step.  The DMA is inline asm and waited for by a counted s_waitcnt that leaves the step's four output
+//     stores in flight: with compiler-tracked loads the waits at the loop head drained those stores every step
+//     (3.4 us per step where the MFMAs need 1.1).
+//   * Epilogue: the accumulator (channel-major per lane) is turned pixel-major through a wave-private LDS area, then
+//     bias, activation (v > 0 ? v : v * slope), an optional bf16 addend (the residual block's skip input), rounding to
+//     bf16 and ONE 16-byte store per lane and 8 channels: every store instruction writes whole 128-byte pixels.
+//     PixelShuffle(2) (srgan/residual.py:27-28) is an output address: the 256 output channels are packed as four groups
+//     of 64, group (i, j) = the channels that land on sub-pixel (i, j), each group a pass of its own (blockIdx.y).
+//   * Addressing is 64-bit per (image, row): tensors above 4 GiB / 2^24 pixels (the 8K feature map: 4.2 GB) need no tiling.
+//
+// Serves (eval mode, torchsr/test.py:57-62 -- the `torchsr test` path): the 32 + 1 trunk convs of the SRGAN generator
+// with BatchNorm folded into the weights (srgan/residual.py:86-91, srgan/generator.py:76-78) and both sub-pixel layers.
+#include "srx_common.h"
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KSTEPS = 36;       // 9 taps x 4 channel groups of 16
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory queue (s_waitcnt vmcnt(0)):
+// here that queue holds the epilogue's stores of the step before -- a full HBM write round trip exposed once per step, with
+// one wave per SIMD and nothing to switch to -- and the next rows' loads, which have a whole step to arrive and are waited
+// for where they are consumed.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// One LDS-DMA instruction: every active lane moves 16 bytes from buffer offset `voff` (out of range: zeros) to LDS byte
+// lds_base + 16 * lane.  M0 (the destination base) is written and restored inside the statement.
+__device__ __forceinline__ void dma16(const u32x4& rsrc, unsigned voff, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_base), "s"(rsrc) : "memory");
+}
+constexpr int EPI_PITCH = 144;   // bytes per pixel of the epilogue's fp32 transpose area (32 floats + 16 bytes)
+
+struct C64Args {
+  const unsigned char* x;    // bf16 NHWC [N][H][W][64]
+  const unsigned char* w;    // packed: [group][kstep 36][half 2][lane 64][8 bf16]
+  const float* bias;         // [groups * 64] in packed (group-major) order, or null
+  const unsigned char* res;  // bf16, laid out like out; null: none (never with shuffle)
+  unsigned char* out;        // bf16 [N][Ho][Wo][out_cs]
+  int N, H, W;
+  int shuffle;               // 0, or 2: group g writes sub-pixel (g >> 1, g & 1) of a [N][2H][2W][out_cs] tensor
+  int out_cs;                // channel stride of the output (and the addend) in bf16 elements, >= 64
+  float slope;               // v > 0 ? v : v * slope (none: 1, ReLU: 0)
+  int strips, chunks, rows_per_chunk, nwork;
+};
+
+// RW x CW = 4 waves: rows x 32-pixel column segments computed per step
+template <int RW, int CW>
+__global__ __launch_bounds__(256) void c64_bf16_kernel(const C64Args a) {
+  static_assert(RW * CW == 4, "four waves, one per SIMD");
+  constexpr int TW = 32 * CW;                    // tile columns
+  constexpr int PX = TW + 2;                     // window pixels per row (one halo pixel each side)
+  // Rows arrive in groups of RW.  A step reads group k and the first two rows of group k + 1 while group k + 2 is being
+  // written (RW = 1: reads groups k .. k + 2, writes k + 3): a ring of 3 RW (4) row slots.
+  constexpr int NR = RW == 1 ? 4 : 3 * RW;
+  constexpr int AHEAD = RW == 1 ? 3 : 2;         // the group written during step k is group k + AHEAD
+  constexpr int ROWB = PX * 128;                 // bytes per window row
+  constexpr int UNITS = RW * PX * 8;             // 16-byte units loaded per step
+  constexpr int NLD = (UNITS + 255) / 256;       // ... per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
+  const int nh = wave & 1, grp = wave >> 1;  // channel half, pixel group
+  // the wave's two 32-pixel segments: (row, column) offsets inside the step's RW x TW tile
+  const int seg_r0 = RW == 1 ? 0 : (RW == 2 ? grp : 2 * grp), seg_r1 = RW == 4 ? seg_r0 + 1 : seg_r0;
+  const int seg_c0 = RW == 1 ? 64 * grp : 0, seg_c1 = RW == 4 ? 0 : seg_c0 + 32;
+  const int l31 = lane & 31, h = lane >> 5;
+  unsigned char* win = smem;
+  unsigned char* epi = smem + NR * ROWB + wave * (64 * EPI_PITCH);
+  const int g = blockIdx.y;
+
+  // ---- the weights of this wave's 32 output channels: 36 fragments of 8 bf16 per lane, resident for the life of the workgroup
+  bf16x8 wf[KSTEPS];
+  {
+    const u32x4* wp = reinterpret_cast<const u32x4*>(a.w + (size_t)g * (KSTEPS * 2 * 1024)) + nh * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, wp[ks * 128]);
+  }
+  // epilogue: this lane finishes channels 32 nh + 8 (lane & 3) .. + 7 of pixels (lane >> 2) + 16 t of the wave's 64
+  const int ech = lane & 3, epx = lane >> 2;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = a.bias ? a.bias[g * 64 + 32 * nh + 8 * ech + e] : 0.f;
+
+  // ---- per-lane window offsets of the B fragments: segment column + l31 + tw, chunk (2 cs + h) ^ swizzle(pixel)
+  unsigned foff0[3][4], foff1[3][4];
+#pragma unroll
+  for (int tw = 0; tw < 3; ++tw) {
+    const int p0 = seg_c0 + l31 + tw, p1 = seg_c1 + l31 + tw;
+#pragma unroll
+    for (int cs = 0; cs < 4; ++cs) {
+      foff0[tw][cs] = (unsigned)(p0 * 128 + (((2 * cs + h) ^ ((p0 >> 1) & 7)) * 16));
+      foff1[tw][cs] = (unsigned)(p1 * 128 + (((2 * cs + h) ^ ((p1 >> 1) & 7)) * 16));
+    }
+  }
+  // ---- per-thread staging units.  Unit e = 256 u + tid of a group of RW rows is 16-byte position (e % 8) of window pixel
+  // (e / 8) % PX of row e / (8 PX): LDS byte 16 e of the group's slots (rows are contiguous), i.e. lane-linear per wave.
+  int srow[NLD], scol[NLD];
+  unsigned ssrc[NLD];
+  bool sok[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) {
+    const int e = u * 256 + tid;
+    const int rr = e / (PX * 8), rem = e - rr * (PX * 8);
+    const int px = rem >> 3, pos = rem & 7;
+    sok[u] = e < UNITS;
+    srow[u] = rr;
+    scol[u] = px - 1;                                           // column relative to the strip's first column
+    ssrc[u] = (unsigned)((pos ^ ((px >> 1) & 7)) * 16);         // source chunk (the swizzle is an involution on chunks)
+  }
+  const unsigned win_lds = (unsigned)(size_t)win;               // LDS byte address of the ring
+
+  const size_t in_row_bytes = (size_t)a.W * 128;
+  const int Ho = a.shuffle ? 2 * a.H : a.H, Wo = a.shuffle ? 2 * a.W : a.W;
+  const int sh = a.shuffle ? 2 : 1, si = a.shuffle ? (g >> 1) : 0, sj = a.shuffle ? (g & 1) : 0;
+  const int gcol = a.shuffle ? 0 : 64 * g;  // without PixelShuffle the groups are channel ranges of one pixel
+  const size_t out_px_bytes = (size_t)a.out_cs * 2;
+  const unsigned out_row_bytes = (unsigned)((size_t)Wo * out_px_bytes);
+
+  for (int wi = blockIdx.x; wi < a.nwork; wi += gridDim.x) {
+    int t = wi;
+    const int chunk = t % a.chunks; t /= a.chunks;
+    const int strip = t % a.strips;
+    const int n = t / a.strips;
+    const int c0 = strip * TW;
+    const int r_beg = chunk * a.rows_per_chunk, r_end = min(a.H, r_beg + a.rows_per_chunk);
+    // descriptor over the rows this chunk can touch: [r_beg - 1, r_end + 1) clipped to the image
+    const int rb = max(r_beg - 1, 0), re = min(r_end + 1, a.H);
+    u32x4 rx;
+    {
+      const unsigned long long xb = (unsigned long long)(a.x + ((size_t)n * a.H + rb) * in_row_bytes);
+      rx[0] = (unsigned)srx_uniform((int)(unsigned)xb);
+      rx[1] = (unsigned)srx_uniform((int)((unsigned)(xb >> 32) & 0xffffu));
+      rx[2] = (unsigned)srx_uniform((int)(unsigned)((size_t)(re - rb) * in_row_bytes));
+      rx[3] = 0x00020000u;
+    }
+    // request the group of RW image rows starting at `first` into ring slots slot0 .. (groups never wrap: NR is a multiple
+    // of RW); rows / columns outside the image are pointed out of range and arrive as zeros: the conv's padding
+    auto dma_group = [&](int first, int slot0) {
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const int row = first + srow[u], col = c0 + scol[u];
+        const bool ok = row >= rb && row < re && (unsigned)col < (unsigned)a.W;
+        const unsigned off = (unsigned)(row - rb) * (unsigned)in_row_bytes + (unsigned)col * 128u + ssrc[u];
+        const unsigned dst = (unsigned)srx_uniform((int)(win_lds + (unsigned)(slot0 * ROWB) + (unsigned)((u * 256 + wave * 64) * 16)));
+        if (sok[u]) dma16(rx, ok ? off : 0xffffffffu, dst);
+      }
+    };
+
+    // the wave's two segments of step R: 32 channels x (32 + 32) pixels.  Row R - 1 sits in ring slot s0.
+    auto tile = [&](int R, int s0) {
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      const int row0 = R + seg_r0, row1 = R + seg_r1;
+      // epilogue addressing of the lane's 4 tasks: pixel epx + 16 t of the 64 (segment t >> 1); the addend's 4 x 8 channels
+      // are requested before the matrix work
+      u32x4 rv[4];
+      unsigned ooff[4];
+      __amdgpu_buffer_rsrc_t rout[2];
+#pragma unroll
+      for (int sgi = 0; sgi < 2; ++sgi) {
+        const int row = sgi ? row1 : row0;
+        const size_t orow = ((size_t)n * Ho + (size_t)(sh * row + si)) * (size_t)Wo;
+        rout[sgi] = srx_rsrc(a.out + orow * out_px_bytes, row < r_end ? out_row_bytes : 0u);
+      }
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const int sgi = t4 >> 1;
+        const int row = sgi ? row1 : row0;
+        const int col = c0 + (sgi ? seg_c1 : seg_c0) + epx + 16 * (t4 & 1);
+        ooff[t4] = (col < a.W && row < r_end) ? (unsigned)((size_t)(sh * col + sj) * out_px_bytes) + (unsigned)(gcol * 2 + 64 * nh + 16 * ech)
+                                              : 0xffffffffu;
+        {  // (no addend: a zero-length descriptor, every lane reads 0 -- no branch around the load)
+          const size_t orow = ((size_t)n * Ho + (size_t)row) * (size_t)Wo;
+          const __amdgpu_buffer_rsrc_t rres = srx_rsrc((a.res ? a.res : a.out) + orow * out_px_bytes, (a.res && row < r_end) ? out_row_bytes : 0u);
+          rv[t4] = __builtin_bit_cast(u32x4, srx_bload(rres, ooff[t4], 0));
+        }
+      }
+      // ring slots of the three taps' rows for the two segments (wave-uniform)
+      unsigned sb0[3], sb1[3];
+#pragma unroll
+      for (int th = 0; th < 3; ++th) {
+        int x0 = s0 + seg_r0 + th, x1 = s0 + seg_r1 + th;
+        x0 = x0 >= NR ? x0 - NR : x0; x1 = x1 >= NR ? x1 - NR : x1;
+        sb0[th] = (unsigned)srx_uniform(x0 * ROWB); sb1[th] = (unsigned)srx_uniform(x1 * ROWB);
+      }
+      // B fragments run PD k-steps ahead of the MFMAs that consume them (a read issued right in front of its MFMA exposes
+      // the whole LDS latency every second instruction)
+      constexpr int PD = 4;
+      bf16x8 b0[PD], b1[PD];
+      auto fetch = [&](int ks, int slot) {
+        const int tap = ks >> 2, th = tap / 3, tw = tap - 3 * th, cs = ks & 3;
+        b0[slot] = *reinterpret_cast<const bf16x8*>(win + sb0[th] + foff0[tw][cs]);
+        b1[slot] = *reinterpret_cast<const bf16x8*>(win + sb1[th] + foff1[tw][cs]);
+      };
+#pragma unroll
+      for (int ks = 0; ks < PD; ++ks) fetch(ks, ks);
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const bf16x8 x0 = b0[ks % PD], x1 = b1[ks % PD];
+        if (ks + PD < KSTEPS) fetch(ks + PD, ks % PD);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], x0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], x1, acc1, 0, 0, 0);
+      }
+      // pin the issue order the loop above spells out: 2 PD reads up front, then per k-step the two reads of step ks + PD
+      // in front of the two MFMAs of step ks (left alone the scheduler sinks every read to just before its MFMA)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * PD, 0);
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        if (ks + PD < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+      // D[row = channel (r & 3) + 8 (r >> 2) + 4 h][col = pixel l31] -> pixel-major fp32 in the wave's own area
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<f32x4*>(epi + l31 * EPI_PITCH + (8 * q + 4 * h) * 4) = f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(epi + (32 + l31) * EPI_PITCH + (8 * q + 4 * h) * 4) = f32x4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
+      }
+      __builtin_amdgcn_wave_barrier();  // (the same wave reads it back: LDS operations of one wave complete in order)
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const unsigned char* src = epi + (epx + 16 * t4) * EPI_PITCH + ech * 32;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
+        const bf16x8 radd = __builtin_bit_cast(bf16x8, rv[t4]);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = (e < 4 ? lo[e] : hi[e - 4]) + bv[e];
+          x = x > 0.f ? x : x * a.slope;
+          v[e] = x + (float)radd[e];
+        }
+        const bf16x8 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3], (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), (t4 >> 1) ? rout[1] : rout[0], (int)ooff[t4], 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();  // the next tile's writes to the area come after these reads
+    };
+
+    // ---- prologue.  Image row r lives in ring slot (r - (r_beg - 1)) % NR; group j = rows r_beg - 1 + j RW .. + RW - 1.
+    lds_barrier();  // the previous work item's window is dead
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) dma_group(r_beg - 1 + j * RW, j * RW);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int next = r_beg - 1 + AHEAD * RW;  // first row of the group requested during the coming step
+    int s0 = 0;                          // ring slot of row R - 1
+    for (int R = r_beg; R < r_end; R += RW) {
+      lds_barrier();  // every wave's requests of the step before have landed (waited for below): the window of this step is
+                      // complete in LDS, and the slots of the group before it are free
+      int wslot = s0 + AHEAD * RW;
+      wslot = wslot >= NR ? wslot - NR : wslot;
+      dma_group(next, wslot);
+      next += RW;
+      if (R + seg_r0 < r_end) {
+        tile(R, s0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the requests above are done; the tile's four stores may still fly
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      s0 += RW;
+      s0 = s0 >= NR ? s0 - NR : s0;
+    }
+  }
+}
+
+// OIHW fp32 [Cout][64][3][3] -> [group][kstep][half][lane][8] bf16: lane l of fragment (ks, nh) holds output channel
+// 32 nh + (l & 31) of its group, input channels 16 (ks & 3) + 8 (l >> 5) .. + 7 of tap ks >> 2.  With PixelShuffle the group
+// g = 2 i + j collects the channels c * 4 + g (c = 0 .. 63), the ones PixelShuffle(2) moves to sub-pixel (i, j).
+__global__ void c64_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, unsigned short* __restrict__ dst,
+                                int Cout, int shuffle) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one 8-channel fragment lane
+  const int total = (Cout / 64) * KSTEPS * 2 * 64;
+  if (idx >= total) return;
+  const int lane = idx & 63, nh = (idx >> 6) & 1, ks = (idx >> 7) % KSTEPS, g = idx / (KSTEPS * 128);
+  const int row = 32 * nh + (lane & 31);
+  const int co = shuffle ? row * 4 + g : 64 * g + row;
+  const int tap = ks >> 2, ci0 = 16 * (ks & 3) + 8 * (lane >> 5);
+  const float s = scale ? scale[co] : 1.f;
+  for (int e = 0; e < 8; ++e) {
+    const float v = w[((size_t)co * 64 + ci0 + e) * 9 + tap] * s;
+    dst[(size_t)idx * 8 + e] = __builtin_bit_cast(unsigned short, (__bf16)v);
+  }
+}
+
+__global__ void c64_pack_bias_kernel(const float* __restrict__ b, float* __restrict__ dst, int Cout, int shuffle) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Cout) return;
+  const int g = idx >> 6, row = idx & 63;
+  dst[idx] = b[shuffle ? row * 4 + g : idx];
+}
+
+__global__ void f32_to_bf16_kernel(const f32x4* __restrict__ x, uint2* __restrict__ y, int64_t nquads) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = x[i];
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    y[i] = __builtin_bit_cast(uint2, o);
+  }
+}
+
+__global__ void bf16_to_f32_kernel(const uint2* __restrict__ x, f32x4* __restrict__ y, int64_t nquads) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * blockDim.x) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const bf16x4 v = __builtin_bit_cast(bf16x4, x[i]);
+    y[i] = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+}
+
+template <int RW, int CW>
+int launch_c64(C64Args& a, int groups, hipStream_t st) {
+  constexpr int TW = 32 * CW, NR = RW == 1 ? 4 : 3 * RW;
+  const size_t lds = (size_t)NR * (TW + 2) * 128 + 4 * 64 * EPI_PITCH;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c64_bf16_kernel<RW, CW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  // One workgroup per CU (a wave owns its SIMD's whole register file), persistent over work items = (image, column strip,
+  // row chunk).  The chunk height is chosen so that the busiest workgroup's rows -- its items x (chunk rows + the 2 halo rows
+  // a chunk loads without computing) -- are fewest.
+  const int cus = srx_plan_cus();
+  const int gx_max = std::max(1, cus / groups);
+  a.strips = (int)srx_cdiv(a.W, TW);
+  const int64_t cols = (int64_t)a.N * a.strips;
+  int best_rpc = (int)srx_roundup(a.H, RW);
+  int64_t best_span = INT64_MAX;
+  for (int k = 1; k <= 8; ++k) {
+    const int64_t want = std::max<int64_t>(1, (int64_t)gx_max * k / cols);  // chunks per column strip
+    const int rpc = (int)srx_roundup(srx_cdiv(a.H, want), RW);
+    const int64_t chunks = srx_cdiv(a.H, rpc);
+    // steps of the busiest workgroup: per item its rows plus the prologue (AHEAD groups loaded and written before the
+    // first MFMA, about three steps' worth) -- short chunks are allowed, they just pay that more often
+    const int64_t span = srx_cdiv(cols * chunks, gx_max) * (rpc / RW + 3);
+    if (span < best_span) { best_span = span; best_rpc = rpc; }
+  }
+  a.rows_per_chunk = best_rpc;
+  a.chunks = (int)srx_cdiv(a.H, best_rpc);
+  a.nwork = (int)(cols * a.chunks);
+  const int gx = std::min(a.nwork, gx_max);
+  char nm[112];
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "c64_bf16_kernel<%d, %d> MxNxK=%lldx%dx576", RW, CW, (long long)a.N * a.H * a.W, 64 * groups);
+  SRX_LAUNCH_PROF(nm, 2.0 * a.N * a.H * a.W * 64.0 * groups * 576.0, (c64_bf16_kernel<RW, CW>), dim3((unsigned)gx, (unsigned)groups),
+                  dim3(256), lds, st, a);
+  SRX_CHECK_LAUNCH("c64_bf16_kernel");
+  return SRX_OK;
+}
+
+}  // namespace
+
+extern "C" size_t srx_conv3x3_c64_bf16_packed_bytes(int Cout) {
+  return Cout > 0 && Cout % 64 == 0 ? (size_t)(Cout / 64) * KSTEPS * 2 * 1024 + (size_t)Cout * sizeof(float) : 0;
+}
+
+extern "C" int srx_conv3x3_c64_bf16_pack(const float* w, const float* bias, const float* out_scale, int Cout, int shuffle,
+                                         void* wpk, void* stream) {
+  SRX_REQUIRE(w && wpk && Cout > 0 && Cout % 64 == 0 && (shuffle == 0 || (shuffle == 2 && Cout == 256)),
+              "conv3x3_c64_bf16_pack: Cout must be a multiple of 64 (256 with PixelShuffle 2)");
+  hipStream_t st = srx_stream(stream);
+  const int total = (Cout / 64) * KSTEPS * 2 * 64;
+  hipLaunchKernelGGL(c64_pack_kernel, dim3((unsigned)srx_cdiv(total, 256)), dim3(256), 0, st, w, out_scale,
+                     static_cast<unsigned short*>(wpk), Cout, shuffle);
+  SRX_CHECK_LAUNCH("c64_pack_kernel");
+  float* bdst = reinterpret_cast<float*>(static_cast<unsigned char*>(wpk) + (size_t)(Cout / 64) * KSTEPS * 2 * 1024);
+  if (bias) {
+    hipLaunchKernelGGL(c64_pack_bias_kernel, dim3((unsigned)srx_cdiv(Cout, 256)), dim3(256), 0, st, bias, bdst, Cout, shuffle);
+    SRX_CHECK_LAUNCH("c64_pack_bias_kernel");
+  } else if (hipMemsetAsync(bdst, 0, (size_t)Cout * sizeof(float), st) != hipSuccess) {
+    SRX_FAIL(SRX_E_HIP, "conv3x3_c64_bf16_pack: memset failed");
+  }
+  return SRX_OK;
+}
+
+extern "C" int srx_conv3x3_c64_bf16_fwd(int N, int H, int W, int Cout, int shuffle, const void* x, const void* wpk, float slope,
+                                        const void* residual, void* y, int y_cs, void* stream) {
+  SRX_REQUIRE(x && wpk && y, "conv3x3_c64_bf16_fwd: null pointer");
+  SRX_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 64 == 0 && Cout <= 1024, "conv3x3_c64_bf16_fwd: bad size (Cout a multiple of 64)");
+  SRX_REQUIRE(shuffle == 0 || (shuffle == 2 && Cout == 256), "conv3x3_c64_bf16_fwd: PixelShuffle(2) needs Cout = 256");
+  SRX_REQUIRE(y_cs % 8 == 0 && y_cs >= (shuffle ? 64 : Cout), "conv3x3_c64_bf16_fwd: the output's channel stride must hold its channels in whole 16-byte chunks");
+  SRX_REQUIRE(!residual || (!shuffle && residual != y), "conv3x3_c64_bf16_fwd: the addend is a tensor of its own, without PixelShuffle");
+  SRX_REQUIRE(x != y, "conv3x3_c64_bf16_fwd: in place is not possible (neighbouring tiles read their halo)");
+  SRX_REQUIRE((int64_t)W * 128 * 130 < (1LL << 32) && (int64_t)(shuffle ? 2 : 1) * W * y_cs * 2 < (1LL << 32) && (int64_t)N * H * W < (1LL << 31),
+              "conv3x3_c64_bf16_fwd: image rows too long for 32-bit offsets inside a chunk");
+  C64Args a{};
+  a.x = static_cast<const unsigned char*>(x);
+  a.w = static_cast<const unsigned char*>(wpk);
+  a.bias = reinterpret_cast<const float*>(a.w + (size_t)(Cout / 64) * KSTEPS * 2 * 1024);
+  a.res = static_cast<const unsigned char*>(residual);
+  a.out = static_cast<unsigned char*>(y);
+  a.N = N; a.H = H; a.W = W; a.shuffle = shuffle; a.out_cs = y_cs; a.slope = slope;
+  hipStream_t st = srx_stream(stream);
+  const int groups = Cout / 64;
+  // narrow images: waves take rows instead of column segments
+  if (W <= 32) return launch_c64<4, 1>(a, groups, st);
+  if (W <= 64) return launch_c64<2, 2>(a, groups, st);
+  return launch_c64<1, 4>(a, groups, st);
+}
+
+extern "C" int srx_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+  SRX_REQUIRE(x && y && n > 0 && n % 4 == 0, "f32_to_bf16: a positive multiple of 4 elements");
+  const int64_t q = n / 4;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)std::min<int64_t>(srx_cdiv(q, 256), 8192)), dim3(256), 0, srx_stream(stream),
+                     reinterpret_cast<const f32x4*>(x), static_cast<uint2*>(y), q);
+  SRX_CHECK_LAUNCH("f32_to_bf16_kernel");
+  return SRX_OK;
+}
+
+extern "C" int srx_bf16_to_f32(const void* x, float* y, int64_t n, void* stream) {
+  SRX_REQUIRE(x && y && n > 0 && n % 4 == 0, "bf16_to_f32: a positive multiple of 4 elements");
+  const int64_t q = n / 4;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)std::min<int64_t>(srx_cdiv(q, 256), 8192)), dim3(256), 0, srx_stream(stream),
+                     static_cast<const uint2*>(x), reinterpret_cast<f32x4*>(y), q);
+  SRX_CHECK_LAUNCH("bf16_to_f32_kernel");
+  return SRX_OK;
+}

@@ -1966,6 +1966,18 @@ extern "C" int srx_conv2d_fwd(const srx_conv2d_t* d, const float* x, const float
   return conv_fwd_impl(d, x, wpk, bias, nullptr, 1.f, y, bn_partials, ws, ws_floats, stream);
 }
 
+// The forward of a 64 -> <= 4 channel layer (the generator's output conv, srgan/generator.py:58) whose INPUT is a bf16 NHWC
+// tensor -- the end of the bf16-native inference chain (c64.hip); precision must be 2 (bf16 products), y is fp32.
+extern "C" int srx_conv2d_fwd_bf16in(const srx_conv2d_t* d, const void* x_bf16, const float* wpk, const float* bias, float* y,
+                                     void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRX_REQUIRE(x_bf16 && wpk && y, "conv2d_fwd_bf16in: null pointer");
+  if (!srx_thin_fwd_applicable(d) || d->precision != 2 || d->up == 2)
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_fwd_bf16in: 64 -> <= 4 channel layers with precision = 2 only");
+  SRX_REQUIRE((int64_t)d->N * d->H * d->W * 128 < (1LL << 32), "conv2d_fwd_bf16in: input above 4 GiB; tile the image");
+  return srx_thin_fwd(d, static_cast<const float*>(x_bf16), wpk, bias, y, d->Cout, srx_stream(stream), 1);
+}
+
 extern "C" int srx_conv2d_fwd_residual(const srx_conv2d_t* d, const float* x, const float* wpk, const float* bias,
                                        const float* residual, float out_scale, float* y, float* ws, size_t ws_floats,
                                        void* stream) {

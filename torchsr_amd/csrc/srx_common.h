@@ -64,7 +64,7 @@ int srx_first3_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, int
 bool srx_thin_dgrad_applicable(const srx_conv2d_t* d);
 int srx_thin_pack(const srx_conv2d_t* d, const float* w, float* p, int mode, hipStream_t st);
 int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, float* out, int n_out,
-                 hipStream_t st);
+                 hipStream_t st, int in_bf16 = 0);  // in_bf16: `in` is a bf16 tensor (precision = 2 only)
 
 // rowtile.hip: 3x3 / 64 -> 64 convolutions with few pixels (the SRGAN residual tower), 36 pixels per CU
 bool srx_rt36_applicable(const srx_conv2d_t* d);

@@ -158,6 +158,7 @@ struct ThinF {
   int N, H, W, Cout;
   int tiles_w, tiles_h;
   unsigned in_bytes;
+  int in_bf16;  // thin_fwd2_bf16_kernel: `in` holds bf16 (128 bytes per pixel), the bf16-native inference chain (c64.hip)
 };
 
 // Forward kernel (also the data gradient of the 3-channel-input layers, with flipped taps).  A first
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void thin_fwd2_kernel(const ThinF a) {
 // tools/probe/mfma4x4_bf16.hip: D[reg i] on lane l += sum_k A(lane 4 (l / 4) + i)[k] B(lane l)[k]): a quarter of the MFMAs
 // and half the LDS reads of the fp32 kernel, which the 9x9 64 -> 3 output conv at 8K resolution (33 M pixels) was bound by.
 // Operands are rounded to bf16 (nearest even) as they are staged; accumulation is fp32.
-template <int K, int R>
+template <int K, int R, bool IN16 = false>
 __global__ __launch_bounds__(256) void thin_fwd2_bf16_kernel(const ThinF a) {
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void thin_fwd2_bf16_kernel(const ThinF a) {
     return bf16x8{(__bf16)u[0], (__bf16)u[1], (__bf16)u[2], (__bf16)u[3], (__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
   };
   for (int cc = 0; cc < 64; cc += CS) {
-    f32x4 vp[LP][2], vw[LW][2];
+    f32x4 vp[LP][IN16 ? 1 : 2], vw[LW][2];
 #pragma unroll
     for (int u = 0; u < LP; ++u) {
       const int i = u * 256 + tid;
@@ -303,9 +304,13 @@ __global__ __launch_bounds__(256) void thin_fwd2_bf16_kernel(const ThinF a) {
       const int pw = pix % PW, ph = pix / PW;
       const int ih = h0 - PAD + ph, iw = w0 - PAD + pw;
       const bool ok = i < NPX && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-      const unsigned off = ok ? 4u * (unsigned)(((n * a.H + ih) * a.W + iw) * 64 + cc + q * 8) : 0xffffffffu;
-      vp[u][0] = srx_bload(rin, off, 0);
-      vp[u][1] = srx_bload(rin, off, 16);
+      if constexpr (IN16) {  // the unit (pixel, 8-channel half) is 16 bytes of the bf16 tensor as it stands
+        vp[u][0] = srx_bload(rin, ok ? 2u * (unsigned)(((n * a.H + ih) * a.W + iw) * 64 + cc + q * 8) : 0xffffffffu, 0);
+      } else {
+        const unsigned off = ok ? 4u * (unsigned)(((n * a.H + ih) * a.W + iw) * 64 + cc + q * 8) : 0xffffffffu;
+        vp[u][0] = srx_bload(rin, off, 0);
+        vp[u][1] = srx_bload(rin, off, 16);
+      }
     }
 #pragma unroll
     for (int u = 0; u < LW; ++u) {
@@ -318,7 +323,8 @@ __global__ __launch_bounds__(256) void thin_fwd2_bf16_kernel(const ThinF a) {
 #pragma unroll
     for (int u = 0; u < LP; ++u) {
       const int i = u * 256 + tid;
-      if (i < NPX) *reinterpret_cast<bf16x8*>(sx + i * 16) = pack(vp[u][0], vp[u][1]);
+      if constexpr (IN16) { if (i < NPX) *reinterpret_cast<f32x4*>(sx + i * 16) = vp[u][0]; }
+      else if (i < NPX) *reinterpret_cast<bf16x8*>(sx + i * 16) = pack(vp[u][0], vp[u][IN16 ? 0 : 1]);
     }
 #pragma unroll
     for (int u = 0; u < LW; ++u) {
@@ -578,30 +584,32 @@ int srx_first3_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, int
   return SRX_OK;
 }
 
-template <int K, int R>
+template <int K, int R, bool IN16 = false>
 static int launch_thin_fwd2_bf16(const ThinF& a, hipStream_t st) {
   constexpr int PH = 4 * R + K - 1, PW = 32 + K - 1;
   const size_t lds = (size_t)(PH * PW * 16 + 4 * K * K * 16) * 2;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd2_bf16_kernel<K, R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd2_bf16_kernel<K, R, IN16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               96 * 1024);
   });
   char nm[64];
-  if (srx_prof_on()) snprintf(nm, sizeof(nm), "thin_fwd2_bf16_kernel<%d, %d>", K, R);
-  SRX_LAUNCH_PROF(nm, 2.0 * a.N * a.H * a.W * K * K * 64 * a.Cout, (thin_fwd2_bf16_kernel<K, R>),
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "thin_fwd2_bf16_kernel<%d, %d, %d>", K, R, (int)IN16);
+  SRX_LAUNCH_PROF(nm, 2.0 * a.N * a.H * a.W * K * K * 64 * a.Cout, (thin_fwd2_bf16_kernel<K, R, IN16>),
                   dim3((unsigned)(a.N * a.tiles_h * a.tiles_w)), dim3(256), lds, st, a);
   SRX_CHECK_LAUNCH("thin_fwd2_bf16_kernel");
   return SRX_OK;
 }
 
 int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, float* out, int n_out,
-                 hipStream_t st) {
+                 hipStream_t st, int in_bf16) {
   ThinF a;
   a.in = in; a.w = wpk; a.bias = bias; a.out = out;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cout = n_out;
   a.tiles_w = (int)srx_cdiv(d->W, 32);
-  a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * 64 * sizeof(float));
+  a.in_bf16 = in_bf16;
+  a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * 64 * (in_bf16 ? 2 : sizeof(float)));
+  if (in_bf16 && d->precision != 2) SRX_FAIL(SRX_E_UNSUPPORTED, "thin_fwd: a bf16 input needs precision = 2 (bf16 products)");
   // rows per lane: 6 reads LDS least (23 b128 per 216 MFMAs) and wins whenever there are plenty of tiles; small
   // images balance better over the CUs with 12-row tiles (R = 3).  SRX_THIN_FWD_ROWS overrides (3, 4, 6).
   const int dev = srx_dev().thin_fwd_rows, cus = srx_plan_cus();
@@ -609,6 +617,10 @@ int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const
   const int R = dev > 0 ? dev : (big_tiles >= 4 * cus ? 6 : 3);
   a.tiles_h = (int)srx_cdiv(d->H, 4 * R);
   if (d->precision == 2) {  // bf16 products in the 3-channel layer too (inference)
+    if (in_bf16) {
+      if (d->KH == 9) return R == 3 ? launch_thin_fwd2_bf16<9, 3, true>(a, st) : launch_thin_fwd2_bf16<9, 6, true>(a, st);
+      return R == 3 ? launch_thin_fwd2_bf16<3, 3, true>(a, st) : launch_thin_fwd2_bf16<3, 6, true>(a, st);
+    }
     if (d->KH == 9) return R == 3 ? launch_thin_fwd2_bf16<9, 3>(a, st) : launch_thin_fwd2_bf16<9, 6>(a, st);
     return R == 3 ? launch_thin_fwd2_bf16<3, 3>(a, st) : launch_thin_fwd2_bf16<3, 6>(a, st);
   }

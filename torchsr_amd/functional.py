@@ -161,6 +161,45 @@ def _chk(t: Tensor, what: str) -> Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _chk16(t: Tensor, what: str) -> Tensor:
+    """A bf16 NHWC activation of the bf16-native inference chain (csrc/c64.hip)."""
+    if t.device.type != 'cuda':
+        raise RuntimeError(f'{what}: the MI355X path needs a CUDA/HIP tensor, got {t.device} (no CPU fallback)')
+    if t.dtype != torch.bfloat16:
+        raise RuntimeError(f'{what}: expected a bfloat16 tensor, got {t.dtype}')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def to_bf16(x: Tensor) -> Tensor:
+    """fp32 -> bf16 (round to nearest even), same shape: the entry of the bf16-native inference chain."""
+    x = _chk(x, 'to_bf16.input')
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    call('srx_f32_to_bf16', _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def to_f32(x: Tensor) -> Tensor:
+    x = _chk16(x, 'to_f32.input')
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    call('srx_bf16_to_f32', _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def conv2d_bf16in(conv, x: Tensor) -> Tensor:
+    """The generator's 64 -> 3 output conv on a bf16 input (``srx_conv2d_fwd_bf16in``; inference, precision 2); fp32 out."""
+    st = conv._st
+    x = _chk16(x, 'conv2d_bf16in.input')
+    n, h, w, cs = x.shape
+    if st.precision != 2 or torch.is_grad_enabled():
+        return conv(to_f32(x))
+    d = st.desc(n, h, w)
+    st.pack(conv.weight, d)
+    y = torch.empty(st.out_shape(n, h, w), dtype=torch.float32, device=x.device)
+    b = None if conv.bias is None else _chk(conv.bias.detach(), 'conv2d.bias')
+    call('srx_conv2d_fwd_bf16in', C.byref(d), _p(x), _p(st.wpk_fwd), _p(b), _p(y), _stream())
+    return y
+
+
 def _ws(n: int, like: Tensor) -> Tensor:
     return torch.empty(max(int(n), 4), dtype=torch.float32, device=like.device)
 
@@ -1418,8 +1457,43 @@ class FoldedConv:
             self.st.precision = src.precision
         self._key = key
 
+    def bf16_native_ok(self) -> bool:
+        """3x3 / stride 1 / pad 1, 64 input channels, a multiple of 64 outputs: the layers ``srx_conv3x3_c64_bf16_fwd`` runs."""
+        st = self.conv._st
+        return (st.k == 3 and st.stride == 1 and st.pad == 1 and st.cin == 64 and st.cout % 64 == 0 and st.up == 0
+                and (st.shuffle == 0 or (st.shuffle == 2 and st.cout == 256)))
+
+    def _call_bf16(self, x: Tensor, residual: Optional[Tensor]) -> Tensor:
+        """bf16 in, bf16 out: the bf16-native chain (activations stored as bf16, weights resident in registers)."""
+        st = self.st
+        if not self.bf16_native_ok():
+            raise RuntimeError('folded_conv: a bf16 input needs a 3x3 / 64-input-channel layer')
+        x = _chk16(x, 'folded_conv.input')
+        n, h, w, cs = x.shape
+        if cs != 64:
+            raise RuntimeError(f'folded_conv: bf16 input has {cs} channels, the layer expects 64')
+        if self.__dict__.get('_key16') != self._key:
+            nbytes = _lib.lib().srx_conv3x3_c64_bf16_packed_bytes(st.cout)
+            wpk = self.__dict__.get('_wpk16')
+            if wpk is None or wpk.numel() != nbytes or wpk.device != x.device:
+                wpk = self._wpk16 = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            call('srx_conv3x3_c64_bf16_pack', _p(self.w), _p(self.b), None, st.cout, st.shuffle, _p(wpk), _stream())
+            self._key16 = self._key
+        y = torch.empty(st.out_shape(n, h, w), dtype=torch.bfloat16, device=x.device)
+        slope = 1.0 if st.act == ACT_NONE else (0.0 if st.act == ACT_RELU else st.slope)
+        r = None
+        if residual is not None:
+            r = _chk16(residual, 'folded_conv.residual')
+            if r.shape != y.shape:
+                raise RuntimeError('folded_conv: residual must have the output shape')
+        call('srx_conv3x3_c64_bf16_fwd', n, h, w, st.cout, st.shuffle, _p(x), _p(self._wpk16), float(slope), _p(r), _p(y),
+             y.shape[3], _stream())
+        return y
+
     def __call__(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         self._refresh()
+        if x.dtype == torch.bfloat16:
+            return self._call_bf16(x, residual)
         st = self.st
         x = _chk(x, 'folded_conv.input')
         n, h, w, cs = x.shape

@@ -1,8 +1,10 @@
 """SRGAN generator (SRResNet) -- interface of torchsr/srgan/generator.py:33-81."""
 import math
 
+import torch
 from torch import nn, Tensor
 
+from .. import _dev
 from .. import functional as F
 from ..layers import BatchNorm2d, Conv2d, PReLU
 from .residual import ResidualBlock, SubpixelConvolutionLayer
@@ -43,6 +45,8 @@ class Generator(nn.Module):
             f = self.__dict__.setdefault('_folded', (F.FoldedConv(self.conv1[0], None, self.conv1[1]),
                                                      F.FoldedConv(self.conv2[0], self.conv2[1], None)))
         conv1 = f[0](x4)
+        if self.bf16_native():  # from here to the output conv the activations are STORED as bf16 (csrc/c64.hip)
+            conv1 = F.to_bf16(conv1)
         out = f[1](self.blocks(conv1), residual=conv1)
         for layer in list(self.conv_layers)[:-1]:
             out = layer(out)
@@ -50,7 +54,15 @@ class Generator(nn.Module):
 
     def infer_head_nhwc(self, feat: Tensor) -> Tensor:
         """Inference, second stage: feature map (or a tile of it with ``head_halo`` pixels around) -> NHWC image."""
-        return self.conv3(self.conv_layers[-1](feat))
+        out = self.conv_layers[-1](feat)
+        if out.dtype == torch.bfloat16:
+            return F.conv2d_bf16in(self.conv3, out)
+        return self.conv3(out)
+
+    def bf16_native(self) -> bool:
+        """Inference with bf16 products (``test.upscale(precision='bf16')``): the 64-channel layers keep their activations
+        in bf16 between kernels (``srx_conv3x3_c64_bf16_fwd``) -- half the HBM traffic, no conversion on the way into LDS."""
+        return self.conv2[0]._st.precision == 1 and not _dev.NO_C64 and F.inference_mode(self)
 
     def forward_nhwc(self, x4: Tensor) -> Tensor:
         """NHWC ``[N,h,w,4]`` -> NHWC ``[N,s*h,s*w,4]`` (4th channel zero)."""
