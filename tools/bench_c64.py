@@ -41,6 +41,42 @@ def run(n, h, w, cout, shuffle, res, reps=20):
           f'{byt / us / 1e3:7.1f} GB/s algorithmic', flush=True)
 
 
+def stamps(n, h, w, cout, shuffle, res):
+    """In-kernel cycle stamps per phase (developer entry point, bound here only)."""
+    import ctypes as C
+    fn = L.srx_conv3x3_c64_bf16_fwd_dbg
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    x = (torch.rand(n, h, w, 64, device=dev) - 0.5).bfloat16()
+    wt = torch.randn(cout, 64, 3, 3, device=dev) * (2.0 / 576) ** 0.5
+    pk = torch.empty(L.srx_conv3x3_c64_bf16_packed_bytes(cout), dtype=torch.uint8, device=dev)
+    _lib.call('srx_conv3x3_c64_bf16_pack', wt.data_ptr(), None, None, cout, shuffle, pk.data_ptr(), s)
+    oh, ow, oc = (2 * h, 2 * w, 64) if shuffle else (h, w, cout)
+    y = torch.empty((n, oh, ow, oc), dtype=torch.bfloat16, device=dev)
+    r = (torch.rand(n, oh, ow, oc, device=dev) - 0.5).bfloat16() if res else None
+    dbg = torch.zeros(1024 * 8 * 8, dtype=torch.int32, device=dev)
+    for _ in range(5):
+        rc = fn(n, h, w, cout, shuffle, x.data_ptr(), pk.data_ptr(), 0.25, None if r is None else r.data_ptr(), y.data_ptr(), oc, s,
+                dbg.data_ptr())
+        assert rc == 0
+    torch.cuda.synchronize()
+    d = dbg.view(-1, 8, 8).cpu().numpy().astype('int64') & 0xffffffff
+    live = d[:, 0, 3] > 0
+    m, hlp = d[live][:, :4, :], d[live][:, 4:, :]
+    steps = m[:, :, 3].mean()
+    print(f'{int(live.sum())} workgroups, {steps:.1f} steps each (cycles per step, mean over waves)')
+    print('  matrix waves: barrier %.0f  mfma loop %.0f  dump %.0f  total %.0f' % tuple(m[:, :, i].mean() / steps for i in (0, 1, 2, 4)))
+    print('  helper waves: barrier %.0f  requests %.0f  addend wait %.0f  finishing %.0f  final wait %.0f  total %.0f'
+          % tuple(hlp[:, :, i].mean() / steps for i in (0, 1, 2, 3, 4, 5)))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'stamps':
+    stamps(1, 1080, 1920, 64, 0, False)
+    stamps(1, 1080, 1920, 64, 0, True)
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == 'trunk':  # one shape (profiler passes)
+    run(1, 1080, 1920, 64, 0, False, reps=10)
+    sys.exit(0)
 run(1, 1080, 1920, 64, 0, False)
 run(1, 1080, 1920, 64, 0, True)
 run(1, 1080, 1920, 256, 2, False)
