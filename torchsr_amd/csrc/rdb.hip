@@ -88,6 +88,7 @@ struct RdbArgs {
   float* out;            // [N][H][W][out_ld], channels 0..63
   int N, H, W, ld, bld, gld, skip_ld, extra_ld, out_ld, tiles_x, tiles_y;
   float scale, slope, skip_scale, post_scale;
+  int dma;
 };
 
 // Roles.  Waves 0..3 (one per SIMD) multiply: a wave owns up to two 32-pixel tiles of the current conv's region and reads
@@ -100,6 +101,7 @@ struct Wave {
   f32x16 acc[2];
   int lane, h, l31, wave;
   int n_img, ty0, tx0;
+  bool dma;  // weights by LDS-DMA (round 4); false: through registers (developer switch SRX_RDB_NO_DMA, A/B runs)
 };
 
 // Every loader thread issues the same number of loads per unit (the last round re-reads the unit's final chunk where
@@ -111,6 +113,34 @@ __device__ __forceinline__ void load_unit(const RdbArgs& a, int lt, f32x4 (&wr)[
 #pragma unroll
   for (int i = 0; i < rounds; ++i) wr[i] = src[min(i * NLOAD_THREADS + lt, chunks - 1)];
 }
+// Round 4: the same stream by LDS-DMA (buffer_load_dwordx4 ... lds).  The packed units are already the LDS image, so the
+// copy is lane-linear: one instruction moves 1 KiB, nothing passes through registers and no ds_write is issued -- the nine
+// 16-byte LDS stores per loader thread and unit competed with the compute waves' fragment reads for the LDS and with their
+// MFMAs for the SIMD's issue slots.  Lanes past the unit's end read 0 through the descriptor's range check and land in the
+// slack of the (36 KB) slot.
+typedef unsigned rdb_u32x4 __attribute__((ext_vector_type(4)));
+template <int U>
+__device__ __forceinline__ void dma_unit(const RdbArgs& a, unsigned lds_base, int lt) {
+  constexpr int chunks = unit_bytes(U) / 16, rounds = (chunks + NLOAD_THREADS - 1) / NLOAD_THREADS;
+  const unsigned long long p = (unsigned long long)(a.wpk + unit_off(U));
+  rdb_u32x4 rs;
+  rs[0] = (unsigned)srx_uniform((int)(unsigned)p);
+  rs[1] = (unsigned)srx_uniform((int)((unsigned)(p >> 32) & 0xffffu));
+  rs[2] = (unsigned)unit_bytes(U);
+  rs[3] = 0x00020000u;
+  const unsigned wave_l = (unsigned)srx_uniform(lt >> 6);
+#pragma unroll
+  for (int i = 0; i < rounds; ++i) {
+    const unsigned dst = (unsigned)srx_uniform((int)(lds_base + (unsigned)(OFF_W + (U & 1) * SLOT_BYTES) + (unsigned)(i * NLOAD_THREADS) * 16u + wave_l * 1024u));
+    const unsigned voff = (unsigned)(i * NLOAD_THREADS + lt) * 16u;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs) : "memory");
+  }
+}
+// workgroup barrier that orders LDS traffic only (see c64.hip): the compute waves' global stores of c1..c4 / g4..g1 fly on
+__device__ __forceinline__ void rdb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int U>
 __device__ __forceinline__ void store_unit(unsigned char* lds, int lt, const f32x4 (&wr)[MAX_ROUNDS]) {
   constexpr int chunks = unit_bytes(U) / 16, rounds = (chunks + NLOAD_THREADS - 1) / NLOAD_THREADS;
@@ -314,12 +344,18 @@ template <int U, bool BWD>
 __device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, Wave& w, int tid, f32x4 (&xs)[4],
                                           f32x4 (&ex)[4]) {
   constexpr int K = unit_conv(U), S = U - unit_first(K);
-  __syncthreads();  // unit U's weights (and, for S == 0, the previous conv's output image) are in LDS; slot (U+1)&1 is free
+  // unit U's weights (and, for S == 0, the previous conv's output image) are in LDS; slot (U+1)&1 is free
+  if (w.dma) rdb_lds_barrier(); else __syncthreads();
   if (w.wave >= NCOMPUTE) {
     if constexpr (U + 1 < NUNITS) {
-      f32x4 wr[MAX_ROUNDS];
-      load_unit<U + 1>(a, tid - NCOMPUTE * 64, wr);
-      store_unit<U + 1>(lds, tid - NCOMPUTE * 64, wr);
+      if (w.dma) {
+        dma_unit<U + 1>(a, (unsigned)(size_t)lds, tid - NCOMPUTE * 64);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // landed before the next barrier (this wave has nothing else to do)
+      } else {
+        f32x4 wr[MAX_ROUNDS];
+        load_unit<U + 1>(a, tid - NCOMPUTE * 64, wr);
+        store_unit<U + 1>(lds, tid - NCOMPUTE * 64, wr);
+      }
     }
   } else {
     if (S == 0) {
@@ -351,10 +387,16 @@ __global__ __launch_bounds__(NTHREADS) void rdb_kernel(const RdbArgs a) {
   const int ty = b % a.tiles_y;
   w.n_img = b / a.tiles_y; w.ty0 = ty * RT; w.tx0 = tx * RT;
 
+  w.dma = a.dma != 0;
   if (w.wave >= NCOMPUTE) {  // the first weight unit
-    f32x4 wr[MAX_ROUNDS];
-    load_unit<0>(a, tid - NCOMPUTE * 64, wr);
-    store_unit<0>(lds, tid - NCOMPUTE * 64, wr);
+    if (w.dma) {
+      dma_unit<0>(a, (unsigned)(size_t)lds, tid - NCOMPUTE * 64);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      f32x4 wr[MAX_ROUNDS];
+      load_unit<0>(a, tid - NCOMPUTE * 64, wr);
+      store_unit<0>(lds, tid - NCOMPUTE * 64, wr);
+    }
   }
   // the input patch, rounded to bf16 once: 324 pixels x 8 groups of 8 channels; every load is issued before the first
   // conversion (out-of-image pixels read a clamped address and are zeroed afterwards)
@@ -473,6 +515,7 @@ extern "C" int srx_rdb_pack_bwd(const float* const* w_table_dev, int nblk, void*
 template <bool BWD>
 static int rdb_launch(RdbArgs& a, const char* what, void* stream) {
   a.tiles_x = (int)srx_cdiv(a.W, RT); a.tiles_y = (int)srx_cdiv(a.H, RT);
+  a.dma = srx_dev().rdb_no_dma ? 0 : 1;
   const int64_t grid = (int64_t)a.N * a.tiles_x * a.tiles_y;
   SRX_REQUIRE(grid < (1LL << 31), "%s: grid too large", what);
   static std::once_flag once;
