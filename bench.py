@@ -244,8 +244,11 @@ def roofline_pass(trainer, lr, hr, reps=2):
              for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][0])}
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE: tools/pmc_run.sh) of
     # tools/pmc_workloads.py restricted to ONE layer shape; counters cannot be read from inside the process
-    tpath = os.path.join(ROOT, 'profiles', 'r03_traffic.json')
-    measured = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    measured = {}
+    for tname in ('r03_traffic.json', 'r04_traffic.json'):  # (later rounds add shapes / supersede entries)
+        tpath = os.path.join(ROOT, 'profiles', tname)
+        if os.path.exists(tpath):
+            measured.update(json.load(open(tpath)))
     shapes = []
     for full, v in sorted(pairs.items(), key=lambda kv: -kv[1][0]):
         if full.split(' MxNxK=')[0] != kname:
@@ -419,14 +422,15 @@ def _dp_child(extra_env, steps=40, timeout_s=240):
     return json.loads(line)['dp']
 
 
-def dp_rehearsal(contention=(8, 16, 32)):
+def dp_rehearsal(contention=(16,)):
     """The data-parallel form of the step on RCCL at world size 1, in a child process (a hang in there cannot take the
     headline with it): ``SRX_BENCH_FORCE_DIST=1 python bench.py``.  Returns the child's ``dp`` object -- backend, buckets,
     segmented vs fused ms per step on the same GPU -- plus ``cu_contention``: the segmented step while a side-stream kernel
     HOLDS k compute units (``srx_occupy_cus``: k workgroups that each claim a CU's whole LDS, so nothing else becomes
     resident there -- the worst case for RCCL's channel workgroups, which in fact co-reside and mostly wait), with plans cut
     for the whole chip and with plans told about the k CUs (``SRX_RESERVED_CUS``).  The one-GPU estimate of what the
-    all-reduce's channel kernels cost grids that are cut for exactly 256 CUs; N > 1 itself stays unmeasured."""
+    all-reduce's channel kernels cost grids that are cut for exactly 256 CUs; N > 1 itself stays unmeasured.  The default run
+    holds 16 CUs (two child processes); ``--dp-contention 8,16,32`` gives the table DESIGN.md section 6 quotes."""
     dp = _dp_child({})
     table = []
     for k in contention:
@@ -499,6 +503,7 @@ def main():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
     ap.add_argument('--no-dp-rehearsal', action='store_true')
+    ap.add_argument('--dp-contention', default='16', help='CUs held during the data-parallel rehearsal, comma separated (default 16)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -693,7 +698,7 @@ def main():
                 out['other_configs'] = other_configs(device)
             if not args.no_dp_rehearsal:
                 try:
-                    out['dp_rehearsal'] = dp_rehearsal()
+                    out['dp_rehearsal'] = dp_rehearsal(tuple(int(v) for v in args.dp_contention.split(',') if v))
                 except Exception as exc:  # noqa: BLE001
                     print(f'bench.py: dp rehearsal failed: {type(exc).__name__}: {exc}', file=sys.stderr)
                     out['dp_rehearsal'] = {'error': f'{type(exc).__name__}: {str(exc)[-300:]}'}

@@ -480,6 +480,10 @@ def test_row_tile_plan(dev):
     d2 = _lib.Conv2dDesc(16, 24, 26, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0)
     _lib.call('srx_conv2d_plan', C.byref(d2), 0, out)
     assert out[0] in (64, 128, 144)
+    # the reference's CPU batch size (BASELINE configs[0]): 12-pixel tiles, 96 workgroups instead of 32 of 36 pixels
+    d3 = _lib.Conv2dDesc(2, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0)
+    _lib.call('srx_conv2d_plan', C.byref(d3), 0, out)
+    assert list(out)[:4] == [12, 64, 1, 96] and _lib.lib().srx_conv2d_stat_rows(C.byref(d3)) == 96
 
 
 @pytest.mark.parametrize('cfg', [(2, 24, 24, 64, 'prelu', True), (2, 12, 12, 128, 'lrelu', False),
@@ -937,7 +941,9 @@ def test_data_gradient_with_bn_backward_reduce_epilogue(dev, prelu):
     m = n * h * w
     d = _lib.Conv2dDesc(n, h, w, c, c, c, c, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
     rows = L.srx_conv2d_bwd_data_bn_rows(C.byref(d))
-    assert rows == m // 36
+    plan = (C.c_int * 6)()
+    _lib.call('srx_conv2d_plan', C.byref(d), 1, plan)
+    assert plan[0] in (12, 36) and rows == m // plan[0]  # (576 pixels: the 12-pixel tiles of small batches)
     g = torch.Generator().manual_seed(31)
     rnd = lambda *shape: torch.randn(*shape, generator=g).to(dev)  # noqa: E731
     wt = rnd(c, c, 3, 3) * 0.05

@@ -27,6 +27,8 @@ namespace {
 
 constexpr int RT36 = 36;   // pixels per workgroup: 32 + 4 (9216 pixels = 256 workgroups), or
 constexpr int RT48 = 48;   // 32 + 4 x 4 (192 workgroups) when fewer than 256 CUs are free (srx_plan_cus: RCCL holds some)
+constexpr int RT12 = 12;   // 3 x 4, no 32-pixel block: small batches (2 x 24 x 24 = 96 workgroups instead of 32; a third of the
+                           // matrix time per workgroup -- the pre-training step at the reference's CPU batch size, BASELINE configs[0])
 constexpr int PSTR = 68;   // floats per patch pixel (64 channels + 4 pad)
 constexpr int KTOT = 576;  // 9 taps x 64 channels
 constexpr int PF = 8;      // weight fragments in flight per wave
@@ -60,8 +62,9 @@ struct RtArgs {
 // and the compiler can wait on them with exact vmcnt values (a runtime loop drains the queue per trip).
 template <int NB, bool BNR = false, bool BNL = false, bool BNB = false, int RT = RT36>
 __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
-  constexpr int XB = (RT - 32) / 4;  // 4-pixel blocks behind the 32-pixel block
-  constexpr int FR = 16 + 4 * XB;    // accumulator rows a lane holds / folds
+  constexpr int MAIN = RT >= 32 ? 1 : 0;        // a 32-pixel block on 32x32x2 MFMAs in front of the 4-pixel blocks
+  constexpr int XB = (RT - 32 * MAIN) / 4;      // 4-pixel blocks (4x4x1 MFMAs)
+  constexpr int FR = 16 * MAIN + 4 * XB;        // accumulator rows a lane holds / folds
   extern __shared__ __attribute__((aligned(16))) float patch[];
   const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
   const int j = wave & 1, hk = wave >> 1;
@@ -179,10 +182,10 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     return ((ih - r_first) * W2 + iw) * PSTR;
   };
   const int choff = 32 * hk + 4 * h2;
-  const float* a32 = patch + slot(p0 + i31) + choff;
+  const float* a32 = patch + (MAIN ? slot(p0 + i31) : 0) + choff;
   const float* a4[XB];
 #pragma unroll
-  for (int b = 0; b < XB; ++b) a4[b] = patch + slot(p0 + 32 + 4 * b + (lane & 3)) + choff;
+  for (int b = 0; b < XB; ++b) a4[b] = patch + slot(p0 + 32 * MAIN + 4 * b + (lane & 3)) + choff;
   const int rowoff = W2 * PSTR;
 
   // two accumulator chains: with one wave per SIMD a single dependent MFMA chain leaves issue gaps
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   auto frag = [&](int it, int set) {
     const int tap = it >> 2, th = tap / 3, tw = tap - 3 * th;
     const int off = th * rowoff + tw * PSTR + 8 * (it & 3);
-    fa[set] = *reinterpret_cast<const f32x4*>(a32 + off);
+    if constexpr (MAIN) fa[set] = *reinterpret_cast<const f32x4*>(a32 + off);
 #pragma unroll
     for (int b = 0; b < XB; ++b) fb[set][b] = *reinterpret_cast<const f32x4*>(a4[b] + off);
   };
@@ -213,15 +216,17 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (e & 1) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[it & 1][e], b[e], accb, 0, 0, 0);
-      else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[it & 1][e], b[e], acc, 0, 0, 0);
+      if constexpr (MAIN) {
+        if (e & 1) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[it & 1][e], b[e], accb, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[it & 1][e], b[e], acc, 0, 0, 0);
+      }
 #pragma unroll
       for (int xb = 0; xb < XB; ++xb) acc4[xb] = __builtin_amdgcn_mfma_f32_4x4x1f32(fb[it & 1][xb][e], b[e], acc4[xb], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] += accb[r];
+  for (int r = 0; r < 16 * MAIN; ++r) acc[r] += accb[r];
   // even / odd channel halves of the 4-pixel block live in lanes l and l+32
 #pragma unroll
   for (int b = 0; b < XB; ++b)
@@ -233,16 +238,16 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   float* fold = patch;  // [j][FR][64]
   if (hk == 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) fold[(j * FR + r) * 64 + lane] = acc[r];
+    for (int r = 0; r < 16 * MAIN; ++r) fold[(j * FR + r) * 64 + lane] = acc[r];
 #pragma unroll
-    for (int i = 0; i < 4 * XB; ++i) fold[(j * FR + 16 + i) * 64 + lane] = acc4[i >> 2][i & 3];
+    for (int i = 0; i < 4 * XB; ++i) fold[(j * FR + 16 * MAIN + i) * 64 + lane] = acc4[i >> 2][i & 3];
   }
   __syncthreads();
   if (hk == 1) return;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] += fold[(j * FR + r) * 64 + lane];
+  for (int r = 0; r < 16 * MAIN; ++r) acc[r] += fold[(j * FR + r) * 64 + lane];
 #pragma unroll
-  for (int i = 0; i < 4 * XB; ++i) acc4[i >> 2][i & 3] += fold[(j * FR + 16 + i) * 64 + lane];
+  for (int i = 0; i < 4 * XB; ++i) acc4[i >> 2][i & 3] += fold[(j * FR + 16 * MAIN + i) * 64 + lane];
 
   // ---- epilogue.  32x32 accumulator: col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5);
   //      4x4 accumulator: row 32+i, col = lane&31 (both lane halves hold the folded sum; half 0 stores)
@@ -259,22 +264,22 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   // all 20 rows before the first store: a load issued behind a store cannot be consumed until that store has landed
   float rv[16], rv4[4 * XB];
 #pragma unroll
-  for (int r = 0; r < 16; ++r)
+  for (int r = 0; r < 16 * MAIN; ++r)
     rv[r] = a.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)obase, ((r & 3) + 8 * (r >> 2)) * 256, 0)) : 0.f;
 #pragma unroll
   for (int i = 0; i < 4 * XB; ++i)
-    rv4[i] = a.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)obase4, (32 + i) * 256, 0)) : 0.f;
+    rv4[i] = a.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)obase4, (32 * MAIN + i) * 256, 0)) : 0.f;
   // BNR: the BatchNorm input at this lane's 20 (row, column) positions, and the layer's per-channel constants
   float yv[16], yv4[4 * XB];
   float bmu = 0.f, bis = 0.f, bgm = 0.f, bbt = 0.f, bsl = 1.f, t1 = 0.f, t2 = 0.f, tp = 0.f;
   if constexpr (BNR) {
     const __amdgpu_buffer_rsrc_t rbn = srx_rsrc(a.bn.y, a.out_bytes);
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+    for (int r = 0; r < 16 * MAIN; ++r)
       yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbn, (int)obase, ((r & 3) + 8 * (r >> 2)) * 256, 0));
 #pragma unroll
     for (int i = 0; i < 4 * XB; ++i)
-      yv4[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbn, (int)obase4, (32 + i) * 256, 0));
+      yv4[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbn, (int)obase4, (32 * MAIN + i) * 256, 0));
     bmu = a.bn.mean[col]; bis = a.bn.invstd[col]; bgm = a.bn.gamma[col]; bbt = a.bn.beta[col];
     if (a.bn.prelu) bsl = a.bn.prelu[0];
   }
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     if (a.bn.prelu && !pos) tp += o * z;
   };
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int r = 0; r < 16 * MAIN; ++r) {
     const float v = acc[r] + bv;
     s1 += v;
     s2 += v * v;
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     if (h2 == 0) { s1 += v; s2 += v * v; }
     const float o = (v > 0.f ? v : v * a.slope) + rv4[i];
     if constexpr (BNR) { if (h2 == 0) bn_acc(o, yv4[i]); }
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rout, obase4, (32 + i) * 256, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rout, obase4, (32 * MAIN + i) * 256, 0);
   }
   if constexpr (BNR) {  // table row of this workgroup: [0, C) sum dz, [C, 2C) sum dz * xhat, 2C + j the PReLU partial of wave j
     t1 += __shfl_xor(t1, 32, 64);
@@ -335,7 +340,7 @@ int patch_batches(int W, int RT) { return (int)srx_cdiv((int64_t)patch_rows_max(
 
 size_t lds_bytes(int W, int RT) {  // every thread stores all its NB * PB slots: size for the rounded-up slot count
   const size_t patch = (size_t)patch_batches(W, RT) * (256 * PB / 16) * PSTR * sizeof(float);
-  const size_t fold = 2 * (RT - 16) * 64 * sizeof(float);
+  const size_t fold = 2 * (size_t)(RT >= 32 ? RT - 16 : RT) * 64 * sizeof(float);
   return patch > fold ? patch : fold;
 }
 
@@ -357,6 +362,7 @@ int tile_pixels(const srx_conv2d_t* d) {
   // small problems only: above ~2 rounds of the chip the generic 128-row tiles re-read far less input
   if (!tile_fits(d, RT36) || m / RT36 > 2 * cus) return 0;
   if (m / RT36 > cus && tile_fits(d, RT48) && m / RT48 <= cus) return RT48;
+  if (m / RT36 <= cus / 4 && tile_fits(d, RT12)) return RT12;  // a quarter of the chip or less at 36 pixels: finer tiles
   return RT36;
 }
 
@@ -406,6 +412,7 @@ int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const
     else RT_LAUNCH(NB_, false, false, false, T_);                      \
   } while (0)
   if (RT == RT36) { if (nb == 1) RT_MODES(1, RT36); else RT_MODES(2, RT36); }
+  else if (RT == RT12) { if (nb == 1) RT_MODES(1, RT12); else RT_MODES(2, RT12); }
   else { if (nb == 1) RT_MODES(1, RT48); else RT_MODES(2, RT48); }
 #undef RT_MODES
 #undef RT_LAUNCH
