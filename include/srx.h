@@ -176,6 +176,14 @@ int srx_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
 int srx_conv2d_fwd_bf16in(const srx_conv2d_t* d, const void* x_bf16, const float* wpk_fwd, const float* bias, float* y,
                           void* stream);
 
+/* The same conv (nn.Conv2d(64, Cout <= 3, 9, 1, 4), srgan/generator.py:58,80) as a GEMM whose N is supplied by the taps -- 9
+ * row taps x 3 channels = 27 MFMA rows, K = 9 column taps x 64 channels -- on v_mfma_f32_32x32x16_bf16 (thin9.hip): x bf16
+ * [N][H][W][64], y fp32 [N][H][W][4] (channels >= Cout written as 0), bf16 products, fp32 accumulation; any H, W.
+ * pack: w OIHW fp32 [Cout][64][9][9], bias [Cout] or NULL -> srx_conv9x9_c64_thin_bf16_packed_bytes() bytes. */
+size_t srx_conv9x9_c64_thin_bf16_packed_bytes(void);
+int srx_conv9x9_c64_thin_bf16_pack(const float* w, const float* bias, int Cout, void* wpk, void* stream);
+int srx_conv9x9_c64_thin_bf16_fwd(int N, int H, int W, const void* x, const void* wpk, float* y, void* stream);
+
 /* y = act(conv(x, W) + bias) * out_scale + residual, residual laid out like y (not for shuffle layers).
  * With the eval-mode BatchNorm folded into W and bias by the host this is a whole `x + BN(conv(.))` of the
  * residual block (srgan/residual.py:86-91, srgan/generator.py:77-78) in one kernel; with out_scale = 0.2 it

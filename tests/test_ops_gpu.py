@@ -1270,3 +1270,29 @@ def test_bf16_native_conv3x3_c64(dev, n, h, w, cout, shuffle, res):
         _lib.call('srx_conv3x3_c64_bf16_fwd', n, h, w, cout, shuffle, xd.data_ptr(), pk.data_ptr(), slope, None, xd.data_ptr(), oc, s)
     with pytest.raises(RuntimeError, match='channel stride'):
         _lib.call('srx_conv3x3_c64_bf16_fwd', n, h, w, cout, shuffle, xd.data_ptr(), pk.data_ptr(), slope, None, y.data_ptr(), 60, s)
+
+
+@pytest.mark.parametrize('n,h,w,cout', [(1, 40, 150, 3), (2, 9, 33, 3), (1, 300, 130, 3), (1, 5, 7, 1), (1, 64, 256, 2)])
+def test_bf16_output_conv_with_taps_as_gemm_columns(dev, n, h, w, cout):
+    """``srx_conv9x9_c64_thin_bf16_fwd`` (the 9x9 64 -> 3 output conv as a GEMM with N = 9 row taps x 3 channels, the vertical
+    sum in an LDS ring of output rows) through the C ABI against fp64 of the bf16 operands: ragged strips, images shorter than
+    the 9-row window, several row chunks per strip, fewer than three output channels."""
+    from torchsr_amd import _lib
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(7 * h + w)
+    x = (torch.rand(n, 64, h, w, generator=g) - 0.5).bfloat16()
+    wt = torch.randn(cout, 64, 9, 9, generator=g) * (1.0 / 5184) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd, bd = wt.to(dev), b.to(dev)
+    pk = torch.empty(L.srx_conv9x9_c64_thin_bf16_packed_bytes(), dtype=torch.uint8, device=dev)
+    _lib.call('srx_conv9x9_c64_thin_bf16_pack', wd.data_ptr(), bd.data_ptr(), cout, pk.data_ptr(), s)
+    y = torch.full((n, h, w, 4), float('nan'), device=dev)
+    _lib.call('srx_conv9x9_c64_thin_bf16_fwd', n, h, w, xd.data_ptr(), pk.data_ptr(), y.data_ptr(), s)
+    torch.cuda.synchronize()
+    z = TF.conv2d(x.double(), wt.bfloat16().double(), b.double(), 1, 4)
+    got = y.permute(0, 3, 1, 2).cpu().double()
+    assert torch.isfinite(got).all()
+    assert ((got[:, :cout] - z).abs().max() / z.abs().max()).item() < 2e-5
+    assert float(got[:, cout:].abs().max()) == 0.0

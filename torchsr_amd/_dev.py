@@ -11,3 +11,4 @@ NO_ACT_FOLD = _on('SRX_NO_ACT_FOLD')            # keep the first LeakyReLU backw
 NO_BN_DGRAD_FUSE = _on('SRX_NO_BN_DGRAD_FUSE')  # residual tower: separate BatchNorm-backward reduce launches
 NO_RDB_FUSED = _on('SRX_NO_RDB_FUSED')          # ESRGAN dense blocks: five conv launches instead of srx_rdb_fwd / srx_rdb_bwd
 NO_C64 = _on('SRX_NO_C64')                      # bf16 inference: fp32-stored activations (round 3's path) instead of the bf16-native chain
+NO_T9 = _on('SRX_NO_T9')                        # bf16 inference: the 9x9 output conv on the 4x4x4 MFMA kernel instead of thin9.hip

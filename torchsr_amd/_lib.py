@@ -12,7 +12,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('SRX_LIB') or os.path.join(CSRC, 'libsrx_hip.so')  # SRX_LIB: developer A/B builds on one GPU box
-SOURCES = ['api.cpp', 'gconv.hip', 'c64.hip', 'rdb.hip', 'thin.hip', 'rowtile.hip', 'augment.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'optim.hip']
+SOURCES = ['api.cpp', 'gconv.hip', 'c64.hip', 'thin9.hip', 'rdb.hip', 'thin.hip', 'rowtile.hip', 'augment.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'optim.hip']
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
 
@@ -154,6 +154,9 @@ _SIGS = {
     'srx_conv3x3_c64_bf16_fwd': (_I, [_I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _I, _P]),
     'srx_f32_to_bf16': (_I, [_P, _P, _L, _P]),
     'srx_bf16_to_f32': (_I, [_P, _P, _L, _P]),
+    'srx_conv9x9_c64_thin_bf16_packed_bytes': (_Z, []),
+    'srx_conv9x9_c64_thin_bf16_pack': (_I, [_P, _P, _I, _P, _P]),
+    'srx_conv9x9_c64_thin_bf16_fwd': (_I, [_I, _I, _I, _P, _P, _P, _P]),
     'srx_conv2d_fwd_bf16in': (_I, [_D, _P, _P, _P, _P, _P]),
     'srx_conv2d_fwd_residual': (_I, [_D, _P, _P, _P, _P, _F, _P, _P, _Z, _P]),
     'srx_conv2d_bwd_data': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),

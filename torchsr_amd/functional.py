@@ -193,9 +193,21 @@ def conv2d_bf16in(conv, x: Tensor) -> Tensor:
     if st.precision != 2 or torch.is_grad_enabled():
         return conv(to_f32(x))
     d = st.desc(n, h, w)
-    st.pack(conv.weight, d)
     y = torch.empty(st.out_shape(n, h, w), dtype=torch.float32, device=x.device)
     b = None if conv.bias is None else _chk(conv.bias.detach(), 'conv2d.bias')
+    if st.k == 9 and st.pad == 4 and st.stride == 1 and st.cin == 64 and st.cout <= 3 and not _dev.NO_T9:
+        # the taps as the GEMM's N (csrc/thin9.hip): 32x32x16 bf16 MFMAs instead of 4x4x4
+        key = st.pack_key(conv.weight) + (None if b is None else (b.data_ptr(), conv.bias._version),)
+        if conv.__dict__.get('_t9_key') != key:
+            wpk = conv.__dict__.get('_t9_wpk')
+            if wpk is None or wpk.device != x.device:
+                wpk = conv.__dict__['_t9_wpk'] = torch.empty(_lib.lib().srx_conv9x9_c64_thin_bf16_packed_bytes(), dtype=torch.uint8,
+                                                             device=x.device)
+            call('srx_conv9x9_c64_thin_bf16_pack', _p(_chk(conv.weight.detach(), 'conv2d.weight')), _p(b), st.cout, _p(wpk), _stream())
+            conv.__dict__['_t9_key'] = key
+        call('srx_conv9x9_c64_thin_bf16_fwd', n, h, w, _p(x), _p(conv.__dict__['_t9_wpk']), _p(y), _stream())
+        return y
+    st.pack(conv.weight, d)
     call('srx_conv2d_fwd_bf16in', C.byref(d), _p(x), _p(st.wpk_fwd), _p(b), _p(y), _stream())
     return y
 
