@@ -274,3 +274,37 @@ def test_esrgan_train_cli(dev, tmp_path, monkeypatch):
     assert out.shape == (144, 176, 3) and out.std() > 0
     main(['train', '--model', 'esrgan', '--train-dir', 'synthetic:8', '--batch-size', '2', '--epochs', '1',
           '--pretrain-epochs', '1', '--seed', '8', '--vgg-weights', 'random', '--skip-image-save', '--device-data'])
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_whole_frame_calls_equal_the_staged_ones(dev, precision):
+    """Round 4: no 2^24-pixel / 4 GiB cap per conv call (64-bit tile bases in the generic kernel, per-tile row bases in the 3-channel
+    output conv, row bases in the bf16-native kernels).  ``upscale(staged=False, max_tile_pixels=huge)`` runs the whole SRGAN
+    generator on the whole 1080p frame -- its last layers see 33 M pixels and 8.5 GB (fp32) tensors in ONE call each -- and
+    must equal the staged result bit for bit (the same kernels on the same values: tiling changes addresses only)."""
+    from oracle.weights import closed_form_state
+    from torchsr_amd.srgan.generator import Generator
+    from torchsr_amd.test import upscale
+    gen = Generator().to(dev)
+    gen.load_state_dict(closed_form_state(gen.state_dict()))
+    frame = torch.rand(1, 3, 1080, 1920, generator=torch.Generator().manual_seed(13)).to(dev)
+    staged = upscale(gen, frame, precision=precision)
+    whole = upscale(gen, frame, precision=precision, staged=False, max_tile_pixels=10 ** 10)
+    assert whole.shape == (1, 3, 4320, 7680)
+    assert torch.equal(whole, staged)
+
+
+def test_esrgan_whole_1080p_frame_untiled(dev):
+    """ESRGAN (one RRDB, so that the receptive field stays inside the tiles' 64-pixel halo and tiling is exact) on a
+    1080p frame as ONE call per layer -- 33 M pixels at the high-resolution convs, the nearest-upsample gather included --
+    against the tiled run: the same kernels on the same values, equal to fp32 rounding of differently ordered tiles."""
+    from torchsr_amd.esrgan.generator import Generator
+    from torchsr_amd.test import upscale
+    torch.manual_seed(3)
+    gen = Generator(num_rrdb_blocks=1).to(dev)
+    frame = torch.rand(1, 3, 1080, 1920, generator=torch.Generator().manual_seed(14)).to(dev)
+    tiled = upscale(gen, frame)
+    whole = upscale(gen, frame, max_tile_pixels=10 ** 10)
+    assert whole.shape == (1, 3, 4320, 7680)
+    top = tiled.abs().max().item()
+    assert (whole - tiled).abs().max().item() <= 1e-5 * top

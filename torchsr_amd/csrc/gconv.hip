@@ -49,8 +49,13 @@ struct GArgs {
   int kchunks, kc_per_split, full_tiles, tail_split;
   float* ws;
   // sizes of the `in` and `w` buffers: both are read through raw buffer descriptors, whose range
-  // check returns 0 for the padding taps (no branch, no select, statically countable loads)
-  unsigned in_bytes, w_bytes;
+  // check returns 0 for the padding taps (no branch, no select, statically countable loads).  The input descriptor is based
+  // at the first byte the TILE can touch (round 4: a 64-bit base per workgroup, 32-bit offsets inside it), so a call is
+  // not capped at 4 GiB of input; `big`: M >= 2^24, pixel indices are split by exact integer division instead of the float one
+  size_t in_bytes;
+  unsigned w_bytes;
+  int big;
+  unsigned in_margin;  // bytes the most negative tap reaches in front of a row's centre pixel
   // epilogue addend, laid out like `out` (null: none): `out` itself when a data gradient is summed into a
   // shared dense-block buffer, or the skip input of a residual block in eval mode (BatchNorm folded into the
   // conv, `x + conv(...)` in one kernel).  Linear outputs only.
@@ -93,7 +98,11 @@ constexpr int INVALID = -20000;  // coordinate that fails every bounds check
 // 32 k-values are rounded to bf16 when they are written to LDS (64-byte rows) and multiplied by two
 // v_mfma_f32_32x32x16_bf16 per 32x32 block instead of sixteen fp32 MFMAs -- the loop is then bound by the
 // L2 -> LDS stream, not by the matrix pipe.
-template <int BM, int BN, int WM, int WN, int KS, int XR, int PR, int UP = 0>
+// BIG = 1 (round 4): calls above 2^24 pixels / 4 GiB of input (whole-frame inference).  The input descriptor is based at the
+// first byte the TILE can touch -- a 64-bit base per workgroup, 32-bit offsets inside it -- and pixel indices are split by
+// exact integer division.  A separate instantiation: with the per-tile base in the common kernel the SRGAN step lost 1 %
+// (same-box A/B, 8.87 vs 8.97 ms), so BIG = 0 is the code of round 3 to the letter.
+template <int BM, int BN, int WM, int WN, int KS, int XR, int PR, int UP = 0, int BIG = 0>
 __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   static_assert(XR == 0 || (XR == 16 && KS == 1), "extra rows: 16, without the in-workgroup K split");
   static_assert(PR == 0 || XR == 0, "the 16-row extension is fp32 only");
@@ -139,7 +148,38 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   const int nt = srx_uniform(tile / a.mtiles), mt = tile - nt * a.mtiles;
   const int m0 = mt * BMT, n0 = nt * BN;
   const int q = tid & 7, r0 = tid >> 3;
-  const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes), rw = srx_rsrc(a.w, a.w_bytes);
+  auto split_row = [&](int m, int& n, int& mh, int& mw) {  // m -> (image, row, column) of the M grid
+    if constexpr (BIG) {  // exact: the float reciprocal trick holds below 2^24 only
+      n = m / a.HmWm;
+      const int rem = m - n * a.HmWm;
+      mh = rem / a.Wm;
+      mw = rem - mh * a.Wm;
+    } else {
+      int rem;
+      srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
+      srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
+    }
+  };
+  // byte offset of row m's centre pixel in the input tensor (monotonic in m)
+  auto centre = [&](int n, int ih0, int iw0) -> size_t {
+    return 4 * (UP ? (size_t)n * (a.Hi >> 1) * (a.Wi >> 1) * a.Ci
+                   : a.in_shuffle ? (((size_t)n * 2 * a.Hi + 2 * ih0) * (2 * a.Wi) + 2 * iw0) * a.Ci
+                                  : (((size_t)n * a.Hi + ih0) * a.Wi + iw0) * a.Ci);
+  };
+  size_t tbase = 0;  // BIG: first byte this tile can touch: its first row's centre less the reach of the most negative tap
+  if constexpr (BIG) {
+    int n, mh, mw;
+    split_row(min(m0, a.M - 1), n, mh, mw);
+    const size_t c0 = centre(n, mh * a.in_stride, mw * a.in_stride);
+    tbase = c0 > a.in_margin ? c0 - a.in_margin : 0;
+    const unsigned tb_in_lo = (unsigned)srx_uniform((int)(unsigned)(tbase & 0xffffffffu));
+    const unsigned tb_in_hi = (unsigned)srx_uniform((int)(unsigned)(tbase >> 32));
+    tbase = ((size_t)tb_in_hi << 32) | tb_in_lo;
+  }
+  const size_t in_left = a.in_bytes - tbase;
+  const __amdgpu_buffer_rsrc_t rin = BIG ? srx_rsrc(reinterpret_cast<const char*>(a.in) + tbase, in_left > 0xfffffff0ull ? 0xfffffff0u : (unsigned)in_left)
+                                         : srx_rsrc(a.in, (unsigned)a.in_bytes);
+  const __amdgpu_buffer_rsrc_t rw = srx_rsrc(a.w, a.w_bytes);
 
   // ---- k table: (dh, dw) and linear input offset for every float4 of K in range
   for (int e = kc_beg * 8 + (int)threadIdx.x; e < kc_end * 8; e += NT) {
@@ -174,15 +214,18 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   for (int p = 0; p < RA; ++p) {
     const int m = m0 + r0 + RPP * p;
     if (m < a.M && r0 + RPP * p < BMT) {
-      int n, rem, mh, mw;
-      srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
-      srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
+      int n, mh, mw;
+      split_row(m, n, mh, mw);
       const int ih0 = mh * a.in_stride, iw0 = mw * a.in_stride;
       rih[p] = ih0;
       riw[p] = iw0;
-      rbase[p] = 4u * (unsigned)(UP ? n * (a.Hi >> 1) * (a.Wi >> 1) * a.Ci
-                                 : a.in_shuffle ? ((n * 2 * a.Hi + 2 * ih0) * (2 * a.Wi) + 2 * iw0) * a.Ci
-                                                : ((n * a.Hi + ih0) * a.Wi + iw0) * a.Ci);
+      if constexpr (BIG) {
+        rbase[p] = (unsigned)(centre(n, ih0, iw0) - tbase);  // (relative to the tile's base: a tile spans a few image rows)
+      } else {
+        rbase[p] = 4u * (unsigned)(UP ? n * (a.Hi >> 1) * (a.Wi >> 1) * a.Ci
+                                   : a.in_shuffle ? ((n * 2 * a.Hi + 2 * ih0) * (2 * a.Wi) + 2 * iw0) * a.Ci
+                                                  : ((n * a.Hi + ih0) * a.Wi + iw0) * a.Ci);
+      }
     } else {
       rih[p] = INVALID; riw[p] = 0; rbase[p] = 0;
     }
@@ -415,11 +458,11 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   // the arithmetic.
   auto out_elem = [&](int m) -> size_t {  // element offset of output row m
     if (a.linear_out) return (size_t)m * a.Co;
-    int n, rem, mh, mw;
-    srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
-    srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
+    int n, mh, mw;
+    split_row(m, n, mh, mw);
     const int oh = mh * a.out_stride + a.oh_off, ow = mw * a.out_stride + a.ow_off;
-    return ((size_t)(n * a.Ho + oh) * a.Wo + ow) * a.Co;
+    if constexpr (BIG) return (((size_t)n * a.Ho + oh) * a.Wo + ow) * a.Co;
+    else return ((size_t)(n * a.Ho + oh) * a.Wo + ow) * a.Co;
   };
   // descriptor based at the tile's first row: offsets inside a tile are small and never negative
   // (output rows are laid out in increasing m), so 32 bits are enough whatever the tensor size
@@ -602,11 +645,11 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int XR, int PR>
+template <int BM, int BN, int WM, int WN, int KS, int XR, int PR, int BIG = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KS) void gconv_kernel(const GArgs a) {
   // the fused-upsample gather is a second copy of the body, entered by ONE scalar branch: the common loop is untouched
-  if (a.up) gconv_body<BM, BN, WM, WN, KS, XR, PR, 1>(a, blockIdx.x);
-  else gconv_body<BM, BN, WM, WN, KS, XR, PR, 0>(a, blockIdx.x);
+  if (a.up) gconv_body<BM, BN, WM, WN, KS, XR, PR, 1, BIG>(a, blockIdx.x);
+  else gconv_body<BM, BN, WM, WN, KS, XR, PR, 0, BIG>(a, blockIdx.x);
 }
 
 // several independent gather-GEMMs in one launch: the stride-parity classes of a strided data
@@ -1297,11 +1340,21 @@ int check_desc(const srx_conv2d_t* d) {
   const int uf = d->up == 2 ? 2 : 1;
   const int Ho = (uf * d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (uf * d->W + 2 * d->pad - d->KW) / d->stride + 1;
   SRX_REQUIRE(Ho > 0 && Wo > 0, "conv2d: empty output");
-  SRX_REQUIRE((int64_t)d->N * uf * d->H * uf * d->W < (1 << 24) && (int64_t)d->N * Ho * Wo < (1 << 24),
-              "conv2d: more than 2^24 pixels per call; tile the image");
-  SRX_REQUIRE((int64_t)d->N * d->H * d->W * d->Cin_s < (1LL << 30) - 4, "conv2d: input above 4 GiB; tile the image");
+  // (the generic forward / data-gradient kernel addresses by 64-bit tile bases and splits pixel indices exactly above 2^24;
+  // the kernels that do not -- weight gradients, the row tile, the 3-channel input layers -- check `small_enough` themselves)
+  SRX_REQUIRE((int64_t)d->N * uf * d->H * uf * d->W < (1LL << 31) - 1024 && (int64_t)d->N * Ho * Wo < (1LL << 31) - 1024,
+              "conv2d: more than 2^31 pixels per call; tile the image");
+  SRX_REQUIRE((int64_t)uf * d->W * d->Cin_s * 4 * (d->KH + 160) < (1LL << 32), "conv2d: image rows too long for 32-bit offsets inside a tile");
   SRX_REQUIRE(d->pad < 16000 && d->KH < 16000, "conv2d: kernel too large");
   return SRX_OK;
+}
+
+// below 2^24 pixels and 4 GiB of input: what the kernels with 32-bit tensor offsets / float index division can take
+bool small_enough(const srx_conv2d_t* d) {
+  const int uf = d->up == 2 ? 2 : 1;
+  const int Ho = (uf * d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (uf * d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  return (int64_t)d->N * uf * d->H * uf * d->W < (1 << 24) && (int64_t)d->N * Ho * Wo < (1 << 24) &&
+         (int64_t)d->N * d->H * d->W * d->Cin_s < (1LL << 30) - 4;
 }
 
 int pad_rows(int c) { return c <= 32 ? 32 : (int)srx_roundup(c, 64); }  // rows of a packed operand: whole 64-column tiles (32 for the narrow tile)
@@ -1372,18 +1425,23 @@ struct Plan { int BM, BN, mtiles, ntiles, tiles, full, tail, split, kc_per_split
 
 int device_cus() { return srx_plan_cus(); }  // the device's CUs less the reserved ones (api.cpp)
 
-Plan make_plan(int M, int Cnp, int kchunks, bool can_split, bool bf16 = false) {
+Plan make_plan(int M, int Cnp, int kchunks, bool can_split, bool bf16 = false, bool big = false) {
   const int P = device_cus();
-  constexpr int NC = 7;
+  constexpr int NC = 8;
   // (64, 32): narrow layers (the 32-channel growth convs of ESRGAN's dense blocks) on twice as many tiles, the
   // k-chunks of each tile split over 2 (fp32) / 4 (bf16) wave groups inside the workgroup -- no fix-up pass
-  const int cand[NC][2] = {{144, 128}, {144, 64}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 32}};
-  const float eff[NC] = {0.91f, 0.82f, 0.95f, 0.85f, 0.60f, 0.50f, 0.50f};  // measured MFMA efficiency in steady state
+  // (256, 128), bf16 only (round 4): 64 x 64 per wave, one LDS fragment read per MFMA instead of 1.5 -- the bf16 loop is bound
+  // by LDS traffic: 256 -> 256 at 32 x 32 x 32 pixels 560 -> 650 TFLOP/s, 128 -> 256 at 64^2 484 -> 546; with fp32 products the
+  // same tile LOSES a third (72 vs 110 TFLOP/s: 212 registers, and nothing there was LDS-bound) and is never planned
+  const int cand[NC][2] = {{144, 128}, {144, 64}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 32}, {256, 128}};
+  const float eff[NC] = {0.91f, 0.82f, 0.95f, 0.85f, 0.60f, 0.50f, 0.50f, 1.08f};  // measured MFMA efficiency in steady state
   Plan best{};
   best.cost = 1e30f;
   for (int i = 0; i < NC; ++i) {
     const int bm = cand[i][0], bn = cand[i][1];
     if (bf16 && bm == 144) continue;
+    if (!bf16 && bm == 256) continue;
+    if (big && bm != 128) continue;  // whole-frame calls (BIG instantiations): 128 x {128, 64, 32}
     if (Cnp == 32) { if (bn != 32) continue; }
     else if (bn == 32 || Cnp % bn != 0) continue;
     Plan p{};
@@ -1398,7 +1456,7 @@ Plan make_plan(int M, int Cnp, int kchunks, bool can_split, bool bf16 = false) {
     const int rounds = p.tiles / P, r = p.tiles % P;
     p.full = rounds * P; p.tail = r; p.split = 1; p.kc_per_split = kchunks;
     float tail_cost = r ? t_tile : 0.f;
-    if (r && can_split) {
+    if (r && can_split && !big) {
       const int smax = kchunks / 4 < 16 ? kchunks / 4 : 16;
       for (int s = 2; s <= smax; ++s) {
         const int kcs = (int)srx_cdiv(kchunks, s);
@@ -1414,7 +1472,7 @@ Plan make_plan(int M, int Cnp, int kchunks, bool can_split, bool bf16 = false) {
     if (p.cost < best.cost) best = p;
   }
   // developer override for tile experiments: SRX_FORCE_PLAN="BM,BN,split,ks" (split: K-split of ALL tiles)
-  if (srx_dev().force_plan) {
+  if (srx_dev().force_plan && !big) {
     const int bm = srx_dev().plan[0], bn = srx_dev().plan[1], sp = srx_dev().plan[2], ks = srx_dev().plan[3];
     if (bn > 0 && Cnp % bn == 0) {
       Plan p{};
@@ -1429,27 +1487,28 @@ Plan make_plan(int M, int Cnp, int kchunks, bool can_split, bool bf16 = false) {
   // fewer workgroups than CUs and a 4-wave tile: split its k-chunks over two wave groups (KS = 2)
   best.ks = (best.BM == 64 && best.BN == 64 && best.full + best.tail * best.split <= P && best.kc_per_split >= 4) ? 2 : 1;
   if (best.BM == 64 && best.BN == 32) best.ks = bf16 ? 4 : 2;
+  if (big) best.ks = 1;
   return best;
 }
 
 size_t plan_ws_floats(const Plan& p) { return p.split > 1 ? (size_t)p.tail * p.split * p.BM * p.BN : 0; }
 
-template <int BM, int BN, int WM, int WN, int KS, int XR, int PR = 0>
+template <int BM, int BN, int WM, int WN, int KS, int XR, int PR = 0, int BIG = 0>
 int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
   const int ktab_chunks = p.full > 0 || p.split == 1 ? a.kchunks : p.kc_per_split;
   const size_t lds = (size_t)(KS * 3 * (BM + XR + BN) * BK) * (PR ? 2 : 4) + (size_t)ktab_chunks * 8 * sizeof(int2);
   if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN, KS, XR, PR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN, KS, XR, PR, BIG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(p.full + p.tail * p.split);
   char nm[112];  // kernel + GEMM shape: the roofline leg of bench.py groups launches by both
   if (srx_prof_on())
-    snprintf(nm, sizeof(nm), "gconv_kernel<%d, %d, %d, %d, %d, %d, %d> MxNxK=%dx%dx%d", BM, BN, WM, WN, KS, XR, PR, a.M, a.Cn,
-             a.K);
-  SRX_LAUNCH_PROF(nm, 2.0 * a.M * a.Cn * a.K, (gconv_kernel<BM, BN, WM, WN, KS, XR, PR>), grid,
+    snprintf(nm, sizeof(nm), "gconv_kernel<%d, %d, %d, %d, %d, %d, %d%s> MxNxK=%dx%dx%d", BM, BN, WM, WN, KS, XR, PR, BIG ? ", big" : "",
+             a.M, a.Cn, a.K);
+  SRX_LAUNCH_PROF(nm, 2.0 * a.M * a.Cn * a.K, (gconv_kernel<BM, BN, WM, WN, KS, XR, PR, BIG>), grid,
                   dim3((BM / WM) * (BN / WN) * 64 * KS), lds, st, a);
   SRX_CHECK_LAUNCH("gconv_kernel");
   if (p.split > 1) {
@@ -1554,7 +1613,21 @@ int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t 
   a.full_tiles = p.full;
   a.tail_split = p.split;
   a.ws = ws;
+  if (a.big) {  // whole-frame calls: three tiles, no K split (plans made with `big` ask for nothing else)
+    if (p.split > 1) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: internal: split plan on a call above 2^24 pixels");
+    if (precision) {
+      if (p.BM == 128 && p.BN == 128) return launch_gconv<128, 128, 64, 32, 1, 0, 1, 1>(a, p, st);
+      if (p.BM == 128 && p.BN == 64) return launch_gconv<128, 64, 32, 32, 1, 0, 1, 1>(a, p, st);
+      if (p.BM == 128 && p.BN == 32) return launch_gconv<128, 32, 32, 32, 1, 0, 1, 1>(a, p, st);
+    } else {
+      if (p.BM == 128 && p.BN == 128) return launch_gconv<128, 128, 64, 32, 1, 0, 0, 1>(a, p, st);
+      if (p.BM == 128 && p.BN == 64) return launch_gconv<128, 64, 32, 32, 1, 0, 0, 1>(a, p, st);
+      if (p.BM == 128 && p.BN == 32) return launch_gconv<128, 32, 32, 32, 1, 0, 0, 1>(a, p, st);
+    }
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: no whole-frame kernel for tile %dx%d", p.BM, p.BN);
+  }
   if (precision) {  // bf16 products (plans made with `bf16 = true` never ask for the 144-row tiles)
+    if (p.BM == 256 && p.BN == 128) return launch_gconv<256, 128, 64, 64, 1, 0, 1>(a, p, st);
     if (p.BM == 128 && p.BN == 128) return launch_gconv<128, 128, 64, 32, 1, 0, 1>(a, p, st);
     if (p.BM == 128 && p.BN == 64) return launch_gconv<128, 64, 32, 32, 1, 0, 1>(a, p, st);
     if (p.BM == 64 && p.BN == 64)
@@ -1579,8 +1652,11 @@ void set_mgrid(GArgs& a, int N, int Hm, int Wm) {
   a.inv_Wm = 1.0f / (float)Wm;
 }
 
+// above 2^24 pixels or 4 GiB of input: the BIG instantiations (64-bit tile bases, exact index division)
+bool is_big(const srx_conv2d_t* d) { return !small_enough(d); }
+
 Plan fwd_plan(const srx_conv2d_t* d, const Geo& g) {
-  return make_plan(d->N * g.Ho * g.Wo, g.Cnp, g.Kp / BK, !d->shuffle, d->precision != 0);
+  return make_plan(d->N * g.Ho * g.Wo, g.Cnp, g.Kp / BK, !d->shuffle, d->precision != 0, is_big(d));
 }
 
 Plan bwd_plan(const srx_conv2d_t* d, const BwdClass& c) {
@@ -1956,8 +2032,10 @@ static int conv_fwd_impl(const srx_conv2d_t* d, const float* x, const float* wpk
   a.add = residual;
   a.oscale = out_scale;
   a.add_ld = a.Co; a.add_hi = 0x7fffffff; a.ascale = 1.f;
-  a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin_s * sizeof(float));
+  a.in_bytes = (size_t)d->N * d->H * d->W * d->Cin_s * sizeof(float);
   a.w_bytes = (unsigned)((size_t)g.Cnp * g.Kp * sizeof(float));
+  a.big = is_big(d);
+  a.in_margin = a.up ? 0u : 4u * (unsigned)((d->pad * a.Wi + d->pad) * a.Ci);  // taps start `pad` rows and columns before the centre
   return run_gconv(a, fwd_plan(d, g), ws, ws_floats, st, d->precision);
 }
 
@@ -2008,6 +2086,7 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
   if (d->up == 2) {
     if (accumulate || act_out || addend)
       SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: up = 2 with accumulate / an addend / a folded activation");
+    SRX_REQUIRE(small_enough(d), "conv2d_bwd_data: up = 2 above 2^24 pixels (the 2x2 block sum keeps 32-bit offsets)");
     const srx_conv2d_t h = upsampled_desc(d);
     const size_t tmp = upsampled_floats(d);
     SRX_REQUIRE(ws && ws_floats >= tmp + srx_conv2d_bwd_data_ws_floats(&h), "conv2d_bwd_data: workspace too small for up = 2");
@@ -2039,7 +2118,9 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
       SRX_FAIL(SRX_E_HIP, "conv2d_bwd_data: memset failed");
   }
   const size_t dy_bytes = (size_t)d->N * g.Ho * g.Wo * (d->shuffle ? 4 : 1) * d->Cout_s * sizeof(float);
-  SRX_REQUIRE(dy_bytes < 0xfffffff0ull, "conv2d_bwd_data: gradient tensor too large for 32-bit offsets; tile the image");
+  SRX_REQUIRE(small_enough(d) && dy_bytes < 0xfffffff0ull,
+              "conv2d_bwd_data: more than 2^24 pixels or 4 GiB per tensor (data gradients keep 32-bit offsets: training crops, not whole frames)");
+
   GMulti multi{};
   for (int i = 0; i < nc; ++i) {
     const BwdClass& c = cls[i];
@@ -2059,7 +2140,17 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
     a.act = SRX_ACT_NONE; a.slope = 1.f;
     a.linear_out = (d->stride == 1);
     a.out = dx;
-    a.in_bytes = (unsigned)dy_bytes;
+    a.in_bytes = dy_bytes;
+    a.big = 0;
+    {  // the most negative tap of this class: dminh rows / dminw columns (in units of the gradient tensor's pixels, x2 when shuffled)
+      const long long o = g.cps ? ((2LL * c.dminh) * (2 * a.Wi) + 2LL * c.dminw) * a.Ci : ((long long)c.dminh * a.Wi + c.dminw) * a.Ci;
+      // A class's grid (Hm x Wm) may be larger than the gradient image (pad = 0: the last input rows / columns see no output):
+      // such rows' "centre" lies past their image, so a LATER row (the next image's first) can sit lower in memory -- the
+      // tile's base must leave room for that overshoot too
+      const long long over_h = std::max(0, c.Hm - a.Hi), over_w = std::max(0, c.Wm - a.Wi);
+      const long long over = g.cps ? ((2 * over_h) * (2LL * a.Wi) + 2 * over_w) * a.Ci : (over_h * a.Wi + over_w) * a.Ci;
+      a.in_margin = (unsigned)(((o < 0 ? -o : 0) + over) * 4);
+    }
     a.w_bytes = (unsigned)((size_t)pad_rows(d->Cin) * c.Kp * sizeof(float));
     a.add = accumulate ? dx : addend;
     a.oscale = out_scale;
@@ -2230,6 +2321,8 @@ static int wgrad_multi_impl(const srx_conv2d_t* d, int nprob, int per_out, const
   SRX_REQUIRE(nprob >= 1 && nprob <= WG_MAXP && per_out >= 1 && nprob % per_out == 0,
               "conv2d_bwd_weight_multi: 1..%d problems, a whole number of outputs", WG_MAXP);
   SRX_REQUIRE(xs && dys && dws && ws, "conv2d_bwd_weight: null pointer");
+  SRX_REQUIRE(small_enough(d), "conv2d_bwd_weight: more than 2^24 pixels or 4 GiB of input per problem (the weight-gradient kernels "
+                               "keep 32-bit tensor offsets: training crops, not whole frames)");
   if (d->up == 2) {
     const srx_conv2d_t h = upsampled_desc(d);
     const size_t tmp = upsampled_floats(d);

@@ -185,7 +185,10 @@ __global__ __launch_bounds__(256) void thin_fwd2_kernel(const ThinF a) {
   const int n = b / a.tiles_h;
   const int h0 = th_i * TH, w0 = tw_i * TW;
   const int pc = lane & 31, hh = lane >> 5, r0 = wave * R, wc = lane & 3;
-  const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes);
+  // the descriptor covers the image rows this tile's patch can touch, based at the first of them (a 64-bit base; offsets
+  // inside it are small): tensors above 4 GiB / 2^24 pixels -- the 8K frame -- need no tiling (round 4)
+  const int hb = max(h0 - PAD, 0), he = min(h0 - PAD + PH, a.H);
+  const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in + ((size_t)n * a.H + hb) * (size_t)a.W * 64, (unsigned)((size_t)(he - hb) * a.W * 256));
   const __amdgpu_buffer_rsrc_t rw = srx_rsrc(a.w, 4 * TAPS * 64 * 4);
 
   f32x4 acc[R];
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256) void thin_fwd2_kernel(const ThinF a) {
       const int pw = pix % PW, ph = pix / PW;
       const int ih = h0 - PAD + ph, iw = w0 - PAD + pw;
       const bool ok = i < NPX && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-      vp[u] = srx_bload(rin, ok ? 4u * (unsigned)(((n * a.H + ih) * a.W + iw) * 64 + cc + q * 4) : 0xffffffffu, 0);
+      vp[u] = srx_bload(rin, ok ? 4u * (unsigned)(((ih - hb) * a.W + iw) * 64 + cc + q * 4) : 0xffffffffu, 0);
     }
 #pragma unroll
     for (int u = 0; u < LW; ++u) {
@@ -282,7 +285,10 @@ __global__ __launch_bounds__(256) void thin_fwd2_bf16_kernel(const ThinF a) {
   const int n = b / a.tiles_h;
   const int h0 = th_i * TH, w0 = tw_i * TW;
   const int pc = lane & 31, hh = lane >> 5, r0 = wave * R, wc = lane & 3;
-  const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes);
+  const int hb = max(h0 - PAD, 0), he = min(h0 - PAD + PH, a.H);  // (64-bit row base: see thin_fwd2_kernel)
+  constexpr unsigned PXB = IN16 ? 128u : 256u;                    // bytes per input pixel
+  const __amdgpu_buffer_rsrc_t rin = srx_rsrc(reinterpret_cast<const unsigned char*>(a.in) + ((size_t)n * a.H + hb) * (size_t)a.W * PXB,
+                                              (unsigned)((size_t)(he - hb) * a.W * PXB));
   const __amdgpu_buffer_rsrc_t rw = srx_rsrc(a.w, 4 * TAPS * 64 * 4);
 
   f32x4 acc[R];
@@ -305,9 +311,9 @@ __global__ __launch_bounds__(256) void thin_fwd2_bf16_kernel(const ThinF a) {
       const int ih = h0 - PAD + ph, iw = w0 - PAD + pw;
       const bool ok = i < NPX && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
       if constexpr (IN16) {  // the unit (pixel, 8-channel half) is 16 bytes of the bf16 tensor as it stands
-        vp[u][0] = srx_bload(rin, ok ? 2u * (unsigned)(((n * a.H + ih) * a.W + iw) * 64 + cc + q * 8) : 0xffffffffu, 0);
+        vp[u][0] = srx_bload(rin, ok ? 2u * (unsigned)(((ih - hb) * a.W + iw) * 64 + cc + q * 8) : 0xffffffffu, 0);
       } else {
-        const unsigned off = ok ? 4u * (unsigned)(((n * a.H + ih) * a.W + iw) * 64 + cc + q * 8) : 0xffffffffu;
+        const unsigned off = ok ? 4u * (unsigned)(((ih - hb) * a.W + iw) * 64 + cc + q * 8) : 0xffffffffu;
         vp[u][0] = srx_bload(rin, off, 0);
         vp[u][1] = srx_bload(rin, off, 16);
       }
