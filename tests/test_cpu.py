@@ -298,7 +298,9 @@ def test_descriptor_validation_without_a_gpu():
 
     ok = (16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)
     assert plan_error(*ok)[0] == 0 and list(out)[:2] == [36, 64]
-    rc, msg = plan_error(1, 5000, 5000, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)          # > 2^24 pixels
+    # > 2^24 pixels: a whole-frame call (round 4: 64-bit tile bases, exact index division) on 128-row tiles
+    assert plan_error(1, 5000, 5000, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)[0] == 0 and out[0] == 128
+    rc, msg = plan_error(1, 50000, 50000, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)        # > 2^31 pixels
     assert rc != 0 and 'tile the image' in msg
     rc, msg = plan_error(16, 24, 24, 64, 62, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)              # stride < channels
     assert rc != 0 and 'Cin_s' in msg

@@ -1024,6 +1024,170 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WMulti mp) {
 }
 
 // ---------------------------------------------------------------------------
+// fp32 weight gradient with LDS-DMA staging (round 4).  wgrad_kernel<0> moves every chunk global -> registers (four stages
+// of 16 VGPRs) -> ds_write_b128 -> LDS and spends 61 % of its wave time in s_waitcnt at 66 % MFMA-busy
+// (profiles/r03_pmc_wgrad.txt).  Both operands are "row r0 = tid / 16, quad tid % 16" images of [32 rows][64 floats]: byte
+// 16 * tid of the chunk buffer, i.e. lane-linear -- so buffer_load_dwordx4 ... lds can land them in LDS directly (per-lane
+// SOURCE address = the gather; rows past the split and padding taps are pointed out of range and arrive as zeros), with no
+// staging registers, no LDS stores and a ring of three chunk buffers: chunk c + 2 is requested while chunk c is multiplied,
+// and the only wait in the loop is a counted vmcnt that leaves the newest chunk's four requests in flight.
+// Same work decomposition, slab layout and bias rows as wgrad_kernel<0>: the reduction kernel is shared.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WMulti mp) {
+  const WArgs& a = mp.a;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  int wi;
+  {  // XCD-contiguous work order (see wgrad_kernel)
+    const int W = (int)gridDim.x, b = (int)blockIdx.x, xcd = b & 7, slot = b >> 3, q = W >> 3, r = W & 7;
+    wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tiles_ = a.ktiles * (a.Cnw / 64);
+  const int tile_id = wi % tiles_, rest_ = wi / tiles_;
+  const int prob = srx_uniform(rest_ % a.nprob), zsplit = srx_uniform(rest_ / a.nprob);
+  constexpr int NSLOT = 3, CHUNK = 32 * 64;  // floats per operand and chunk
+  __shared__ __attribute__((aligned(16))) float sD[NSLOT][CHUNK];
+  __shared__ __attribute__((aligned(16))) float sX[NSLOT][CHUNK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
+  const int ntile = srx_uniform(tile_id / a.ktiles), kt = srx_uniform(tile_id - ntile * a.ktiles);
+  const int k0 = kt * 64, n0 = ntile * 64;
+  const int q = tid & 15, r0 = tid >> 4;
+  auto make_rsrc = [](const void* p, unsigned bytes) {
+    const unsigned long long v = (unsigned long long)p;
+    u32x4 r;
+    r[0] = (unsigned)srx_uniform((int)(unsigned)v);
+    r[1] = (unsigned)srx_uniform((int)((unsigned)(v >> 32) & 0xffffu));
+    r[2] = bytes;
+    r[3] = 0x00020000u;
+    return r;
+  };
+  const u32x4 rx_ = make_rsrc(mp.x[prob], a.in_bytes), rd_ = make_rsrc(mp.dy[prob], a.dy_bytes);
+
+  // this thread's fixed k (A gather) and fixed dy column
+  const int k = k0 + 4 * q;
+  const bool kvalid = k < a.K;
+  int dh = 0, dw = 0, kc = 0;
+  if (kvalid) {
+    const int tap = k / a.Ck;
+    kc = k - tap * a.Ck;
+    const int th = tap / a.ntw, tw = tap - th * a.ntw;
+    dh = a.dh0 + th;
+    dw = a.dw0 + tw;
+  }
+  const int col = n0 + 4 * q;
+  const bool cvalid = col < a.Cdv;
+  int sh_i = 0, sh_j = 0, sh_c = col;
+  if (a.dy_shuffle) {
+    const int ij = col / a.dy_shuffle;
+    sh_c = col - ij * a.dy_shuffle;
+    sh_i = ij >> 1;
+    sh_j = ij & 1;
+  }
+  const int mbeg = zsplit * a.rows_per_split;
+  const int mend = min(a.M, mbeg + a.rows_per_split);
+
+  // row state of this thread's two rows (r0 + 16 p of the current chunk), advanced by one chunk per request
+  int rm[2], rmh[2], rmw[2];
+  unsigned rox[2], rod[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int m = mbeg + r0 + 16 * p;
+    int n, rem, mh, mw;
+    srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
+    srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
+    rm[p] = m; rmh[p] = mh; rmw[p] = mw;
+    rox[p] = (unsigned)(((n * a.Hi + mh * a.in_stride + dh) * a.Wi + mw * a.in_stride + dw) * a.Ci + kc);
+    rod[p] = (unsigned)(a.dy_shuffle ? ((n * 2 * a.Hm + 2 * mh + sh_i) * (2 * a.Wm) + 2 * mw + sh_j) * a.Cd + sh_c
+                                     : m * a.Cd + col);
+  }
+  const unsigned ldsX = (unsigned)(size_t)&sX[0][0], ldsD = (unsigned)(size_t)&sD[0][0];
+  auto dma = [&](const u32x4& rs, unsigned voff, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs) : "memory");
+  };
+  // four requests per wave and chunk, always (so that the waits can be counted): the thread's 16 bytes of row r0 + 16 p land at
+  // byte 16 tid + 4096 p of the slot
+  auto request = [&](int slot) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const bool valid = rm[p] < mend;
+      const int ih = rmh[p] * a.in_stride + dh, iw = rmw[p] * a.in_stride + dw;
+      const bool okx = valid && kvalid && ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
+      const unsigned dst = (unsigned)srx_uniform((int)((unsigned)(slot * CHUNK * 4) + (unsigned)(p * 4096 + wave * 1024)));
+      dma(rx_, okx ? 4u * rox[p] : 0xffffffffu, ldsX + dst);
+      dma(rd_, (valid && cvalid) ? 4u * rod[p] : 0xffffffffu, ldsD + dst);
+      rm[p] += 32; rmw[p] += a.s_c; rmh[p] += a.s_rm; rox[p] += (unsigned)a.dX0; rod[p] += (unsigned)a.dD0;
+      const bool wc = rmw[p] >= a.Wm;
+      rmw[p] -= wc ? a.Wm : 0; rmh[p] += wc ? 1 : 0;
+      rox[p] += wc ? (unsigned)a.dX1 : 0u; rod[p] += wc ? (unsigned)a.dD1 : 0u;
+      const bool wr = rmh[p] >= a.Hm;
+      rmh[p] -= wr ? a.Hm : 0;
+      rox[p] += wr ? (unsigned)a.dX2 : 0u;
+    }
+  };
+  const bool want_bias = a.bslab != nullptr && kt == 0;  // workgroup-uniform
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wn = wave >> 1, wk = wave & 1;
+  auto compute = [&](int slot) {
+    const float* cD = &sD[0][0] + slot * CHUNK + h * 64 + wn * 32 + l31;
+    const float* cX = &sX[0][0] + slot * CHUNK + h * 64 + wk * 32 + l31;
+    if (want_bias) {  // (fp32 values of this thread's two dy quads, as wgrad_kernel<0> adds them)
+      const float* bd = &sD[0][0] + slot * CHUNK + r0 * 64 + q * 4;
+      bsum += *reinterpret_cast<const f32x4*>(bd) + *reinterpret_cast<const f32x4*>(bd + 16 * 64);
+    }
+    float dv[16], xv[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { dv[s] = cD[s * 128]; xv[s] = cX[s * 128]; }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[s], xv[s], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+  };
+  const int nchunks = (mend - mbeg + 31) / 32;
+  request(0);
+  request(1);  // (past the split's end: every lane out of range, zeros land -- never multiplied)
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // chunk 0 has landed, chunk 1 flies on
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  int slot = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    int s2 = slot + 2; s2 = s2 >= NSLOT ? s2 - NSLOT : s2;
+    request(s2);    // chunk c + 2 into the slot chunk c - 1 was read from (free since the barrier)
+    compute(slot);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // chunk c + 1 has landed; the four requests of chunk c + 2 fly on
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    slot = slot + 1 == NSLOT ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the trailing requests write LDS: land before the slots are reused below)
+  const size_t slab_id = (size_t)prob * a.nsplit + zsplit;
+  float* slab = a.slab + slab_id * a.Cnw * a.Kw;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    slab[(size_t)row * a.Kw + k0 + wk * 32 + l31] = acc[r];
+  }
+  if (want_bias) {  // 16 row lanes x 16 column quads -> 64 column sums of this row split
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(&sD[0][0]);
+    red[r0 * 16 + q] = bsum;
+    __syncthreads();
+    if (tid < 16) {
+      f32x4 t = red[tid];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) t += red[r * 16 + tid];
+      *reinterpret_cast<f32x4*>(a.bslab + slab_id * a.Cnw + n0 + 4 * tid) = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // bf16 weight gradient of 3x3 / stride 1 / pad 1 convs with 64 output columns, on WHOLE IMAGE ROWS (round 3).
 // wgrad_kernel above gathers one (tap, channel) k-tile per workgroup: every tap re-reads the same x pixels and every k-tile
 // re-reads the dy tile -- 16 FLOP per byte pulled through the L2s, and with bf16 MFMAs (16x the fp32 rate) ESRGAN's 207
@@ -2427,7 +2591,8 @@ static int wgrad_multi_impl(const srx_conv2d_t* d, int nprob, int per_out, const
   if (srx_prof_on())
     snprintf(nm, sizeof(nm), "wgrad_kernel<%d> MxNxK=%dx%dx%d x%d", d->precision ? 1 : 0, a.M, d->Cout, a.K, nprob);
   if (d->precision) SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<1>, grid, dim3(256), 0, st, mp);
-  else SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<0>, grid, dim3(256), 0, st, mp);
+  else if (srx_dev().no_wgrad_dma) SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<0>, grid, dim3(256), 0, st, mp);
+  else SRX_LAUNCH_PROF(nm, wfl, wgrad_dma_kernel, grid, dim3(256), 0, st, mp);
   SRX_CHECK_LAUNCH("wgrad_kernel");
   }
   const int64_t n = (int64_t)d->Cout * g.K;
