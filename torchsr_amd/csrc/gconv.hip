@@ -1212,7 +1212,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_bf16_kernel(const WMulti mp) {
   constexpr int XPS = 64, XROW = (WPX + 2) * XPS;  // window: bytes per pixel (32 channels), per row (one zero pixel each side)
   constexpr int DPS = 192, DROW = WPX * DPS;       // dy: bytes per pixel (64 columns + pad: see wgrad_kernel), per row
   constexpr int XR = (WPX * 8 + 255) / 256, DR = (WPX * 16 + 255) / 256, KS = WPX / 16;
-  __shared__ __attribute__((aligned(16))) unsigned char sX[4 * XROW];
+  __shared__ __attribute__((aligned(16))) unsigned char sX[5 * XROW];  // four window slots + a row of zeros (slot 4)
   __shared__ __attribute__((aligned(16))) unsigned char sD[2 * DROW > 4096 ? 2 * DROW : 4096];
   const int groups = a.Ck >> 5;
   int wi;
@@ -1288,8 +1288,11 @@ __global__ __launch_bounds__(256) void wgrad_rows_bf16_kernel(const WMulti mp) {
       for (int ti = 0; ti < NT; ++ti) {
         constexpr int dummy = 0; (void)dummy;
         const int t = T0 + ti, ty = t / 3 - 1, tx = t % 3 - 1;
-        if ((unsigned)(ih + ty) >= (unsigned)a.Hi) continue;  // (wave-uniform) the row above / below lies outside the image
-        const unsigned char* xb = sX + ((gr + ty) & 3) * XROW + (16 * s + 8 * h + rq + tx + 1) * XPS + 2 * colh;
+        // (wave-uniform) the row above / below lies outside the image: the tap multiplies the row of zeros.  Branch-free on
+        // purpose -- with a `continue` here hipcc kept the five accumulators in different AGPRs on the two paths and moved
+        // them at every join (16 v_accvgpr_mov per accumulator and row: 20 VALU instructions per MFMA, profiles/r04_pmc_esrgan.txt)
+        const int slot = (unsigned)(ih + ty) < (unsigned)a.Hi ? ((gr + ty) & 3) : 4;
+        const unsigned char* xb = sX + slot * XROW + (16 * s + 8 * h + rq + tx + 1) * XPS + 2 * colh;
         const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(xb));
         const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(xb + 4 * XPS));
         const s16x8 fx = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
@@ -1298,7 +1301,8 @@ __global__ __launch_bounds__(256) void wgrad_rows_bf16_kernel(const WMulti mp) {
     }
   };
 
-  // zero columns left and right of every window slot
+  // the row of zeros; zero columns left and right of every window slot
+  if (tid < XROW / 16) *reinterpret_cast<f32x4*>(sX + 4 * XROW + 16 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
   if (tid < 32) {
     const int slot = tid >> 3, side = (tid >> 2) & 1, part = tid & 3;
     *reinterpret_cast<f32x4*>(sX + slot * XROW + (side ? (WPX + 1) * XPS : 0) + 16 * part) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1314,15 +1318,20 @@ __global__ __launch_bounds__(256) void wgrad_rows_bf16_kernel(const WMulti mp) {
   dstore(rbeg, da);
   xload(rbeg + 2, xa);
   dload(rbeg + 1, da);
-  for (int gr = rbeg; gr < rend; ++gr) {
-    __syncthreads();  // rows gr - 1 .. gr + 1 and dy row gr are in LDS; the slots of x row gr - 2 and dy row gr - 1 are free
-    xstore(gr + 2, xa);
-    dstore(gr + 1, da);
-    xload(gr + 3, xa);
-    dload(gr + 2, da);
-    if (th == 0) compute(gr, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
-    else compute(gr, std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
-  }
+  // one copy of the row loop per tap range (th is wave-uniform): with the choice INSIDE the loop the two paths kept the
+  // accumulators in different AGPRs and every row paid 80 v_accvgpr_mov to bring them back together
+  auto rows = [&](auto t0_c, auto nt_c) {
+    for (int gr = rbeg; gr < rend; ++gr) {
+      __syncthreads();  // rows gr - 1 .. gr + 1 and dy row gr are in LDS; the slots of x row gr - 2 and dy row gr - 1 are free
+      xstore(gr + 2, xa);
+      dstore(gr + 1, da);
+      xload(gr + 3, xa);
+      dload(gr + 2, da);
+      compute(gr, t0_c, nt_c);
+    }
+  };
+  if (th == 0) rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+  else rows(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
   const size_t slab_id = (size_t)prob * a.nsplit + zsplit;
   float* slab = a.slab + slab_id * a.Cnw * a.Kw;
 #pragma unroll
