@@ -42,6 +42,33 @@ def chain():
                   bufs[(i + 1) % 4].data_ptr(), 192, s)
 
 
+if len(sys.argv) > 1 and sys.argv[1] == 'stamps':
+    # in-kernel clock stamps (developer entry point, bound here only): where a block's 25 us go, per weight unit
+    import numpy as np
+    fn = L.srx_rdb_fwd_dbg
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    dbg = torch.zeros(256 * 8 * 48, dtype=torch.int32, device=dev)
+    for i in range(6):
+        rc = fn(n, h, w, bufs[i % 4].data_ptr(), 192, pk.data_ptr() + i * per, biases, 0.2, 0.2, bufs[(i + 1) % 4].data_ptr(), 192, s, dbg.data_ptr())
+        assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    d = (dbg.view(256, 8, 48).cpu().numpy().astype('int64') & 0xffffffff)
+    t0 = d[:, :, 0].min(axis=1, keepdims=True)[:, :, None]
+    d = (d - t0) & 0xffffffff
+    comp, load = d[:, :4, :], d[:, 4:, :]
+    print('stamps in s_memtime ticks (100 MHz -> 10 ns each), mean over the 256 workgroups')
+    print('patch staged at %.0f (compute waves), %.0f (loader waves); block ends at %.0f' % (comp[:, :, 1].mean(), load[:, :, 1].mean(), comp[:, :, 41].max(axis=1).mean()))
+    print('unit conv  open  | compute waves: work mean / max wave, wait at next barrier | loader: issue+wait')
+    for u in range(20):
+        conv = 1 if u < 2 else 2 if u < 5 else 3 if u < 9 else 4 if u < 14 else 5
+        opened = comp[:, :, 2 + 2 * u].mean()
+        work = comp[:, :, 3 + 2 * u] - comp[:, :, 2 + 2 * u]
+        nxt = (comp[:, :, 4 + 2 * u] - comp[:, :, 3 + 2 * u]) if u < 19 else np.zeros_like(work)
+        lw = load[:, :, 3 + 2 * u] - load[:, :, 2 + 2 * u]
+        print('%4d %4d %6.0f | %6.1f / %6.1f   %6.1f | %6.1f' % (u, conv, opened, work.mean(), work.max(axis=1).mean(), nxt.mean(), lw.mean()))
+    sys.exit(0)
+
 gf = 2.0 * n * h * w * 9 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64) / 1e9
 for name, fn in (('rdb_fwd', chain), ('rdb_bwd', chain_bwd)):
     fn()

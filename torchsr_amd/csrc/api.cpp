@@ -43,7 +43,6 @@ static SrxDevSwitches read_switches() {
   s.no_bn_fwd_fuse = flag("SRX_NO_BN_FWD_FUSE");
   s.no_first3 = flag("SRX_NO_FIRST3");
   s.no_c64 = flag("SRX_NO_C64");
-  s.rdb_no_dma = flag("SRX_RDB_NO_DMA");
   s.no_wgrad_dma = flag("SRX_NO_WGRAD_DMA");
   s.wgrad_nsplit = num("SRX_WGRAD_NSPLIT");
   s.wgrad_rows_nsplit = num("SRX_WGRAD_ROWS_NSPLIT");

@@ -12,8 +12,8 @@
 //     10x10): 84 KB in all.  Halo pixels are recomputed by the neighbouring tiles (1.77x the FLOPs, at a few per cent
 //     of the bf16 MFMA peak that is free); pixels outside the image are stored as the zeros the next conv's padding reads.
 //   * weights come as bf16 tiles pre-swizzled for the LDS image (srx_rdb_pack, once per optimiser step for all blocks):
-//     one unit = one 32-channel source x 9 taps x all output channels (18 / 36 KB).  Waves 4..7 stream them: unit u + 1
-//     goes global -> registers -> the other LDS slot while unit u is multiplied; ONE barrier per unit, 20 units per block.
+//     one unit = one 32-channel source x 9 taps x all output channels (18 / 36 KB).  Waves 4..7 stream them by LDS-DMA into
+//     a ring of four 18 KB slots, three units ahead (conv 5's 36 KB units: one ahead); ONE barrier per unit, 20 units per block.
 //   * waves 0..3 (one per SIMD) multiply: a wave owns up to two 32-pixel x 32-channel output tiles of the current conv and
 //     reads every weight fragment once for both; fragments are requested two taps ahead, reads and address arithmetic
 //     interleaved with the MFMAs (sched_group_barrier).  Operands are (weights as A, pixels as B) so that a lane ends
@@ -60,9 +60,16 @@ __host__ __device__ constexpr int unit_off(int u) {
   return o;
 }
 constexpr int PACKED_BYTES = unit_off(NUNITS);  // 479232 per block
-constexpr int SLOT_BYTES = 9 * 64 * 64;         // 36864: the largest unit
+constexpr int SLOT_BYTES = 9 * 32 * 64;         // 18432: a unit of conv 1..4; conv 5's units (64 outputs) take two slots
+constexpr int NSLOT = 4;
 constexpr int OFF_W = ACT_BYTES;
-constexpr int OFF_BIAS = OFF_W + 2 * SLOT_BYTES;
+constexpr int OFF_BIAS = OFF_W + NSLOT * SLOT_BYTES;
+// The weight ring (round 4, second step): four 18 KB slots.  A unit of conv 1..4 sits in slot u % 4 and is requested THREE
+// units before it is multiplied (at the barrier that opens unit u - 3 the slot's previous tenant, unit u - 4, has just been
+// finished); conv 5's 36 KB units alternate between the slot pairs {2,3} and {0,1} and stay one unit ahead, as before.  With
+// one unit ahead every barrier waited for an L2 round trip of the weight stream (~0.55 us x 20; the MFMAs of a small unit
+// take 0.27-0.55 us).
+__host__ __device__ constexpr int unit_slot(int u) { return u < 14 ? u % NSLOT : ((u & 1) ? 0 : 2); }
 constexpr int LDS_BYTES = OFF_BIAS + 192 * 4;   // 160512
 constexpr int NTHREADS = 512;
 
@@ -88,40 +95,36 @@ struct RdbArgs {
   float* out;            // [N][H][W][out_ld], channels 0..63
   int N, H, W, ld, bld, gld, skip_ld, extra_ld, out_ld, tiles_x, tiles_y;
   float scale, slope, skip_scale, post_scale;
-  int dma;
+  unsigned* dbg;  // developer aid (srx_rdb_fwd_dbg): [workgroup][wave][48] shader-clock stamps, staged in LDS behind LDS_BYTES; null in the product
 };
+constexpr int DBG_SLOTS = 48;
+// stamp `idx` of this wave: 0 kernel start, 1 patch staged, 2 + 2U unit U's barrier passed, 3 + 2U unit U's work done
+__device__ __forceinline__ void rdb_stamp(const RdbArgs& a, unsigned char* lds, int wave, int lane, int idx) {
+  if (a.dbg && lane == 0) reinterpret_cast<unsigned*>(lds + LDS_BYTES)[wave * DBG_SLOTS + idx] = (unsigned)__builtin_amdgcn_s_memtime();
+}
 
 // Roles.  Waves 0..3 (one per SIMD) multiply: a wave owns up to two 32-pixel tiles of the current conv's region and reads
 // every weight fragment once for both (LDS traffic is what bounds this kernel: 3 fragment reads per 2 MFMAs instead of 4).
 // Waves 4..7 stream the weights: unit u + 1 goes global -> registers -> the other LDS slot while unit u is multiplied.
 constexpr int NCOMPUTE = 4, NLOAD_THREADS = NTHREADS - NCOMPUTE * 64;
-constexpr int MAX_ROUNDS = (SLOT_BYTES / 16 + NLOAD_THREADS - 1) / NLOAD_THREADS;  // 9
 
 struct Wave {
   f32x16 acc[2];
   int lane, h, l31, wave;
   int n_img, ty0, tx0;
-  bool dma;  // weights by LDS-DMA (round 4); false: through registers (developer switch SRX_RDB_NO_DMA, A/B runs)
 };
 
-// Every loader thread issues the same number of loads per unit (the last round re-reads the unit's final chunk where
-// a thread has nothing left to fetch): a predicated load would be waited for on the spot.
-template <int U>
-__device__ __forceinline__ void load_unit(const RdbArgs& a, int lt, f32x4 (&wr)[MAX_ROUNDS]) {
-  constexpr int chunks = unit_bytes(U) / 16, rounds = (chunks + NLOAD_THREADS - 1) / NLOAD_THREADS;
-  const f32x4* src = reinterpret_cast<const f32x4*>(a.wpk + unit_off(U));
-#pragma unroll
-  for (int i = 0; i < rounds; ++i) wr[i] = src[min(i * NLOAD_THREADS + lt, chunks - 1)];
-}
-// Round 4: the same stream by LDS-DMA (buffer_load_dwordx4 ... lds).  The packed units are already the LDS image, so the
-// copy is lane-linear: one instruction moves 1 KiB, nothing passes through registers and no ds_write is issued -- the nine
-// 16-byte LDS stores per loader thread and unit competed with the compute waves' fragment reads for the LDS and with their
-// MFMAs for the SIMD's issue slots.  Lanes past the unit's end read 0 through the descriptor's range check and land in the
-// slack of the (36 KB) slot.
+// Round 4: the weight stream by LDS-DMA (buffer_load_dwordx4 ... lds).  The packed units are already the LDS image, so the
+// copy is lane-linear: one instruction of one wave moves 1 KiB, nothing passes through registers and no ds_write is issued --
+// the nine 16-byte LDS stores per loader thread and unit competed with the compute waves' fragment reads for the LDS and with
+// their MFMAs for the SIMD's issue slots.  A unit is a whole number of KiB (18 or 36): KiB j goes to loader wave j % 4, so a
+// wave issues dma_count(U, wave) instructions per unit -- the counted vmcnt waits below depend on it -- and no lane ever
+// writes past the unit's end (the next slot may hold a live unit).
 typedef unsigned rdb_u32x4 __attribute__((ext_vector_type(4)));
+__host__ __device__ constexpr int dma_count(int u, int wave_l) { return (unit_bytes(u) / 1024 - wave_l + 3) / 4; }
 template <int U>
 __device__ __forceinline__ void dma_unit(const RdbArgs& a, unsigned lds_base, int lt) {
-  constexpr int chunks = unit_bytes(U) / 16, rounds = (chunks + NLOAD_THREADS - 1) / NLOAD_THREADS;
+  constexpr int kib = unit_bytes(U) / 1024, rounds = (kib + 3) / 4;
   const unsigned long long p = (unsigned long long)(a.wpk + unit_off(U));
   rdb_u32x4 rs;
   rs[0] = (unsigned)srx_uniform((int)(unsigned)p);
@@ -131,24 +134,25 @@ __device__ __forceinline__ void dma_unit(const RdbArgs& a, unsigned lds_base, in
   const unsigned wave_l = (unsigned)srx_uniform(lt >> 6);
 #pragma unroll
   for (int i = 0; i < rounds; ++i) {
-    const unsigned dst = (unsigned)srx_uniform((int)(lds_base + (unsigned)(OFF_W + (U & 1) * SLOT_BYTES) + (unsigned)(i * NLOAD_THREADS) * 16u + wave_l * 1024u));
+    if ((i + 1) * 4 > kib && i * 4 + (int)wave_l >= kib) continue;  // (wave-uniform; last round of an 18 KiB unit: waves 0, 1 only)
+    const unsigned dst = (unsigned)srx_uniform((int)(lds_base + (unsigned)(OFF_W + unit_slot(U) * SLOT_BYTES) + (unsigned)(i * 4) * 1024u + wave_l * 1024u));
     const unsigned voff = (unsigned)(i * NLOAD_THREADS + lt) * 16u;
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs) : "memory");
   }
 }
+// the loader waves' wait: every request has landed except the newest `units_18k` 18 KiB units / `units_36k` 36 KiB units
+// (requests retire in issue order; the loader waves issue no other vector memory instruction)
+template <int UNITS_18K, int UNITS_36K>
+__device__ __forceinline__ void dma_wait(int wave_l) {
+  constexpr int HI = UNITS_18K * dma_count(0, 0) + UNITS_36K * dma_count(14, 0), LO = UNITS_18K * dma_count(0, 3) + UNITS_36K * dma_count(14, 3);
+  if (wave_l < 2) __builtin_amdgcn_s_waitcnt(0x0f70 | (HI & 15) | ((HI >> 4) << 14));  // vmcnt(HI), expcnt / lgkmcnt untouched
+  else __builtin_amdgcn_s_waitcnt(0x0f70 | (LO & 15) | ((LO >> 4) << 14));
+}
+
 // workgroup barrier that orders LDS traffic only (see c64.hip): the compute waves' global stores of c1..c4 / g4..g1 fly on
 __device__ __forceinline__ void rdb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int U>
-__device__ __forceinline__ void store_unit(unsigned char* lds, int lt, const f32x4 (&wr)[MAX_ROUNDS]) {
-  constexpr int chunks = unit_bytes(U) / 16, rounds = (chunks + NLOAD_THREADS - 1) / NLOAD_THREADS;
-  f32x4* dst = reinterpret_cast<f32x4*>(lds + OFF_W + (U & 1) * SLOT_BYTES);
-#pragma unroll
-  for (int i = 0; i < rounds; ++i)
-    if ((i + 1) * NLOAD_THREADS <= chunks || i * NLOAD_THREADS + lt < chunks) dst[i * NLOAD_THREADS + lt] = wr[i];
-}
 
 // conv K: pixel tiles of 32, channel tiles of 32; a compute wave takes TPW consecutive pixel tiles of one channel tile
 template <int K> __host__ __device__ constexpr int m_tiles() { return (reg_w(K) * reg_w(K) + 31) / 32; }
@@ -178,7 +182,7 @@ __device__ __forceinline__ void mma_unit(const unsigned char* lds, Wave& w) {
     bp[i] = (qy + D) * WS + qx + D;
   }
   const int nrow = nt * 32 + w.l31;
-  const unsigned char* wrow = lds + OFF_W + (U & 1) * SLOT_BYTES + nrow * 64;
+  const unsigned char* wrow = lds + OFF_W + unit_slot(U) * SLOT_BYTES + nrow * 64;
   const int wsw = (nrow >> 2) & 3;
   const unsigned char* act = lds + src_off(S);
   // fragments of tap t + 2 are requested before tap t is multiplied: the wave is alone on its SIMD and an LDS read
@@ -344,18 +348,19 @@ template <int U, bool BWD>
 __device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, Wave& w, int tid, f32x4 (&xs)[4],
                                           f32x4 (&ex)[4]) {
   constexpr int K = unit_conv(U), S = U - unit_first(K);
-  // unit U's weights (and, for S == 0, the previous conv's output image) are in LDS; slot (U+1)&1 is free
-  if (w.dma) rdb_lds_barrier(); else __syncthreads();
+  // unit U's weights (and, for S == 0, the previous conv's output image) are in LDS; unit U - 1's slot is free
+  rdb_lds_barrier();
+  rdb_stamp(a, lds, w.wave, w.lane, 2 + 2 * U);
   if (w.wave >= NCOMPUTE) {
+    const int lt = tid - NCOMPUTE * 64, wl = srx_uniform(lt >> 6);
+    constexpr int NEXT = U <= 10 ? U + 3 : (U == 12 ? 14 : (U >= 14 && U + 1 < NUNITS ? U + 1 : -1));  // the request this barrier frees a slot for
+    if constexpr (NEXT >= 0) dma_unit<NEXT>(a, (unsigned)(size_t)lds, lt);
+    // unit U + 1 has landed before the next barrier; what was requested after it flies on
     if constexpr (U + 1 < NUNITS) {
-      if (w.dma) {
-        dma_unit<U + 1>(a, (unsigned)(size_t)lds, tid - NCOMPUTE * 64);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // landed before the next barrier (this wave has nothing else to do)
-      } else {
-        f32x4 wr[MAX_ROUNDS];
-        load_unit<U + 1>(a, tid - NCOMPUTE * 64, wr);
-        store_unit<U + 1>(lds, tid - NCOMPUTE * 64, wr);
-      }
+      if constexpr (U <= 10) dma_wait<2, 0>(wl);        // units U + 2, U + 3
+      else if constexpr (U == 11) dma_wait<1, 0>(wl);   // unit 13
+      else if constexpr (U == 12) dma_wait<0, 1>(wl);   // unit 14
+      else dma_wait<0, 0>(wl);
     }
   } else {
     if (S == 0) {
@@ -373,6 +378,7 @@ __device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, 
       else epilogue_out<BWD>(a, lds, w, xs, ex);
     }
   }
+  rdb_stamp(a, lds, w.wave, w.lane, 3 + 2 * U);
   if constexpr (U + 1 < NUNITS) run_units<U + 1, BWD>(a, lds, w, tid, xs, ex);
 }
 
@@ -387,16 +393,12 @@ __global__ __launch_bounds__(NTHREADS) void rdb_kernel(const RdbArgs a) {
   const int ty = b % a.tiles_y;
   w.n_img = b / a.tiles_y; w.ty0 = ty * RT; w.tx0 = tx * RT;
 
-  w.dma = a.dma != 0;
-  if (w.wave >= NCOMPUTE) {  // the first weight unit
-    if (w.dma) {
-      dma_unit<0>(a, (unsigned)(size_t)lds, tid - NCOMPUTE * 64);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      f32x4 wr[MAX_ROUNDS];
-      load_unit<0>(a, tid - NCOMPUTE * 64, wr);
-      store_unit<0>(lds, tid - NCOMPUTE * 64, wr);
-    }
+  rdb_stamp(a, lds, w.wave, w.lane, 0);
+  if (w.wave >= NCOMPUTE) {  // the first three weight units
+    const int lt = tid - NCOMPUTE * 64;
+    dma_unit<0>(a, (unsigned)(size_t)lds, lt);
+    dma_unit<1>(a, (unsigned)(size_t)lds, lt);
+    dma_unit<2>(a, (unsigned)(size_t)lds, lt);
   }
   // the input patch, rounded to bf16 once: 324 pixels x 8 groups of 8 channels; every load is issued before the first
   // conversion (out-of-image pixels read a clamped address and are zeroed afterwards)
@@ -435,8 +437,12 @@ __global__ __launch_bounds__(NTHREADS) void rdb_kernel(const RdbArgs a) {
       reinterpret_cast<float*>(lds + OFF_BIAS)[tid] = a.bias[k][tid < 128 ? (tid & 31) : tid - 128];
     }
   }
+  if (w.wave >= NCOMPUTE) dma_wait<2, 0>(srx_uniform((tid - NCOMPUTE * 64) >> 6));  // unit 0 has landed (units 1, 2 may fly on)
+  rdb_stamp(a, lds, w.wave, w.lane, 1);
   f32x4 xs[4], ex[4];
   run_units<0, BWD>(a, lds, w, tid, xs, ex);
+  if (a.dbg && w.lane < DBG_SLOTS)  // (each wave copies the stamps its own lane 0 wrote)
+    a.dbg[((size_t)blockIdx.x * 8 + w.wave) * DBG_SLOTS + w.lane] = reinterpret_cast<const unsigned*>(lds + LDS_BYTES)[w.wave * DBG_SLOTS + w.lane];
 }
 
 // OIHW fp32 weights of every block's five convs -> the bf16 unit streams rdb_kernel reads.  One thread per (row, 8 channels)
@@ -515,7 +521,6 @@ extern "C" int srx_rdb_pack_bwd(const float* const* w_table_dev, int nblk, void*
 template <bool BWD>
 static int rdb_launch(RdbArgs& a, const char* what, void* stream) {
   a.tiles_x = (int)srx_cdiv(a.W, RT); a.tiles_y = (int)srx_cdiv(a.H, RT);
-  a.dma = srx_dev().rdb_no_dma ? 0 : 1;
   const int64_t grid = (int64_t)a.N * a.tiles_x * a.tiles_y;
   SRX_REQUIRE(grid < (1LL << 31), "%s: grid too large", what);
   static std::once_flag once;
@@ -527,7 +532,7 @@ static int rdb_launch(RdbArgs& a, const char* what, void* stream) {
   const double fl = 2.0 * a.N * a.H * a.W * 9.0 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64);
   char nm[112];
   if (srx_prof_on()) snprintf(nm, sizeof(nm), "rdb_kernel<%d> MxNxK=%dx192x(576..1728)", BWD ? 1 : 0, a.N * a.H * a.W);
-  SRX_LAUNCH_PROF(nm, fl, rdb_kernel<BWD>, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES, srx_stream(stream), a);
+  SRX_LAUNCH_PROF(nm, fl, rdb_kernel<BWD>, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES + (a.dbg ? 8 * DBG_SLOTS * 4 : 0), srx_stream(stream), a);
   SRX_CHECK_LAUNCH(what);
   return SRX_OK;
 }
@@ -552,6 +557,19 @@ extern "C" int srx_rdb_fwd(int N, int H, int W, float* buf, int ld, const void* 
   a.N = N; a.H = H; a.W = W; a.ld = ld; a.bld = ld; a.out_ld = out_ld;
   a.scale = scale; a.slope = slope; a.post_scale = post_scale; a.extra = extra; a.extra_ld = extra_ld;
   return rdb_launch<false>(a, "rdb_fwd", stream);
+}
+
+// Developer aid (tools/bench_rdb.py stamps): srx_rdb_fwd with in-kernel clock stamps, dbg: [workgroups][8 waves][48] unsigned
+extern "C" int srx_rdb_fwd_dbg(int N, int H, int W, float* buf, int ld, const void* wpk, const float* const* bias5, float scale,
+                               float slope, float* out, int out_ld, void* stream, unsigned* dbg) {
+  SRX_REQUIRE(buf && wpk && bias5 && out && dbg && out != buf && N > 0 && H > 0 && W > 0 && ld >= 192 && out_ld >= 64, "rdb_fwd_dbg: bad argument");
+  RdbArgs a{};
+  a.src = buf; a.buf = buf; a.wpk = reinterpret_cast<const unsigned char*>(wpk); a.out = out;
+  for (int k = 0; k < 5; ++k) a.bias[k] = bias5[k];
+  a.N = N; a.H = H; a.W = W; a.ld = ld; a.bld = ld; a.out_ld = out_ld;
+  a.scale = scale; a.slope = slope; a.post_scale = 1.f;
+  a.dbg = dbg;
+  return rdb_launch<false>(a, "rdb_fwd_dbg", stream);
 }
 
 extern "C" int srx_rdb_bwd(int N, int H, int W, const float* dy, int dy_ld, float scale, const float* buf, int ld,
