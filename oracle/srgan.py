@@ -74,7 +74,7 @@ class _ConvBF16(torch.autograd.Function):
         stride, pad, has_b = ctx.cfg
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            exact = stride != 1 or ctx.thin_in
+            exact = ctx.thin_in  # (round 4: the strided data gradients multiply bf16 operands too)
             dx = torch.nn.grad.conv2d_input(x.shape, w if exact else _r(w), dy if exact else _r(dy), stride=stride, padding=pad)
         if ctx.needs_input_grad[1]:
             exact = ctx.thin_in or ctx.thin_out

@@ -659,12 +659,12 @@ struct GMulti {
   int first[5];  // first[i] = first workgroup of problem i; first[n] = grid size
   GArgs g[4];
 };
-template <int BM, int BN, int WM, int WN, int XR>
+template <int BM, int BN, int WM, int WN, int XR, int PR = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_multi_kernel(const GMulti m) {
   int ci = 0;
   while (ci + 1 < m.n && (int)blockIdx.x >= m.first[ci + 1]) ++ci;
   const GArgs a = m.g[ci];
-  gconv_body<BM, BN, WM, WN, 1, XR, 0>(a, blockIdx.x - m.first[ci]);
+  gconv_body<BM, BN, WM, WN, 1, XR, PR>(a, blockIdx.x - m.first[ci]);
 }
 
 // finishes the K-split tail tiles: out = act(sum_z partial[z] + bias) and, when asked, the tile's
@@ -1691,20 +1691,20 @@ int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
   return SRX_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int XR>
+template <int BM, int BN, int WM, int WN, int XR, int PR = 0>
 int launch_gconv_multi(const GMulti& m, size_t lds, hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_multi_kernel<BM, BN, WM, WN, XR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_multi_kernel<BM, BN, WM, WN, XR, PR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   char nm[64];
   double fl = 0.0;
   if (srx_prof_on()) {
-    snprintf(nm, sizeof(nm), "gconv_multi_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, XR);
+    snprintf(nm, sizeof(nm), "gconv_multi_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, XR, PR);
     for (int i = 0; i < m.n; ++i) fl += 2.0 * m.g[i].M * m.g[i].Cn * m.g[i].K;
   }
-  SRX_LAUNCH_PROF(nm, fl, (gconv_multi_kernel<BM, BN, WM, WN, XR>), dim3(m.first[m.n]), dim3((BM / WM) * (BN / WN) * 64),
+  SRX_LAUNCH_PROF(nm, fl, (gconv_multi_kernel<BM, BN, WM, WN, XR, PR>), dim3(m.first[m.n]), dim3((BM / WM) * (BN / WN) * 64),
                   lds, st, m);
   SRX_CHECK_LAUNCH("gconv_multi_kernel");
   return SRX_OK;
@@ -1714,7 +1714,7 @@ int launch_gconv_multi(const GMulti& m, size_t lds, hipStream_t st) {
 // 1x..4x different K, and their strided outputs cannot take the split-K fix-up path, so balance comes
 // from the tile size alone: every candidate's workgroups are list-scheduled heavy-first (the order
 // run_gconv_multi launches them in) over the CUs and the shortest makespan wins.
-void multi_tile(const GMulti& m, int Cnp, int& BM, int& BN) {
+void multi_tile(const GMulti& m, int Cnp, int& BM, int& BN, bool bf16 = false) {
   const int P = device_cus();
   constexpr int NC = 6;
   const int cand[NC][2] = {{144, 128}, {144, 64}, {128, 128}, {128, 64}, {64, 64}, {128, 32}};
@@ -1724,6 +1724,7 @@ void multi_tile(const GMulti& m, int Cnp, int& BM, int& BN) {
   std::vector<float> heap;
   for (int i = 0; i < NC; ++i) {
     const int bm = cand[i][0], bn = cand[i][1];
+    if (bf16 && bm == 144) continue;  // (the 16-row extension is fp32 only)
     if (Cnp == 32) { if (bn != 32) continue; }
     else if (bn == 32 || Cnp % bn != 0) continue;
     heap.assign(P, 0.f);  // min-heap of CU finish times
@@ -1735,7 +1736,7 @@ void multi_tile(const GMulti& m, int Cnp, int& BM, int& BN) {
         int rank = 1;
         for (int o = 0; o < m.n; ++o) rank += (m.g[o].Kp < m.g[c].Kp);
         if (rank != pass) continue;
-        const float cost = 1.0f + 2.0f * bm * bn * (float)kch * BK / (4 * 64 * 2.1e3f) / eff[i];
+        const float cost = 1.0f + 2.0f * bm * bn * (float)kch * BK / (4 * 64 * 2.1e3f) / eff[i] / (bf16 ? 3.0f : 1.0f);  // (see make_plan)
         const int tiles = (int)srx_cdiv(m.g[c].M, bm) * (int)srx_cdiv(m.g[c].Cn, bn);
         for (int t = 0; t < tiles; ++t) {
           std::pop_heap(heap.begin(), heap.end(), later);
@@ -1749,7 +1750,7 @@ void multi_tile(const GMulti& m, int Cnp, int& BM, int& BN) {
 }
 
 // all problems use tile (BM, BN); no K split.  Problems are launched heaviest (largest K) first.
-int run_gconv_multi(GMulti& m, int BM, int BN, hipStream_t st) {
+int run_gconv_multi(GMulti& m, int BM, int BN, hipStream_t st, int precision = 0) {
   std::stable_sort(m.g, m.g + m.n, [](const GArgs& x, const GArgs& y) { return x.Kp > y.Kp; });
   int maxk = 0;
   m.first[0] = 0;
@@ -1765,8 +1766,14 @@ int run_gconv_multi(GMulti& m, int BM, int BN, hipStream_t st) {
     m.first[i + 1] = m.first[i] + tiles;
     if (a.kchunks > maxk) maxk = a.kchunks;
   }
-  const size_t lds = (size_t)(3 * (BM + BN) * BK) * sizeof(float) + (size_t)maxk * 8 * sizeof(int2);
+  const size_t lds = (size_t)(3 * (BM + BN) * BK) * (precision ? 2 : 4) + (size_t)maxk * 8 * sizeof(int2);
   if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
+  if (precision) {  // bf16 products (round 4: the stride-parity classes of a strided data gradient too)
+    if (BM == 128 && BN == 128) return launch_gconv_multi<128, 128, 64, 32, 0, 1>(m, lds, st);
+    if (BM == 128 && BN == 64) return launch_gconv_multi<128, 64, 32, 32, 0, 1>(m, lds, st);
+    if (BM == 64 && BN == 64) return launch_gconv_multi<64, 64, 32, 32, 0, 1>(m, lds, st);
+    return launch_gconv_multi<128, 32, 32, 32, 0, 1>(m, lds, st);
+  }
   if (BM == 144 && BN == 128) return launch_gconv_multi<128, 128, 64, 32, 16>(m, lds, st);
   if (BM == 144 && BN == 64) return launch_gconv_multi<128, 64, 32, 32, 16>(m, lds, st);
   if (BM == 128 && BN == 128) return launch_gconv_multi<128, 128, 64, 32, 0>(m, lds, st);
@@ -1989,7 +1996,7 @@ extern "C" int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out) {
         m.g[m.n++].Kp = cls[i].Kp;
       }
       p = Plan{};
-      multi_tile(m, pad_rows(d->Cin), p.BM, p.BN);
+      multi_tile(m, pad_rows(d->Cin), p.BM, p.BN, d->precision != 0);
       p.split = 1; p.ks = 1; p.tail = 0;
       for (int i = 0; i < m.n; ++i) p.full += (int)srx_cdiv(m.g[i].M, p.BM) * (int)srx_cdiv(d->Cin, p.BN);
       multi = 1;
@@ -2340,8 +2347,8 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
   }
   if (multi.n > 0) {
     int bm, bn;
-    multi_tile(multi, pad_rows(d->Cin), bm, bn);
-    if (int rc = run_gconv_multi(multi, bm, bn, st)) return rc;
+    multi_tile(multi, pad_rows(d->Cin), bm, bn, d->precision != 0);
+    if (int rc = run_gconv_multi(multi, bm, bn, st, d->precision)) return rc;
   }
   return SRX_OK;
 }
