@@ -444,10 +444,54 @@ def dp_rehearsal(contention=(16,)):
             except Exception as exc:  # noqa: BLE001
                 row[name + '_ms'] = None
                 row[name + '_error'] = f'{type(exc).__name__}: {str(exc)[-200:]}'
+        # the same k CUs held only while a large gradient bucket would be on the wire (from the launch() of the 75.5 MB
+        # classifier bucket to the wait() in front of the discriminator's optimiser: D's conv backward + the VGG19 forward),
+        # with plans that know nothing and with plans that leave k CUs free INSIDE that window only (GradBuckets.reserve_cus)
+        for name, env in (('window_plans_for_256', {'SRX_BENCH_WINDOW_OCCUPY_CUS': str(k)}),
+                          ('window_plans_aware', {'SRX_BENCH_WINDOW_OCCUPY_CUS': str(k), 'SRX_BENCH_WINDOW_RESERVED_CUS': str(k)})):
+            try:
+                child = _dp_child(env, steps=30)
+                row[name + '_ms'] = child['segmented_ms_per_step']
+            except Exception as exc:  # noqa: BLE001
+                row[name + '_ms'] = None
+                row[name + '_error'] = f'{type(exc).__name__}: {str(exc)[-200:]}'
         table.append(row)
     dp['cu_contention'] = {'unheld_segmented_ms': dp['segmented_ms_per_step'], 'rows': table,
-                           'how': 'k whole CUs held by srx_occupy_cus on a side stream for the whole timed region'}
+                           'how': 'k whole CUs held by srx_occupy_cus on a side stream: for the whole timed region (plans_*: an upper '
+                                  'bound nobody reaches -- RCCL occupies channels only while a bucket is in flight) and only inside '
+                                  'the communication window of the large discriminator buckets (window_*)'}
     return dp
+
+
+class _WindowHolder:
+    """Rehearsal stand-in for RCCL's channel kernels (``GradBuckets(window_hook=...)``): holds k compute units on a side stream
+    from the launch() of a large gradient bucket to the wait() that closes the window -- not for the whole timed region."""
+
+    def __init__(self, device, k, whole_cu):
+        self.k, self.whole_cu = k, whole_cu
+        self.side = torch.cuda.Stream(device)
+        self.flags = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(2)]
+        self.i, self.windows = 0, 0
+        self.ev = torch.cuda.Event()
+
+    def begin(self):
+        from torchsr_amd import _lib
+        flag = self.flags[self.i]
+        self.ev.record()  # the window opens where the compute stream is now
+        with torch.cuda.stream(self.side):
+            flag.zero_()
+            self.side.wait_event(self.ev)
+            _lib.call('srx_occupy_cus', self.k, self.whole_cu, flag.data_ptr(), 50, self.side.cuda_stream)  # bounded: 50 ms
+        self.windows += 1
+
+    def end(self):
+        self.flags[self.i].fill_(1)  # on the compute stream: the holder exits when the compute stream gets here
+        self.i ^= 1
+
+
+def _window_holder(device):
+    k = int(os.environ.get('SRX_BENCH_WINDOW_OCCUPY_CUS', '0'))
+    return _WindowHolder(device, k, int(os.environ.get('SRX_BENCH_OCCUPY_WHOLE_CU', '1'))) if k > 0 else None
 
 
 def _plan_cus():
@@ -527,9 +571,16 @@ def main():
         os.environ.setdefault('WORLD_SIZE', '1')
         if 'MASTER_PORT' not in os.environ:
             os.environ['MASTER_PORT'] = str(_free_port())
+    comm = None
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('SRX_BENCH_BACKEND', 'nccl')  # 'nccl' is RCCL on ROCm
+        # at world > 1: bound RCCL's channel count and tell the launch plans how many CUs the channel workgroups get while a
+        # large gradient bucket is on the wire -- decided here, BEFORE the process group exists, and printed in `config`
+        from torchsr_amd.ddp import configure_comm
+        comm = configure_comm(world, backend)
+        if forced and os.environ.get('SRX_BENCH_WINDOW_RESERVED_CUS'):  # one-GPU rehearsal of the windowed reservation
+            comm['reserved_cus_in_comm_window'] = int(os.environ['SRX_BENCH_WINDOW_RESERVED_CUS'])
         if backend == 'nccl':
             dist.init_process_group(backend='nccl', device_id=device)
         else:
@@ -542,7 +593,8 @@ def main():
     targs = Namespace(disable_amp=True, batch_size=BATCH, epochs=8, gan_checkpoint=None, local_rank=local_rank,
                       pretrain_epochs=1, psnr_checkpoint=None, skip_image_save=True, world_size=world,
                       rank=rank if distributed else -1, use_graphs=not args.no_graphs, vgg_weights='random',
-                      force_collectives=forced)
+                      force_collectives=forced, comm_reserved_cus=comm['reserved_cus_in_comm_window'] if comm else 0,
+                      comm_window_hook=_window_holder(device))
     trainer = SRGANTrainer(device, targs, [], [], BATCH, BATCH, distributed=distributed)
     trainer.generator.train()
     trainer.discriminator.train()
@@ -627,7 +679,9 @@ def main():
               'bucket_bytes': {'generator': [int(x.numel()) * 4 for x in trainer.gen_sync.slices],
                                'discriminator': [int(x.numel()) * 4 for x in trainer.disc_sync.slices]},
               'graph_segments': sorted(k for k in trainer._graphs), 'hip_graph': trainer.use_graphs,
-              'cus_held': occupy, 'plan_cus': _plan_cus(),
+              'cus_held': occupy, 'plan_cus': _plan_cus(), 'comm': comm,
+              'cus_held_in_comm_windows': int(os.environ.get('SRX_BENCH_WINDOW_OCCUPY_CUS', '0')),
+              'comm_windows_opened': getattr(targs.comm_window_hook, 'windows', None),
               'segmented_ms_per_step': round(seg_ms, 3), 'fused_ms_per_step': round(fused_ms, 3),
               'segmentation_overhead': round(seg_ms / fused_ms - 1.0, 4), 'steps': args.steps,
               'what': 'SRGAN GAN step, batch 16, world size 1 on RCCL: 7 hipGraph segments + 4 async all-reduces '
@@ -660,7 +714,7 @@ def main():
                        'process_group': describe_group(),
                        'grad_buckets': ({'generator': len(trainer.gen_sync), 'discriminator': len(trainer.disc_sync)}
                                         if distributed else None),
-                       'plan_cus': _plan_cus()},
+                       'plan_cus': _plan_cus(), 'comm': comm},
             'per_rank_ms_per_step': rank_ms,
             'step_tflops': round(value * GF_PER_CROP / 1e3, 2),
             'step_frac_of_fp32_mfma_peak': round(value * GF_PER_CROP / 1e3 / (PEAK_TFLOPS * world), 4),

@@ -168,6 +168,9 @@ int srx_conv3x3_c64_bf16_pack(const float* w, const float* bias, const float* ou
                               void* stream);
 int srx_conv3x3_c64_bf16_fwd(int N, int H, int W, int Cout, int shuffle, const void* x, const void* wpk, float slope,
                              const void* residual, void* y, int y_cs, void* stream);
+/* host only: out[3] = {rows per chunk, chunks per column strip, column strips} of the launch _fwd makes at this size.  A chunk is
+ * addressed with 32-bit byte offsets from its first row, so rows per chunk x W x 128 bytes stays below 4 GiB (shorter chunks) */
+int srx_conv3x3_c64_bf16_plan(int N, int H, int W, int Cout, int* out);
 /* fp32 <-> bf16 (round to nearest even), n elements, a multiple of 4: the two ends of the chain */
 int srx_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 int srx_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
@@ -271,7 +274,7 @@ int srx_bn_act_bwd_finish(const float* dout, const float* y, const float* mean, 
                           int C, int act, float slope, const float* prelu, float* dgamma_acc, float* dbeta_acc,
                           float* dprelu_acc, void* stream);
 /* dw (OIHW) = autograd of nn.Conv2d wrt its weight; accumulate != 0 adds into dw (a .grad buffer)
- * instead of overwriting it.  db (may be NULL; not for shuffle layers) receives the bias gradient
+ * instead of overwriting it.  db (may be NULL) receives the bias gradient
  * sum_m dy[m][co] under the same flag: the kernel stages every dy row anyway.  The same flag exists on srx_colsum, srx_linear_bwd_weight,
  * srx_prelu_bwd; srx_bn_act_bwd_reduce takes optional accumulation targets. */
 int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, const float* dy, float* dw_oihw,
@@ -461,6 +464,11 @@ int srx_l1_fwd(const float* a, const float* b, float* loss, int64_t n, float* ws
 /* da = gscale[0] * d(mean loss)/da ; db (if non-NULL) = -da */
 int srx_mse_bwd(const float* a, const float* b, const float* gscale, float* da, float* db, int64_t n, void* stream);
 int srx_l1_bwd(const float* a, const float* b, const float* gscale, float* da, float* db, int64_t n, void* stream);
+/* F.l1_loss with an explicit divisor `count` (<= n): NHWC images carry a zero padding channel (3 of 4 stored channels are
+ * real), and the reference's mean (esrgan/trainer.py:466) runs over the real elements only */
+int srx_l1_fwd_count(const float* a, const float* b, float* loss, int64_t n, int64_t count, float* ws, void* stream);
+int srx_l1_bwd_count(const float* a, const float* b, const float* gscale, float* da, float* db, int64_t n, int64_t count,
+                     void* stream);
 /* nn.BCELoss on probabilities against a constant label (srgan/trainer.py:164,446-447,456);
  * log terms clamped at -100 as torch does */
 int srx_bce_fwd(const float* p, float target, float* loss, int64_t n, float* ws, void* stream);
@@ -472,6 +480,33 @@ int srx_bce_logits_bwd(const float* x, const float* shift, float target, const f
 int srx_mean_fwd(const float* x, float* out, int64_t n, float* ws, void* stream);
 int srx_mean_bwd(const float* x, const float* gscale, float* dx, int64_t n, void* stream);
 /* sum of squared error -> used for PSNR (srgan/trainer.py:296) is srx_mse_fwd */
+
+/* ------------------------------------------------- discriminator head + loss */
+/* The end of a discriminator pass inside the GAN steps -- last Linear layer -> [Sigmoid] -> adversarial loss -- as ONE
+ * forward and ONE backward launch (as separate operators: ~25 one-workgroup launches per discriminator update).
+ *   SRX_HEAD_SRGAN_D  srgan/discriminator.py:67-68 + srgan/trainer.py:446-448: rows [0, n_first) = D(real), the rest =
+ *                     D(fake); out[0] = BCELoss(sigmoid(z_real), 1) + BCELoss(sigmoid(z_fake), 0), out[1], out[2] the terms
+ *   SRX_HEAD_SRGAN_G  srgan/trainer.py:456-457: out[1] = BCELoss(sigmoid(z), 1), out[0] = addend[0] + adv_weight * out[1]
+ *   SRX_HEAD_ESRGAN_D esrgan/discriminator.py:75 + esrgan/trainer.py:451-453: out[0] = (BCEWithLogits(z_real - mean(z_fake), 1)
+ *                     + BCEWithLogits(z_fake - mean(z_real), 0)) / 2, both means differentiated; out[4], out[5] the means
+ *   SRX_HEAD_ESRGAN_G esrgan/trainer.py:468-469: out[1] = BCEWithLogits(z - shift[0], 1) (shift = mean(D(real)), no
+ *                     gradient), out[0] = addend[0] + adv_weight * out[1]
+ * hidden [B][J] is the OUTPUT of the hidden layer's LeakyReLU(slope); z = hidden w2 + b2.  zp [B] receives what the backward
+ * needs (probabilities for the SRGAN modes, logits for the ESRGAN ones), out at least 8 floats; loss (may be NULL) receives
+ * out[0] once more (a tensor of its own for the caller's autograd tape).  B <= 256.
+ * Backward, given g[0] = d(loss)/d(out[0]) on the device: dpre [B][J] = gradient of the hidden layer's PRE-activation
+ * (LeakyReLU backward applied), dw2 [J], db2 [1], db1 [J] = column sums of dpre (the hidden layer's bias gradient); any of
+ * the three may be NULL; accumulate != 0 adds to them.  (The gradient of `addend` is g[0] itself.) */
+enum { SRX_HEAD_SRGAN_D = 0, SRX_HEAD_SRGAN_G = 1, SRX_HEAD_ESRGAN_D = 2, SRX_HEAD_ESRGAN_G = 3 };
+typedef struct {
+  int32_t mode, B, J, n_first;
+  float slope, adv_weight;
+} srx_gan_head_t;
+int srx_gan_head_fwd(const srx_gan_head_t* h, const float* hidden, const float* w2, const float* b2, const float* shift,
+                     const float* addend, float* zp, float* out, float* loss, void* stream);
+int srx_gan_head_bwd(const srx_gan_head_t* h, const float* hidden, const float* w2, const float* zp, const float* out,
+                     const float* shift, const float* g, float* dpre, float* dw2, float* db2, float* db1, int accumulate,
+                     void* stream);
 
 /* --------------------------------------------------------------- optimiser */
 /* torch.optim.Adam(lr, betas, eps, weight_decay=0) over one flat buffer

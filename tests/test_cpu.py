@@ -531,3 +531,44 @@ def test_device_loader_shards_have_equal_length_on_every_rank():
                 assert lens[0] >= 1
             # what __iter__ slices must exist on every rank
             assert all(lens[0] * batch - len(s) < batch for s in shards) if test else all(lens[0] * batch <= len(s) for s in shards)
+
+
+def test_bf16_native_conv_chunks_stay_inside_32_bit_offsets():
+    """srx_conv3x3_c64_bf16_fwd addresses a chunk's rows by 32-bit byte offsets from the chunk's first row: the planner must
+    cut chunks so that rows per chunk (+ the rows in flight around it) x W x 128 bytes stays below 4 GiB, whatever H is
+    (round-4 advice: rows_per_chunk could grow to H and the offsets wrapped silently).  Host only: nothing is launched."""
+    import ctypes as C
+    from torchsr_amd import _lib
+    lib = _lib.lib()
+    out = (C.c_int * 3)()
+    for n, h, w in ((1, 1080, 1920), (1, 4320, 7680), (1, 400000, 5000), (1, 40000, 50000), (2, 9000, 200000), (1, 64, 24)):
+        if n * h * w >= 2 ** 31:
+            continue
+        assert lib.srx_conv3x3_c64_bf16_plan(n, h, w, 64, out) == 0, (n, h, w)
+        rpc, chunks, strips = out[0], out[1], out[2]
+        rw = 4 if w <= 32 else (2 if w <= 64 else 1)
+        assert rpc >= rw and rpc % rw == 0 and rpc * chunks >= h and strips >= 1
+        assert (rpc + 2 + 3 * rw + 1) * w * 128 < 2 ** 32, (n, h, w, rpc)
+    assert lib.srx_conv3x3_c64_bf16_plan(1, 16, 300000, 64, out) != 0  # one row of the window alone is past the range
+
+
+def test_comm_configuration_is_decided_before_the_process_group(monkeypatch):
+    """torchsr/torchsr.py:257-258 + srgan/trainer.py:142-157 (DistributedDataParallel): at world size > 1 the RCCL channel count
+    is bounded and the launch plans are told how many CUs the channel kernels get while a large bucket is on the wire -- by
+    default, not through a hand-set switch -- and a user's own NCCL_* values win."""
+    from torchsr_amd import ddp
+    for k in ('NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS', 'SRX_NCCL_CHANNELS', 'SRX_COMM_RESERVED_CUS'):
+        monkeypatch.delenv(k, raising=False)
+    one = ddp.configure_comm(1, 'nccl')
+    assert one['reserved_cus_in_comm_window'] == 0 and 'NCCL_MAX_NCHANNELS' not in os.environ
+    gloo = ddp.configure_comm(2, 'gloo')
+    assert gloo['reserved_cus_in_comm_window'] == 0 and 'NCCL_MAX_NCHANNELS' not in os.environ
+    eight = ddp.configure_comm(8, 'nccl')
+    assert os.environ['NCCL_MAX_NCHANNELS'] == os.environ['NCCL_MIN_NCHANNELS'] == str(ddp.DEFAULT_CHANNELS)
+    assert eight['reserved_cus_in_comm_window'] == ddp.DEFAULT_CHANNELS and eight['nccl_max_nchannels'] == str(ddp.DEFAULT_CHANNELS)
+    monkeypatch.setenv('NCCL_MAX_NCHANNELS', '4')
+    monkeypatch.setenv('NCCL_MIN_NCHANNELS', '2')
+    mine = ddp.configure_comm(8, 'nccl')
+    assert mine['nccl_max_nchannels'] == '4' and mine['nccl_min_nchannels'] == '2' and mine['reserved_cus_in_comm_window'] == 4
+    monkeypatch.setenv('SRX_COMM_RESERVED_CUS', '12')
+    assert ddp.configure_comm(8, 'nccl')['reserved_cus_in_comm_window'] == 12

@@ -612,7 +612,8 @@ def test_activations_and_pool(dev):
 
 
 @pytest.mark.parametrize('cfg', [(16, 18432, 1024, 2), (16, 1024, 1, 0), (3, 20, 5, 1), (16, 2048, 100, 2),
-                                 (33, 256, 40, 0)], ids=lambda c: 'x'.join(map(str, c)))
+                                 (33, 256, 40, 0), (32, 18432, 1024, 2), (64, 2048, 100, 2), (70, 512, 48, 0)],
+                         ids=lambda c: 'x'.join(map(str, c)))
 def test_linear(dev, cfg):
     from torchsr_amd import functional as F
     b, k, j, act = cfg

@@ -12,7 +12,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('SRX_LIB') or os.path.join(CSRC, 'libsrx_hip.so')  # SRX_LIB: developer A/B builds on one GPU box
-SOURCES = ['api.cpp', 'gconv.hip', 'c64.hip', 'thin9.hip', 'rdb.hip', 'thin.hip', 'rowtile.hip', 'augment.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'optim.hip']
+SOURCES = ['api.cpp', 'gconv.hip', 'c64.hip', 'thin9.hip', 'rdb.hip', 'thin.hip', 'rowtile.hip', 'augment.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'head.hip', 'optim.hip']
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
 
@@ -35,6 +35,15 @@ class DgradEpilogue(C.Structure):
         ('addend_channels', C.c_int32), ('addend_scale', C.c_float), ('act_out', C.c_void_p), ('act_slope', C.c_float),
         ('c_lo', C.c_int32), ('c_hi', C.c_int32),
     ]
+
+
+class GanHead(C.Structure):
+    """Mirror of ``srx_gan_head_t`` (include/srx.h)."""
+    _fields_ = [('mode', C.c_int32), ('B', C.c_int32), ('J', C.c_int32), ('n_first', C.c_int32), ('slope', C.c_float),
+                ('adv_weight', C.c_float)]
+
+
+HEAD_SRGAN_D, HEAD_SRGAN_G, HEAD_ESRGAN_D, HEAD_ESRGAN_G = 0, 1, 2, 3
 
 
 def source_digest() -> str:
@@ -152,6 +161,7 @@ _SIGS = {
     'srx_conv3x3_c64_bf16_packed_bytes': (_Z, [_I]),
     'srx_conv3x3_c64_bf16_pack': (_I, [_P, _P, _P, _I, _I, _P, _P]),
     'srx_conv3x3_c64_bf16_fwd': (_I, [_I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _I, _P]),
+    'srx_conv3x3_c64_bf16_plan': (_I, [_I, _I, _I, _I, C.POINTER(C.c_int)]),
     'srx_f32_to_bf16': (_I, [_P, _P, _L, _P]),
     'srx_bf16_to_f32': (_I, [_P, _P, _L, _P]),
     'srx_conv9x9_c64_thin_bf16_packed_bytes': (_Z, []),
@@ -221,10 +231,14 @@ _SIGS = {
     'srx_l1_fwd': (_I, [_P, _P, _P, _L, _P, _P]),
     'srx_mse_bwd': (_I, [_P, _P, _P, _P, _P, _L, _P]),
     'srx_l1_bwd': (_I, [_P, _P, _P, _P, _P, _L, _P]),
+    'srx_l1_fwd_count': (_I, [_P, _P, _P, _L, _L, _P, _P]),
+    'srx_l1_bwd_count': (_I, [_P, _P, _P, _P, _P, _L, _L, _P]),
     'srx_bce_fwd': (_I, [_P, _F, _P, _L, _P, _P]),
     'srx_bce_bwd': (_I, [_P, _F, _P, _P, _L, _P]),
     'srx_bce_logits_fwd': (_I, [_P, _P, _F, _P, _L, _P, _P]),
     'srx_bce_logits_bwd': (_I, [_P, _P, _F, _P, _P, _L, _P]),
+    'srx_gan_head_fwd': (_I, [C.POINTER(GanHead), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'srx_gan_head_bwd': (_I, [C.POINTER(GanHead), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'srx_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
 }
 # functions whose int return value is data, not a status

@@ -50,6 +50,7 @@ static SrxDevSwitches read_switches() {
   s.thin_fwd_rows = num("SRX_THIN_FWD_ROWS");
   s.reserved_cus = num("SRX_RESERVED_CUS");
   s.c64_ablate = num("SRX_C64_ABLATE");
+  s.rdb_ablate = num("SRX_RDB_ABLATE");
   if (const char* f = getenv("SRX_FORCE_PLAN")) {
     int v[4] = {0, 0, 1, 1};
     if (sscanf(f, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) { s.force_plan = true; for (int i = 0; i < 4; ++i) s.plan[i] = v[i]; }

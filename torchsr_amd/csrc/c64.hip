@@ -480,6 +480,37 @@ __global__ void bf16_to_f32_kernel(const uint2* __restrict__ x, f32x4* __restric
   }
 }
 
+// One workgroup per CU (a wave owns its SIMD's whole register file), persistent over work items = (image, column strip,
+// row chunk).  The chunk height is chosen so that the busiest workgroup's rows -- its items x (chunk rows + the 2 halo rows
+// a chunk loads without computing) -- are fewest.
+int c64_plan(int N, int H, int W, int groups, int RW, int TW, int* rows_per_chunk, int* nchunks, int* nstrips) {
+  const int cus = srx_plan_cus();
+  const int gx_max = std::max(1, cus / groups);
+  const int strips = (int)srx_cdiv(W, TW);
+  const int64_t cols = (int64_t)N * strips;
+  int best_rpc = (int)srx_roundup(H, RW);
+  int64_t best_span = INT64_MAX;
+  for (int k = 1; k <= 8; ++k) {
+    const int64_t want = std::max<int64_t>(1, (int64_t)gx_max * k / cols);  // chunks per column strip
+    const int rpc = (int)srx_roundup(srx_cdiv(H, want), RW);
+    const int64_t chunks = srx_cdiv(H, rpc);
+    // steps of the busiest workgroup: per item its rows plus the prologue (AHEAD groups loaded and written before the
+    // first MFMA, about three steps' worth) -- short chunks are allowed, they just pay that more often
+    const int64_t span = srx_cdiv(cols * chunks, gx_max) * (rpc / RW + 3);
+    if (span < best_span) { best_span = span; best_rpc = rpc; }
+  }
+  // A chunk's rows are addressed by 32-bit byte offsets from the chunk's first row (rows x row bytes; the ring runs AHEAD
+  // groups of RW rows ahead, plus the row above / below): the whole span must stay below 4 GiB, or offsets wrap silently
+  // and rows above the image stop failing the descriptor's range check.  Shorter chunks cost time only.
+  const int64_t span_rows = (int64_t)(1LL << 32) / ((int64_t)W * 128) - (2 + 3 * RW + 1);
+  if (span_rows < RW) SRX_FAIL(SRX_E_UNSUPPORTED, "conv3x3_c64_bf16_fwd: image rows of %d pixels are too long for 32-bit offsets inside a chunk", W);
+  if (best_rpc > span_rows) best_rpc = (int)(span_rows / RW) * RW;
+  *rows_per_chunk = best_rpc;
+  *nchunks = (int)srx_cdiv(H, best_rpc);
+  *nstrips = strips;
+  return SRX_OK;
+}
+
 template <int RW, int CW>
 int launch_c64(C64Args& a, int groups, hipStream_t st) {
   constexpr int TW = 32 * CW, NR = RW == 1 ? 4 : 3 * RW;
@@ -488,27 +519,9 @@ int launch_c64(C64Args& a, int groups, hipStream_t st) {
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c64_bf16_kernel<RW, CW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  // One workgroup per CU (a wave owns its SIMD's whole register file), persistent over work items = (image, column strip,
-  // row chunk).  The chunk height is chosen so that the busiest workgroup's rows -- its items x (chunk rows + the 2 halo rows
-  // a chunk loads without computing) -- are fewest.
-  const int cus = srx_plan_cus();
-  const int gx_max = std::max(1, cus / groups);
-  a.strips = (int)srx_cdiv(a.W, TW);
-  const int64_t cols = (int64_t)a.N * a.strips;
-  int best_rpc = (int)srx_roundup(a.H, RW);
-  int64_t best_span = INT64_MAX;
-  for (int k = 1; k <= 8; ++k) {
-    const int64_t want = std::max<int64_t>(1, (int64_t)gx_max * k / cols);  // chunks per column strip
-    const int rpc = (int)srx_roundup(srx_cdiv(a.H, want), RW);
-    const int64_t chunks = srx_cdiv(a.H, rpc);
-    // steps of the busiest workgroup: per item its rows plus the prologue (AHEAD groups loaded and written before the
-    // first MFMA, about three steps' worth) -- short chunks are allowed, they just pay that more often
-    const int64_t span = srx_cdiv(cols * chunks, gx_max) * (rpc / RW + 3);
-    if (span < best_span) { best_span = span; best_rpc = rpc; }
-  }
-  a.rows_per_chunk = best_rpc;
-  a.chunks = (int)srx_cdiv(a.H, best_rpc);
-  a.nwork = (int)(cols * a.chunks);
+  const int gx_max = std::max(1, srx_plan_cus() / groups);
+  if (int rc = c64_plan(a.N, a.H, a.W, groups, RW, TW, &a.rows_per_chunk, &a.chunks, &a.strips)) return rc;
+  a.nwork = (int)((int64_t)a.N * a.strips * a.chunks);
   const int gx = std::min(a.nwork, gx_max);
   char nm[112];
   if (srx_prof_on()) snprintf(nm, sizeof(nm), "c64_bf16_kernel<%d, %d> MxNxK=%lldx%dx576", RW, CW, (long long)a.N * a.H * a.W, 64 * groups);
@@ -568,6 +581,14 @@ static int c64_fwd_impl(int N, int H, int W, int Cout, int shuffle, const void* 
   if (W <= 32) return launch_c64<4, 1>(a, groups, st);
   if (W <= 64) return launch_c64<2, 2>(a, groups, st);
   return launch_c64<1, 4>(a, groups, st);
+}
+
+// out[3] = {rows per chunk, chunks per column strip, column strips} of the launch srx_conv3x3_c64_bf16_fwd would make (host only)
+extern "C" int srx_conv3x3_c64_bf16_plan(int N, int H, int W, int Cout, int* out) {
+  SRX_REQUIRE(out && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 64 == 0, "conv3x3_c64_bf16_plan: bad argument");
+  SRX_REQUIRE((int64_t)W * 128 * 130 < (1LL << 32) && (int64_t)N * H * W < (1LL << 31), "conv3x3_c64_bf16_plan: image rows too long for 32-bit offsets inside a chunk");
+  const int RW = W <= 32 ? 4 : (W <= 64 ? 2 : 1), CW = W <= 32 ? 1 : (W <= 64 ? 2 : 4);
+  return c64_plan(N, H, W, Cout / 64, RW, 32 * CW, out, out + 1, out + 2);
 }
 
 extern "C" int srx_conv3x3_c64_bf16_fwd(int N, int H, int W, int Cout, int shuffle, const void* x, const void* wpk, float slope,

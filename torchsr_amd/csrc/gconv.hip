@@ -1375,7 +1375,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab_all, int nsla
       float s = 0.f;
       for (int z = 0; z < nslab; ++z) s += bslab[(size_t)z * Cnw + idx];
       s *= outs.scale[o];
-      const int bi = (rows_lo && idx >= rows_lo) ? (int)idx - rows_lo : (int)idx;
+      int bi = (rows_lo && idx >= rows_lo) ? (int)idx - rows_lo : (int)idx;
+      // PixelShuffle layers: the slab's columns are in packed (sub-pixel, channel) order, the bias in the conv's own
+      if (shuffle_cps) { const int ij = (int)idx / shuffle_cps, cc = (int)idx - ij * shuffle_cps; bi = cc * 4 + ij; }
       dbp[bi] = accumulate ? dbp[bi] + s : s;
     }
   }
@@ -2523,7 +2525,6 @@ static int wgrad_multi_impl(const srx_conv2d_t* d, int nprob, int per_out, const
     SRX_REQUIRE(dws[o] && (!dws_hi || dws_hi[o]), "conv2d_bwd_weight: null gradient pointer for output %d", o);
     any_db |= (dbs && dbs[o]) || (dbs_hi && dbs_hi[o]);
   }
-  if (any_db && d->shuffle) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_weight: bias gradient of a PixelShuffle layer is not fused");
   hipStream_t st = srx_stream(stream);
   if (srx_thin_wgrad_applicable(d)) {  // 3-channel layers: their own kernel, one problem at a time
     for (int o = 0; out_scales && o < nout; ++o)

@@ -7,11 +7,15 @@
 //
 // MFMA 16x16x4 maps: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D: col=l&15, row=4*(l>>4)+reg.
 #include "srx_common.h"
+#include <algorithm>
 
 namespace {
 
 // y_partial[z][b][j] = sum_{k in split z} x[b][k] w[j][k]
-// block = 4 waves, one 16-wide j tile; the waves interleave 64-wide k slices.
+// block = 4 waves, one 16-wide j tile; the waves interleave 64-wide k slices.  NB blocks of 16 batch rows share every
+// weight fragment (round 5: a batch of 32 -- the discriminator's real + fake pair -- streamed the 75.5 MB weight once per
+// 16-row block: two launches of ~20 us where one does)
+template <int NB>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ part, int B, int K, int J, int b0,
                                                          int kper) {
@@ -20,38 +24,55 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   const int r = lane & 15, h = lane >> 4;
   const int j0 = blockIdx.x * 16;
   const int kbeg = blockIdx.y * kper, kend = min(K, kbeg + kper);
-  const int b = b0 + r, j = j0 + r;
-  const bool bok = b < B, jok = j < J;
-  const float* xr = x + (size_t)(bok ? b : 0) * K;
+  const int j = j0 + r;
+  const bool jok = j < J;
   const float* wr = w + (size_t)(jok ? j : 0) * K;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* xr[NB];
+  bool bok[NB];
+  f32x4 acc[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int b = b0 + 16 * n + r;
+    bok[n] = b < B;
+    xr[n] = x + (size_t)(bok[n] ? b : 0) * K;
+    acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   for (int kb = kbeg + wave * 64; kb < kend; kb += 256) {
-    f32x4 xa[4], wa[4];
+    f32x4 xa[NB][4], wa[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int k = kb + 16 * t + 4 * h;
       const bool ok = k < kend;
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + (ok ? k : 0));
       const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (ok ? k : 0));
-      xa[t] = (ok && bok) ? xv : (f32x4){0.f, 0.f, 0.f, 0.f};
       wa[t] = (ok && jok) ? wv : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xr[n] + (ok ? k : 0));
+        xa[n][t] = (ok && bok[n]) ? xv : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int n = 0; n < NB; ++n)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t][e], wa[t][e], acc, 0, 0, 0);
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[n][t][e], wa[t][e], acc[n], 0, 0, 0);
   }
-  red[wave][lane] = acc;
-  __syncthreads();
-  if (wave == 0) {
-    f32x4 s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-    // D: col = j0 + (lane&15), rows b0 + 4*(lane>>4) + reg
-    const int jj = j0 + r;
-    if (jj < J) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int bb = b0 + 4 * h + e;
-        if (bb < B) part[((size_t)blockIdx.y * B + bb) * J + jj] = s[e];
+  for (int n = 0; n < NB; ++n) {
+    if (n) __syncthreads();
+    red[wave][lane] = acc[n];
+    __syncthreads();
+    if (wave == 0) {
+      f32x4 s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+      // D: col = j0 + (lane&15), rows b0 + 16 n + 4*(lane>>4) + reg
+      const int jj = j0 + r;
+      if (jj < J) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int bb = b0 + 16 * n + 4 * h + e;
+          if (bb < B) part[((size_t)blockIdx.y * B + bb) * J + jj] = s[e];
+        }
       }
     }
   }
@@ -76,7 +97,9 @@ __global__ void linear_fwd_final_kernel(const float* __restrict__ part, int nspl
   y[i] = s;
 }
 
-// dx_partial[z][b][k] = sum_{j in split z} dy[b][j] w[j][k];  wave = 64 k columns (4 accumulators)
+// dx_partial[z][b][k] = sum_{j in split z} dy[b][j] w[j][k];  wave = 64 k columns (4 accumulators per block of 16 rows);
+// NB blocks of 16 batch rows share every weight fragment (see linear_fwd_kernel)
+template <int NB>
 __global__ __launch_bounds__(256) void linear_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                               float* __restrict__ part, int B, int K, int J, int b0,
                                                               int jper) {
@@ -87,38 +110,51 @@ __global__ __launch_bounds__(256) void linear_bwd_data_kernel(const float* __res
   const int jbeg = blockIdx.y * jper, jend = min(J, jbeg + jper);
   const int kcol = n0 + 4 * r;
   const bool kok = kcol < K;
-  const int b = b0 + r;
-  const bool bok = b < B;
-  f32x4 acc[4];
+  bool bok[NB];
+  const float* dyr[NB];
+  f32x4 acc[NB][4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < NB; ++n) {
+    const int b = b0 + 16 * n + r;
+    bok[n] = b < B;
+    dyr[n] = dy + (size_t)(bok[n] ? b : 0) * J;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[n][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   for (int jb = jbeg; jb < jend; jb += 16) {
-    float av[4];
+    float av[NB][4];
     f32x4 wv[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int j = jb + 4 * t + h;
       const bool jok = j < jend;
-      const float a = dy[(size_t)(bok ? b : 0) * J + (jok ? j : 0)];
-      av[t] = (jok && bok) ? a : 0.f;
       const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)(jok ? j : 0) * K + (kok ? kcol : 0));
       wv[t] = (jok && kok) ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], wv[t][e], acc[e], 0, 0, 0);
-  }
-  // acc[e][reg]: row b0 + 4h + reg, column n0 + 4*r + e  -> one float4 per row
-  if (kok) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int bb = b0 + 4 * h + g;
-      if (bb < B) {
-        f32x4 o = {acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
-        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.y * B + bb) * K + kcol) = o;
+      for (int n = 0; n < NB; ++n) {
+        const float a = dyr[n][jok ? j : 0];
+        av[n][t] = (jok && bok[n]) ? a : 0.f;
       }
     }
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[n][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n][t], wv[t][e], acc[n][e], 0, 0, 0);
+  }
+  // acc[n][e][reg]: row b0 + 16 n + 4h + reg, column n0 + 4*r + e  -> one float4 per row
+  if (kok) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int bb = b0 + 16 * n + 4 * h + g;
+        if (bb < B) {
+          f32x4 o = {acc[n][0][g], acc[n][1][g], acc[n][2][g], acc[n][3][g]};
+          *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.y * B + bb) * K + kcol) = o;
+        }
+      }
   }
 }
 
@@ -178,7 +214,7 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* __r
 }
 
 int fwd_splits(int K, int J, int B) {
-  const int64_t tiles = srx_cdiv(J, 16) * srx_cdiv(B, 16);
+  const int64_t tiles = srx_cdiv(J, 16) * srx_cdiv(B, 64);  // (a launch covers 64 rows)
   int64_t s = srx_cdiv(1024, tiles);
   const int64_t maxs = srx_cdiv(K, 256);
   if (s > maxs) s = maxs;
@@ -186,7 +222,7 @@ int fwd_splits(int K, int J, int B) {
   return (int)s;
 }
 int bwd_splits(int K, int J, int B) {
-  const int64_t blocks = srx_cdiv(K, 256) * srx_cdiv(B, 16);
+  const int64_t blocks = srx_cdiv(K, 256) * srx_cdiv(B, 64);
   int64_t s = srx_cdiv(1024, blocks);
   const int64_t maxs = srx_cdiv(J, 64);
   if (s > maxs) s = maxs;
@@ -211,9 +247,13 @@ extern "C" int srx_linear_fwd(const float* x, const float* w, const float* bias,
   const int kper = (int)srx_roundup(srx_cdiv(K, ns), 256);
   const int nsplit = (int)srx_cdiv(K, kper);
   hipStream_t st = srx_stream(stream);
-  for (int b0 = 0; b0 < B; b0 += 16) {
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)srx_cdiv(J, 16), nsplit), dim3(256), 0, st, x, w, ws, B, K, J,
-                       b0, kper);
+  for (int b0 = 0; b0 < B; b0 += 64) {  // up to four 16-row blocks per launch share one pass over the weight
+    const dim3 grid((unsigned)srx_cdiv(J, 16), nsplit);
+    const int nb = (int)srx_cdiv(std::min(B - b0, 64), 16);
+    if (nb == 1) hipLaunchKernelGGL(linear_fwd_kernel<1>, grid, dim3(256), 0, st, x, w, ws, B, K, J, b0, kper);
+    else if (nb == 2) hipLaunchKernelGGL(linear_fwd_kernel<2>, grid, dim3(256), 0, st, x, w, ws, B, K, J, b0, kper);
+    else if (nb == 3) hipLaunchKernelGGL(linear_fwd_kernel<3>, grid, dim3(256), 0, st, x, w, ws, B, K, J, b0, kper);
+    else hipLaunchKernelGGL(linear_fwd_kernel<4>, grid, dim3(256), 0, st, x, w, ws, B, K, J, b0, kper);
     SRX_CHECK_LAUNCH("linear_fwd_kernel");
   }
   hipLaunchKernelGGL(linear_fwd_final_kernel, dim3((unsigned)srx_cdiv((int64_t)B * J, 256)), dim3(256), 0, st, ws,
@@ -231,9 +271,13 @@ extern "C" int srx_linear_bwd_data(const float* dy, const float* w, float* dx, i
   const int jper = (int)srx_roundup(srx_cdiv(J, ns), 16);
   const int nsplit = (int)srx_cdiv(J, jper);
   hipStream_t st = srx_stream(stream);
-  for (int b0 = 0; b0 < B; b0 += 16) {
-    hipLaunchKernelGGL(linear_bwd_data_kernel, dim3((unsigned)srx_cdiv(K, 256), nsplit), dim3(256), 0, st, dy, w, ws, B,
-                       K, J, b0, jper);
+  for (int b0 = 0; b0 < B; b0 += 64) {  // up to four 16-row blocks per launch share one pass over the weight
+    const dim3 grid((unsigned)srx_cdiv(K, 256), nsplit);
+    const int nb = (int)srx_cdiv(std::min(B - b0, 64), 16);
+    if (nb == 1) hipLaunchKernelGGL(linear_bwd_data_kernel<1>, grid, dim3(256), 0, st, dy, w, ws, B, K, J, b0, jper);
+    else if (nb == 2) hipLaunchKernelGGL(linear_bwd_data_kernel<2>, grid, dim3(256), 0, st, dy, w, ws, B, K, J, b0, jper);
+    else if (nb == 3) hipLaunchKernelGGL(linear_bwd_data_kernel<3>, grid, dim3(256), 0, st, dy, w, ws, B, K, J, b0, jper);
+    else hipLaunchKernelGGL(linear_bwd_data_kernel<4>, grid, dim3(256), 0, st, dy, w, ws, B, K, J, b0, jper);
     SRX_CHECK_LAUNCH("linear_bwd_data_kernel");
   }
   const int64_t n = (int64_t)B * K;

@@ -82,25 +82,26 @@ unsigned red_grid(int64_t n) {
   return (unsigned)b;
 }
 
+// count: the mean's divisor (0: n, every element counts)
 int loss_fwd(int kind, const float* a, const float* b, const float* shift, float target, float* loss, int64_t n,
-             float* ws, void* stream, const char* who) {
-  SRX_REQUIRE(a && loss && ws && n > 0, "%s: bad argument", who);
+             float* ws, void* stream, const char* who, int64_t count = 0) {
+  SRX_REQUIRE(a && loss && ws && n > 0 && count >= 0, "%s: bad argument", who);
   const unsigned nb = red_grid(n);
   hipStream_t st = srx_stream(stream);
   hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(256), 0, st, kind, a, b, shift, target, ws, n);
   SRX_CHECK_LAUNCH("loss_partial_kernel");
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, ws, (int)nb, 1.0 / (double)n, loss);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, ws, (int)nb, 1.0 / (double)(count ? count : n), loss);
   SRX_CHECK_LAUNCH("loss_final_kernel");
   return SRX_OK;
 }
 
 int loss_bwd(int kind, const float* a, const float* b, const float* shift, float target, const float* gscale, float* da,
-             float* db, int64_t n, void* stream, const char* who) {
-  SRX_REQUIRE(a && gscale && da && n > 0, "%s: bad argument", who);
+             float* db, int64_t n, void* stream, const char* who, int64_t count = 0) {
+  SRX_REQUIRE(a && gscale && da && n > 0 && count >= 0, "%s: bad argument", who);
   int64_t blocks = srx_cdiv(n, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, srx_stream(stream), kind, a, b, shift,
-                     target, gscale, da, db, n, 1.0f / (float)n);
+                     target, gscale, da, db, n, 1.0f / (float)(count ? count : n));
   SRX_CHECK_LAUNCH("loss_bwd_kernel");
   return SRX_OK;
 }
@@ -114,6 +115,17 @@ extern "C" int srx_mse_fwd(const float* a, const float* b, float* loss, int64_t 
 extern "C" int srx_l1_fwd(const float* a, const float* b, float* loss, int64_t n, float* ws, void* stream) {
   SRX_REQUIRE(b, "l1_fwd: bad argument");
   return loss_fwd(L_L1, a, b, nullptr, 0.f, loss, n, ws, stream, "l1_fwd");
+}
+// the same with an explicit divisor: images stored with a zero padding channel (NHWC, 3 of 4 channels real) take the
+// mean over the real elements only (count = 3/4 n), which is what the reference's NCHW tensors give
+extern "C" int srx_l1_fwd_count(const float* a, const float* b, float* loss, int64_t n, int64_t count, float* ws, void* stream) {
+  SRX_REQUIRE(b && count > 0, "l1_fwd_count: bad argument");
+  return loss_fwd(L_L1, a, b, nullptr, 0.f, loss, n, ws, stream, "l1_fwd_count", count);
+}
+extern "C" int srx_l1_bwd_count(const float* a, const float* b, const float* gscale, float* da, float* db, int64_t n,
+                                int64_t count, void* stream) {
+  SRX_REQUIRE(b && count > 0, "l1_bwd_count: bad argument");
+  return loss_bwd(L_L1, a, b, nullptr, 0.f, gscale, da, db, n, stream, "l1_bwd_count", count);
 }
 extern "C" int srx_mse_bwd(const float* a, const float* b, const float* gscale, float* da, float* db, int64_t n,
                            void* stream) {

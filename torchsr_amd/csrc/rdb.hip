@@ -167,7 +167,11 @@ __device__ __forceinline__ void job(int wave, int& mt0, int& nt, int& cnt) {
   cnt = nt < n_tiles<K>() ? max(0, min(tpw<K>(), m_tiles<K>() - mt0)) : 0;
 }
 
-template <int K, int S, int U>
+// ABL (developer ablations, SRX_RDB_ABLATE; 0 in the product -- every other value is a separate instantiation, so the product's
+// code is untouched): 1 = the MFMAs multiply constant registers, no fragment is read from LDS (what the block costs without
+// its LDS operand traffic); 2 = every fragment is read, no MFMA is issued (what the reads cost alone); 3 = ABL 0 without the
+// stage epilogues (no conversion, no LDS image of the next source, no global stores): results are garbage in all three.
+template <int K, int S, int U, int ABL>
 __device__ __forceinline__ void mma_unit(const unsigned char* lds, Wave& w) {
   constexpr int NK = conv_n(K), WS = src_w(S), WK = reg_w(K), RK = WK * WK, TPW = tpw<K>();
   constexpr int D = reg_org(K) - src_org(S) - 1;  // source coordinate of tap (0,0) = region coordinate + D
@@ -189,6 +193,18 @@ __device__ __forceinline__ void mma_unit(const unsigned char* lds, Wave& w) {
   // under load (four waves reading, four writing the next weights) returns after ~250 cycles -- two taps of MFMAs
   // (one tap ahead: 255 cycles per tap measured in-kernel, twice the MFMA time)
   bf16x8 wf[3][2], xf[3][TPW][2];
+  if constexpr (ABL == 1) {  // constant operands: the matrix pipe alone
+    const bf16x8 one = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) w.acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one, one, w.acc[i], 0, 0, 0);
+    }
+    (void)wrow; (void)act; (void)wsw; (void)bp;
+    return;
+  }
   auto fetch = [&](int t, int set) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -208,6 +224,15 @@ __device__ __forceinline__ void mma_unit(const unsigned char* lds, Wave& w) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     if (t + 2 < 9) fetch(t + 2, (t + 2) % 3);
+    if constexpr (ABL == 2) {  // the reads alone: every fragment is consumed by an empty asm, nothing is multiplied
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        asm volatile("" ::"v"(wf[t % 3][kk]));
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) asm volatile("" ::"v"(xf[t % 3][i][kk]));
+      }
+      continue;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -344,7 +369,7 @@ __device__ __forceinline__ void load_skip(const RdbArgs& a, const Wave& w, f32x4
   }
 }
 
-template <int U, bool BWD>
+template <int U, bool BWD, int ABL>
 __device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, Wave& w, int tid, f32x4 (&xs)[4],
                                           f32x4 (&ex)[4]) {
   constexpr int K = unit_conv(U), S = U - unit_first(K);
@@ -372,17 +397,17 @@ __device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, 
     if constexpr (U == unit_first(5)) load_skip<BWD>(a, w, xs, ex);
     f32x4 masks[2][4];
     if constexpr (BWD && S == K && K < 5) load_masks<K>(a, w, masks);
-    mma_unit<K, S, U>(lds, w);
-    if constexpr (S == K) {  // last source of stage K
+    mma_unit<K, S, U, ABL>(lds, w);
+    if constexpr (S == K && ABL != 3) {  // last source of stage K
       if constexpr (K < 5) epilogue_mid<K, BWD>(a, lds, w, masks);
       else epilogue_out<BWD>(a, lds, w, xs, ex);
     }
   }
   rdb_stamp(a, lds, w.wave, w.lane, 3 + 2 * U);
-  if constexpr (U + 1 < NUNITS) run_units<U + 1, BWD>(a, lds, w, tid, xs, ex);
+  if constexpr (U + 1 < NUNITS) run_units<U + 1, BWD, ABL>(a, lds, w, tid, xs, ex);
 }
 
-template <bool BWD>
+template <bool BWD, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS) void rdb_kernel(const RdbArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
@@ -440,7 +465,7 @@ __global__ __launch_bounds__(NTHREADS) void rdb_kernel(const RdbArgs a) {
   if (w.wave >= NCOMPUTE) dma_wait<2, 0>(srx_uniform((tid - NCOMPUTE * 64) >> 6));  // unit 0 has landed (units 1, 2 may fly on)
   rdb_stamp(a, lds, w.wave, w.lane, 1);
   f32x4 xs[4], ex[4];
-  run_units<0, BWD>(a, lds, w, tid, xs, ex);
+  run_units<0, BWD, ABL>(a, lds, w, tid, xs, ex);
   if (a.dbg && w.lane < DBG_SLOTS)  // (each wave copies the stamps its own lane 0 wrote)
     a.dbg[((size_t)blockIdx.x * 8 + w.wave) * DBG_SLOTS + w.lane] = reinterpret_cast<const unsigned*>(lds + LDS_BYTES)[w.wave * DBG_SLOTS + w.lane];
 }
@@ -527,7 +552,18 @@ static int rdb_launch(RdbArgs& a, const char* what, void* stream) {
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rdb_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rdb_kernel<BWD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rdb_kernel<BWD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rdb_kernel<BWD, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
+  if (const int abl = srx_dev().rdb_ablate; abl >= 1 && abl <= 3 && !a.dbg) {  // developer ablations (garbage results): see mma_unit
+    const dim3 g((unsigned)grid), b(NTHREADS);
+    if (abl == 1) hipLaunchKernelGGL((rdb_kernel<BWD, 1>), g, b, LDS_BYTES, srx_stream(stream), a);
+    else if (abl == 2) hipLaunchKernelGGL((rdb_kernel<BWD, 2>), g, b, LDS_BYTES, srx_stream(stream), a);
+    else hipLaunchKernelGGL((rdb_kernel<BWD, 3>), g, b, LDS_BYTES, srx_stream(stream), a);
+    SRX_CHECK_LAUNCH(what);
+    return SRX_OK;
+  }
   // algorithmic FLOPs: the five convs (or their data gradients) on the tile pixels; the halo recompute is not counted
   const double fl = 2.0 * a.N * a.H * a.W * 9.0 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64);
   char nm[112];

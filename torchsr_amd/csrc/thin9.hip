@@ -300,6 +300,11 @@ extern "C" int srx_conv9x9_c64_thin_bf16_fwd(int N, int H, int W, const void* x,
     const int64_t span = srx_cdiv(cols * chunks, cus) * ((rpc + 8) / RW + 3);
     if (span < best_span) { best_span = span; best_rpc = rpc; }
   }
+  {  // 32-bit byte offsets inside a chunk (rows_per_chunk + the 8-row window + the rows in flight): see c64.hip
+    const int64_t span_rows = (int64_t)(1LL << 32) / ((int64_t)W * 128) - (8 + 4);
+    if (span_rows < RW) SRX_FAIL(SRX_E_UNSUPPORTED, "conv9x9_c64_thin_bf16_fwd: image rows of %d pixels are too long for 32-bit offsets inside a chunk", W);
+    if (best_rpc > span_rows) best_rpc = (int)(span_rows / RW) * RW;
+  }
   a.rows_per_chunk = best_rpc;
   a.chunks = (int)srx_cdiv(H, best_rpc);
   a.nwork = (int)(cols * a.chunks);

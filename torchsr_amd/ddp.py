@@ -77,8 +77,16 @@ class GradBuckets:
     stream-orders the compute stream behind everything launched.
     """
 
+    # a bucket at least this large opens a "communication window": from its launch() to the next wait() the launch plans
+    # leave ``reserve_cus`` compute units to RCCL's channel workgroups (srx_set_reserved_cus) -- the generator's 1.2 / 4.9 MB
+    # buckets are on the wire for tens of microseconds and do not
+    window_bytes = 8 << 20
+
     def __init__(self, flat, boundaries: Sequence[str] = (), module: Optional[torch.nn.Module] = None,
-                 group: Optional[dist.ProcessGroup] = None, force: bool = False):
+                 group: Optional[dist.ProcessGroup] = None, force: bool = False, reserve_cus: int = 0, window_hook=None):
+        self.reserve_cus = int(reserve_cus)
+        self.window_hook = window_hook  # rehearsal aid: .begin() / .end() around a window (bench.py holds CUs there)
+        self._window = False
         self.flat = flat
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -114,6 +122,13 @@ class GradBuckets:
         if self.world_size <= 1 and not self.force:
             return
         for s in (self.slices if i is None else [self.slices[i]]):
+            if not self._window and s.numel() * 4 >= self.window_bytes and (self.reserve_cus > 0 or self.window_hook is not None):
+                # what is launched (or captured) from here to wait() runs next to RCCL's channel kernels
+                self._window = True
+                self._base_reserved = reserved_cus()  # (a reservation made for the whole run, SRX_RESERVED_CUS, stays)
+                set_reserved_cus(max(self.reserve_cus, self._base_reserved))
+                if self.window_hook is not None:
+                    self.window_hook.begin()
             self._work.append(dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.issued += 1
 
@@ -121,6 +136,51 @@ class GradBuckets:
         for w in self._work:
             w.wait()  # stream-orders the compute stream after the collective (no host block on RCCL)
         self._work = []
+        if self._window:
+            self._window = False
+            if self.window_hook is not None:
+                self.window_hook.end()
+            set_reserved_cus(self._base_reserved)
+
+
+def reserved_cus() -> int:
+    """Compute units the launch plans currently leave free (device CUs less ``srx_plan_cus``)."""
+    from . import _lib
+    return max(0, int(_lib.lib().srx_device_cus()) - int(_lib.lib().srx_plan_cus()))
+
+
+def set_reserved_cus(k: int) -> None:
+    """Compute units the launch plans made from now on leave to someone else (``srx_set_reserved_cus``)."""
+    from . import _lib
+    _lib.call('srx_set_reserved_cus', int(k))
+
+
+# RCCL channels (= channel workgroups per collective kernel) of a data-parallel run, and the compute units the launch plans
+# leave to them while a large gradient bucket is on the wire.  The exchange has ~3.5 ms of compute to hide under (94 MB of
+# discriminator gradients go out before the VGG19 forward, the optimiser that needs them comes after it): 1.75 x 94 MB per
+# GPU in 3.5 ms is ~50 GB/s, a fraction of one xGMI link pair -- a few channels carry it, and every channel is a
+# workgroup that shares a CU with the convolutions.  RCCL's default (tens of channels) is sized for bandwidth benchmarks.
+DEFAULT_CHANNELS = 8
+
+
+def configure_comm(world_size: int, backend: str = 'nccl') -> dict:
+    """Call BEFORE ``init_process_group`` of a data-parallel run.  At world size > 1 on RCCL: bounds the channel count
+    (``NCCL_MIN_NCHANNELS`` / ``NCCL_MAX_NCHANNELS``; values already in the environment win, ``SRX_NCCL_CHANNELS`` sets both)
+    and returns what the trainers pass to ``GradBuckets(reserve_cus=...)`` (``SRX_COMM_RESERVED_CUS`` overrides; default one
+    CU per channel).  Nothing is left to chance silently: the returned dict is printed by ``bench.py`` and the CLI."""
+    import os
+    out = {'world_size': int(world_size), 'backend': backend, 'nccl_min_nchannels': os.environ.get('NCCL_MIN_NCHANNELS'),
+           'nccl_max_nchannels': os.environ.get('NCCL_MAX_NCHANNELS'), 'reserved_cus_in_comm_window': 0,
+           'window_bytes': GradBuckets.window_bytes}
+    if world_size <= 1 or backend != 'nccl':
+        return out
+    k = int(os.environ.get('SRX_NCCL_CHANNELS', str(DEFAULT_CHANNELS)))
+    os.environ.setdefault('NCCL_MIN_NCHANNELS', str(k))
+    os.environ.setdefault('NCCL_MAX_NCHANNELS', str(k))
+    out['nccl_min_nchannels'] = os.environ['NCCL_MIN_NCHANNELS']
+    out['nccl_max_nchannels'] = os.environ['NCCL_MAX_NCHANNELS']
+    out['reserved_cus_in_comm_window'] = int(os.environ.get('SRX_COMM_RESERVED_CUS', os.environ['NCCL_MAX_NCHANNELS']))
+    return out
 
 
 def GradAllReduce(flat, group: Optional[dist.ProcessGroup] = None) -> GradBuckets:

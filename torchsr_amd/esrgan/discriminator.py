@@ -27,9 +27,9 @@ class Discriminator(nn.Module):
             Linear(100, 1),
         )
 
-    def forward_nhwc(self, x4: Tensor, groups: int = 1) -> Tensor:
-        """``groups`` > 1: the batch holds that many forward calls of the reference back to back (``forward_pair``);
-        every BatchNorm then normalises each call's rows with their own statistics."""
+    def features_flat_nhwc(self, x4: Tensor, groups: int = 1) -> Tensor:
+        """``torch.flatten(self.features(x), 1)``.  ``groups`` > 1: the batch holds that many forward calls of the reference
+        back to back (``forward_pair``); every BatchNorm then normalises each call's rows with their own statistics."""
         mods = list(self.features)
         # the first conv's LeakyReLU backward rides in the second conv's (strided) data gradient: its output feeds nothing else
         fold = torch.is_grad_enabled() and mods[0]._st.act == ACT_LRELU and not _dev.NO_ACT_FOLD  # (developer switch)
@@ -49,9 +49,30 @@ class Discriminator(nn.Module):
             out = bn(y, part, act=ACT_LRELU, slope=0.2, groups=groups)
             i += 3
         out = F.cut_point('d.head', out)  # data parallel: classifier.* gradients are a bucket of their own
-        out = F.flatten_nchw(out)
+        return F.flatten_nchw(out)
+
+    def forward_nhwc(self, x4: Tensor, groups: int = 1) -> Tensor:
+        out = self.features_flat_nhwc(x4, groups)
         out = self.classifier[0](out, act=ACT_LRELU, slope=0.2)
         return self.classifier[2](out)
+
+    # ---- the classifier and the relativistic-average loss behind it as one autograd node (functional.gan_head,
+    # ---- csrc/head.hip): what the trainer calls; forward / forward_pair keep the reference's module surface (logits out)
+    def pair_loss_nhwc(self, real4: Tensor, fake4: Tensor):
+        """``(BCEWithLogits(D(real) - mean(D(fake)), 1) + BCEWithLogits(D(fake) - mean(D(real)), 0)) / 2``
+        (esrgan/trainer.py:448-453) on NHWC inputs; ``(loss, aux)``."""
+        n = real4.shape[0]
+        if fake4.shape != real4.shape or (self.training and not self._pair_fits(2 * n, real4.shape[1], real4.shape[2])):
+            flat = torch.cat([self.features_flat_nhwc(real4), self.features_flat_nhwc(fake4)], dim=0)
+        else:
+            flat = self.features_flat_nhwc(torch.cat([real4, fake4], dim=0), groups=2 if self.training else 1)
+        return F.gan_head(flat, self.classifier[0], self.classifier[2], F.HEAD_ESRGAN_D, n_first=n, slope=0.2)
+
+    def adversarial_loss_nhwc(self, fake4: Tensor, real_mean: Tensor, addend: Tensor, weight: float):
+        """``addend + weight * BCEWithLogits(D(fake) - real_mean, 1)`` (esrgan/trainer.py:464-469); ``(loss, aux)``."""
+        flat = self.features_flat_nhwc(fake4)
+        return F.gan_head(flat, self.classifier[0], self.classifier[2], F.HEAD_ESRGAN_G, slope=0.2, adv_weight=weight,
+                          shift=real_mean, addend=addend)
 
     def forward(self, x: Tensor) -> Tensor:
         return self.forward_nhwc(F.to_nhwc(x, 4))

@@ -37,27 +37,29 @@ class ESRGANTrainer(SRGANTrainer):
 
     def _phase_disc(self) -> None:
         """esrgan/trainer.py:444-455 (optimizer step is issued by ``_phase_gen`` after the all-reduce)."""
-        low_res, high_res = self._static['low_res'], self._static['high_res']
+        # the three networks exchange NHWC tensors (as in the SRGAN trainer): the batch is converted once, the super-resolved
+        # image never goes through the NCHW module boundary
+        with torch.no_grad():
+            low4 = F.to_nhwc(self._static['low_res'], 4)
+            self._high4 = F.to_nhwc(self._static['high_res'], 4)
         self.disc_optimizer.zero_grad()                                          # :444
         # The reference runs the generator twice per step (:447 and again at :462) on the same input with the same
         # weights -- only the discriminator is updated in between, and RRDBNet has no BatchNorm, dropout or other
         # state -- so the second forward reproduces the first bit for bit.  It is run once, with its graph kept for
         # the generator update (as the reference's own SRGAN loop does, srgan/trainer.py:444,455-456): 587 GFLOP and
         # ~700 launches per step that change no result.
-        self._super_res = self.generator(low_res)                                # :447 (and :462)
-        real_output, fake_output = self.discriminator.forward_pair(high_res, self._super_res.detach())  # :448-449
-        d_real = self.bce_loss(real_output, 1.0, shift=F.mean(fake_output))      # :451
-        d_fake = self.bce_loss(fake_output, 0.0, shift=F.mean(real_output))      # :452
-        disc_loss = F.axpby(d_real, d_fake, 0.5, 0.5)                            # :453
+        self._super_res = self.generator.forward_nhwc(low4)                      # :447 (and :462)
+        # :448-453 -- D(real), D(fake) as one batch; both relativistic terms and their mean in the head's launch
+        disc_loss, _ = self.discriminator.pair_loss_nhwc(self._high4, self._super_res.detach())
         self._backward(disc_loss)                                                # :455
         self._losses['gan/disc-loss'] = disc_loss.detach()
 
     def _phase_content(self) -> None:
         """esrgan/trainer.py:459-467: pixel and perceptual terms (the generator output of ``_phase_disc`` is reused)."""
-        high_res = self._static['high_res']
         self.gen_optimizer.zero_grad()                                           # :459
-        pixel = self.l1_loss(self._super_res, high_res)                          # :466
-        content = self.vgg_loss(self._super_res, high_res)                       # :467
+        # :466 -- the 4th NHWC channel is zero on both sides: the mean runs over the 3 real ones
+        pixel = self.l1_loss(self._super_res, self._high4, count=self._high4.numel() // 4 * 3)
+        content = self.vgg_loss.forward_nhwc(self._super_res, self._high4)       # :467
         self._content = F.axpby(pixel, content, 0.01, 1.0)
         self._losses['gan/pixel-loss'] = pixel.detach()
         self._losses['gan/content-loss'] = content.detach()
@@ -67,11 +69,10 @@ class ESRGANTrainer(SRGANTrainer):
         self.disc_optimizer.step()                                               # :456
         with no_weight_grad():
             with torch.no_grad():  # mean(real_output) carries no gradient to the generator
-                real_mean = F.mean(self.discriminator(self._static['high_res']))  # :463
-            fake_output = self.discriminator(self._super_res)                    # :464
-        adversarial = self.bce_loss(fake_output, 1.0, shift=real_mean)           # :468
-        gen_loss = F.axpby(self._content, adversarial, 1.0, 0.005)               # :469
+                real_mean = F.mean(self.discriminator.forward_nhwc(self._high4))  # :463
+            # :464,468-469 -- gen_loss = 0.01 * pixel + content + 0.005 * BCEWithLogits(D(fake) - mean(D(real)), 1)
+            gen_loss, aux = self.discriminator.adversarial_loss_nhwc(self._super_res, real_mean, self._content, 0.005)
         self._backward(gen_loss)                                                 # :480
-        self._losses['gan/adversarial-loss'] = adversarial.detach()
+        self._losses['gan/adversarial-loss'] = aux[1]
         self._losses['gan/train-loss'] = gen_loss.detach()
-        self._super_res = self._content = None
+        self._super_res = self._content = self._high4 = None

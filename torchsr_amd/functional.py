@@ -16,7 +16,8 @@ from torch import Tensor
 from torch.autograd import Function
 
 from . import _dev, _lib
-from ._lib import ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, Conv2dDesc, call
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, HEAD_ESRGAN_D, HEAD_ESRGAN_G, HEAD_SRGAN_D, HEAD_SRGAN_G,  # noqa: F401
+                   Conv2dDesc, call)
 
 import ctypes as C
 
@@ -502,7 +503,7 @@ class _Conv2d(Function):
             # the bias gradient rides along in the weight-gradient kernel (it stages every dy row anyway)
             # when both results go the same way: both accumulated into .grad, or both returned
             bptr = None
-            if ctx.has_bias and ctx.needs_input_grad[2] and not st.shuffle:
+            if ctx.has_bias and ctx.needs_input_grad[2]:  # (PixelShuffle layers too: the reduction maps packed columns back)
                 bsink = _sink(bparam)
                 if (bsink is None) == (sink is None):
                     if bsink is None:
@@ -1244,19 +1245,111 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor], act: int = ACT_NONE, sl
     return _Linear.apply(x, w, bias, act, float(slope))
 
 
-# --------------------------------------------------------------------------- losses
-class _PairLoss(Function):
-    """mean((a-b)^2) / mean(|a-b|)"""
+class _GanHead(Function):
+    """Discriminator head + adversarial loss of a GAN train step as ONE autograd node (csrc/head.hip):
+    ``hidden = LeakyReLU(Linear1(x))`` on the streaming linear kernels, then last Linear -> [Sigmoid] -> loss in one
+    launch, and in the backward pass one launch for everything between the loss and the hidden layer's pre-activation
+    (loss, sigmoid, last Linear, LeakyReLU backwards; both bias gradients and the last weight gradient) followed by the
+    hidden layer's data and weight gradients.  Returns ``(loss, aux)``; ``aux`` (8 floats, no gradient) holds the terms.
+    """
 
     @staticmethod
-    def forward(ctx, a: Tensor, b: Tensor, kind: str):
+    def forward(ctx, x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], mode: int, n_first: int,
+                slope: float, adv_weight: float, shift: Optional[Tensor], addend: Optional[Tensor]):
+        ctx.set_materialize_grads(False)
+        x = _chk(x, 'gan_head.input')
+        w1d, w2d = _chk(w1.detach(), 'gan_head.weight1'), _chk(w2.detach(), 'gan_head.weight2')
+        bsz, k = x.shape
+        j = w1d.shape[0]
+        if w2d.numel() != j:
+            raise RuntimeError(f'gan_head: the last layer must map {j} hidden units to ONE output, got {tuple(w2d.shape)}')
+        s = _stream()
+        hidden = torch.empty((bsz, j), dtype=torch.float32, device=x.device)
+        nws = _lib.lib().srx_linear_ws_floats(bsz, k, j)
+        b1d = None if b1 is None else _chk(b1.detach(), 'gan_head.bias1')
+        b2d = None if b2 is None else _chk(b2.detach(), 'gan_head.bias2')
+        call('srx_linear_fwd', _p(x), _p(w1d), _p(b1d), _p(hidden), bsz, k, j, ACT_LRELU, slope, _p(_ws(nws, x)), nws, s)
+        h = _lib.GanHead(mode, bsz, j, n_first, slope, adv_weight)
+        zp = torch.empty(bsz, dtype=torch.float32, device=x.device)
+        out = torch.empty(8, dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        sh = None if shift is None else _chk(shift.detach().reshape(1), 'gan_head.shift')
+        ad = None if addend is None else _chk(addend.detach().reshape(1), 'gan_head.addend')
+        call('srx_gan_head_fwd', C.byref(h), _p(hidden), _p(w2d), _p(b2d), _p(sh), _p(ad), _p(zp), _p(out), _p(loss), s)
+        ctx.h, ctx.nws = h, nws
+        ctx.params = (w1, b1, w2, b2)
+        ctx.save_for_backward(x, w1d, w2d, hidden, zp, out, sh)
+        ctx.mark_non_differentiable(out)
+        return loss, out
+
+    @staticmethod
+    def backward(ctx, g: Tensor, _gaux=None):
+        x, w1, w2, hidden, zp, out, sh = ctx.saved_tensors
+        h = ctx.h
+        bsz, k = x.shape
+        j = h.J
+        s = _stream()
+        g = _chk(g, 'gan_head.grad').reshape(1)
+        w1p, b1p, w2p, b2p = ctx.params
+        need = ctx.needs_input_grad  # (x, w1, b1, w2, b2, ..., shift, addend)
+        dw1 = db1 = dw2 = db2 = None
+        sinks = [(_sink(p) if (p is not None and need[i + 1]) else None) for i, p in enumerate(ctx.params)]
+        wanted = [p is not None and need[i + 1] for i, p in enumerate(ctx.params)]
+        # the small gradients either ALL accumulate into flat .grad buffers (the trainers) or are all returned
+        direct = all(sk is not None for sk, wnt in zip(sinks, wanted) if wnt) and any(wanted)
+        ptrs = [None, None, None, None]
+        if not direct:
+            if wanted[1]:
+                db1 = torch.empty(j, dtype=torch.float32, device=x.device)
+            if wanted[2]:
+                dw2 = torch.empty_like(w2)
+            if wanted[3]:
+                db2 = torch.empty(1, dtype=torch.float32, device=x.device)
+            ptrs = [None, _p(db1), _p(dw2), _p(db2)]
+        else:
+            ptrs = [None] + [_p(sk) if wnt else None for sk, wnt in list(zip(sinks, wanted))[1:]]
+        dpre = torch.empty((bsz, j), dtype=torch.float32, device=x.device)
+        call('srx_gan_head_bwd', C.byref(h), _p(hidden), _p(w2), _p(zp), _p(out), _p(sh), _p(g), _p(dpre), ptrs[2], ptrs[3],
+             ptrs[1], 1 if direct else 0, s)
+        dx = None
+        if need[0]:
+            dx = torch.empty_like(x)
+            call('srx_linear_bwd_data', _p(dpre), _p(w1), _p(dx), bsz, k, j, _p(_ws(ctx.nws, x)), ctx.nws, s)
+        if wanted[0]:
+            sink = sinks[0] if direct else None
+            if sink is None:
+                dw1 = torch.empty_like(w1)
+            call('srx_linear_bwd_weight', _p(x), _p(dpre), _p(dw1 if sink is None else sink), 0 if sink is None else 1, bsz, k, j, s)
+        dadd = g.view(()) if need[10] else None
+        return dx, dw1, db1, (None if dw2 is None else dw2.view_as(w2p)), db2, None, None, None, None, None, dadd
+
+
+def gan_head(x: Tensor, lin1, lin2, mode: int, n_first: int = 0, slope: float = 0.2, adv_weight: float = 1.0,
+             shift: Optional[Tensor] = None, addend: Optional[Tensor] = None):
+    """``(loss, aux)`` of a discriminator's classifier (``lin1`` -> LeakyReLU -> ``lin2`` [-> Sigmoid]) and the adversarial
+    loss behind it on the flattened features ``x`` [B, K]; modes and ``aux`` layout: ``srx_gan_head_t`` in include/srx.h.
+    ``lin1`` / ``lin2`` are ``layers.Linear`` modules (``no_weight_grad`` is honoured)."""
+    from .layers import _w
+    return _GanHead.apply(x, _w(lin1.weight), _w(lin1.bias), _w(lin2.weight), _w(lin2.bias), int(mode), int(n_first), float(slope),
+                          float(adv_weight), shift, addend)
+
+
+# --------------------------------------------------------------------------- losses
+class _PairLoss(Function):
+    """mean((a-b)^2) / mean(|a-b|); ``count``: the mean's divisor when not every stored element is a real one"""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor, kind: str, count: int = 0):
         ctx.set_materialize_grads(False)
         a, b = _chk(a, f'{kind}.input'), _chk(b, f'{kind}.target')
         if a.shape != b.shape:
             raise RuntimeError(f'{kind}_loss: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}')
         loss = torch.empty((), dtype=torch.float32, device=a.device)
-        call(f'srx_{kind}_fwd', _p(a), _p(b), _p(loss), a.numel(), _p(_ws(2048, a)), _stream())
-        ctx.kind = kind
+        if count:
+            call(f'srx_{kind}_fwd_count', _p(a), _p(b), _p(loss), a.numel(), count, _p(_ws(2048, a)), _stream())
+        else:
+            call(f'srx_{kind}_fwd', _p(a), _p(b), _p(loss), a.numel(), _p(_ws(2048, a)), _stream())
+        ctx.kind, ctx.count = kind, count
         ctx.save_for_backward(a, b)
         return loss
 
@@ -1266,8 +1359,11 @@ class _PairLoss(Function):
         g = _chk(g, 'loss.grad')
         da = torch.empty_like(a)
         db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
-        call(f'srx_{ctx.kind}_bwd', _p(a), _p(b), _p(g), _p(da), _p(db), a.numel(), _stream())
-        return (da if ctx.needs_input_grad[0] else None), db, None
+        if ctx.count:
+            call(f'srx_{ctx.kind}_bwd_count', _p(a), _p(b), _p(g), _p(da), _p(db), a.numel(), ctx.count, _stream())
+        else:
+            call(f'srx_{ctx.kind}_bwd', _p(a), _p(b), _p(g), _p(da), _p(db), a.numel(), _stream())
+        return (da if ctx.needs_input_grad[0] else None), db, None, None
 
 
 def mse_loss(a: Tensor, b: Tensor) -> Tensor:
@@ -1275,9 +1371,10 @@ def mse_loss(a: Tensor, b: Tensor) -> Tensor:
     return _PairLoss.apply(a, b, 'mse')
 
 
-def l1_loss(a: Tensor, b: Tensor) -> Tensor:
-    """F.l1_loss / nn.L1Loss() (srgan/loss.py:52)."""
-    return _PairLoss.apply(a, b, 'l1')
+def l1_loss(a: Tensor, b: Tensor, count: int = 0) -> Tensor:
+    """F.l1_loss / nn.L1Loss() (srgan/loss.py:52).  ``count``: divisor of the mean when the tensors carry padding (NHWC images
+    with a zero 4th channel: ``count = 3 * pixels``)."""
+    return _PairLoss.apply(a, b, 'l1', int(count))
 
 
 class _BCE(Function):

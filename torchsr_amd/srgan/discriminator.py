@@ -28,9 +28,9 @@ class Discriminator(nn.Module):
             Marker('Sigmoid'),
         )
 
-    def forward_nhwc(self, x4: Tensor, groups: int = 1) -> Tensor:
-        """``groups`` > 1: the batch holds that many forward calls of the reference back to back (``forward_pair``);
-        every BatchNorm then normalises each call's rows with their own statistics."""
+    def features_flat_nhwc(self, x4: Tensor, groups: int = 1) -> Tensor:
+        """``torch.flatten(self.features(x), 1)``.  ``groups`` > 1: the batch holds that many forward calls of the reference
+        back to back (``forward_pair``); every BatchNorm then normalises each call's rows with their own statistics."""
         mods = list(self.features)
         # the first conv's LeakyReLU backward rides in the second conv's (strided) data gradient: its output feeds nothing else
         fold = torch.is_grad_enabled() and mods[0]._st.act == ACT_LRELU and not _dev.NO_ACT_FOLD  # (developer switch)
@@ -50,10 +50,30 @@ class Discriminator(nn.Module):
             out = bn(y, part, act=ACT_LRELU, slope=0.2, groups=groups)
             i += 3
         out = F.cut_point('d.head', out)  # data parallel: classifier.* gradients are a bucket of their own
-        out = F.flatten_nchw(out)  # torch.flatten(out, 1) in NCHW order, discriminator.py:86
+        return F.flatten_nchw(out)  # torch.flatten(out, 1) in NCHW order, discriminator.py:86
+
+    def forward_nhwc(self, x4: Tensor, groups: int = 1) -> Tensor:
+        out = self.features_flat_nhwc(x4, groups)
         out = self.classifier[0](out, act=ACT_LRELU, slope=0.2)
         out = self.classifier[2](out)
         return F.sigmoid(out)
+
+    # ---- the classifier and the adversarial loss behind it as one autograd node (functional.gan_head, csrc/head.hip): what
+    # ---- the trainers call; forward / forward_pair above keep the reference's module surface (probabilities out)
+    def pair_loss_nhwc(self, real4: Tensor, fake4: Tensor):
+        """``BCELoss(self(real), 1) + BCELoss(self(fake), 0)`` (srgan/trainer.py:446-448) on NHWC inputs; ``(loss, aux)``."""
+        n = real4.shape[0]
+        if fake4.shape != real4.shape or (self.training and not self._pair_fits(2 * n, real4.shape[1], real4.shape[2])):
+            flat = torch.cat([self.features_flat_nhwc(real4), self.features_flat_nhwc(fake4)], dim=0)
+        else:
+            flat = self.features_flat_nhwc(torch.cat([real4, fake4], dim=0), groups=2 if self.training else 1)
+        return F.gan_head(flat, self.classifier[0], self.classifier[2], F.HEAD_SRGAN_D, n_first=n, slope=0.2)
+
+    def adversarial_loss_nhwc(self, fake4: Tensor, addend: Tensor, weight: float):
+        """``addend + weight * BCELoss(self(fake), 1)`` (srgan/trainer.py:456-457); ``(loss, aux)``, ``aux[1]`` = the BCE term."""
+        flat = self.features_flat_nhwc(fake4)
+        return F.gan_head(flat, self.classifier[0], self.classifier[2], F.HEAD_SRGAN_G, slope=0.2, adv_weight=weight,
+                          addend=addend)
 
     def forward(self, x: Tensor) -> Tensor:
         return self.forward_nhwc(F.to_nhwc(x, 4))

@@ -72,7 +72,8 @@ class LossRing:
         self.ring = self._buf[:cap * 4]
         self.counter = self._buf[cap * 4:cap * 4 + 1].view(torch.int32)
         self.read = 0        # device records accounted for (flushed or skipped)
-        self.pending = []    # [(key, step, other contents)] in push order
+        self.pushed = 0      # records the HOST knows were pushed (one per train step, counted where the step is issued)
+        self.pending = []    # [(key, step, other contents, record index)] in push order
         self.unnoted = 0     # pushes that never got a note (direct step calls outside the training loops)
 
     def push(self, loss: Tensor) -> None:
@@ -80,30 +81,44 @@ class LossRing:
         F.call('srx_ring_push', loss.data_ptr(), None, None, None, 1, self.ring.data_ptr(), self.counter.data_ptr(),
                self.cap, torch.cuda.current_stream().cuda_stream)
 
+    def mark_push(self) -> None:
+        """Host side, once per issued step (a replayed graph pushes without any host code of ``push`` running)."""
+        self.pushed += 1
+
     def note(self, key: str, step: int, contents: dict) -> bool:
-        """Host side, once per pushed record; True when the ring is full and must be flushed."""
-        self.pending.append((key, step, contents))
-        return len(self.pending) >= self.cap
+        """Host side, right after the step whose record this is; True when the ring must be flushed before it wraps.  The
+        note remembers WHICH record it belongs to (the last one issued), so a step that pushed without being noted -- a direct
+        ``gan_step`` between two loop steps -- cannot shift the samples behind it onto the wrong step."""
+        self.pending.append((key, step, contents, self.pushed - 1))
+        return self.pushed - self.pending[0][3] >= self.cap
 
     def flush(self, log) -> None:
-        """Deliver the pending samples.  The device counter (read in the same copy as the ring) is the truth about how many
-        records exist: a ``gan_step`` / ``pretrain_step`` called directly (bench, tests, user code) pushes without a note, and a
-        step that raises between its push and its note does too -- the pending notes are then the LAST ``len(pending)`` records
-        (the training loops note right after their push), never a slot counted from a host-side guess, and ``read`` is
-        resynchronised from the counter."""
+        """Deliver the pending samples: one device -> host copy (none when nothing is pending).  The device counter, read in
+        the same copy as the ring, is checked against the host's count of issued pushes; a disagreement (a step that raised
+        between its push and the host's mark) is reported and the mapping falls back to "the last len(pending) records"."""
+        if not self.pending:
+            self.unnoted += self.pushed - self.read  # (host bookkeeping only: no copy, no sync)
+            self.read = self.pushed
+            return
         host = self._buf.cpu()  # the one sync
         count = int(host[self.cap * 4:self.cap * 4 + 1].view(torch.int32)[0])
         n = len(self.pending)
-        extra = count - self.read - n
-        if extra < 0:
-            raise RuntimeError(f'LossRing: {n} samples noted but the device pushed only {count - self.read} records')
-        self.unnoted += extra
-        if n > self.cap:
-            raise RuntimeError(f'LossRing: {n} samples pending in a ring of {self.cap} slots (flush when note() says so)')
+        if count < n:
+            raise RuntimeError(f'LossRing: {n} samples noted but the device pushed only {count} records')
+        index = [p[3] for p in self.pending]
+        if count != self.pushed:
+            import warnings
+            warnings.warn(f'LossRing: the device holds {count} records, the host issued {self.pushed}; mapping the {n} pending '
+                          'samples to the last records', stacklevel=2)
+            index = list(range(count - n, count))
+            self.pushed = count
+        if count - min(index) > self.cap:
+            raise RuntimeError(f'LossRing: a pending sample is {count - min(index)} records old in a ring of {self.cap} slots '
+                               '(flush when note() says so)')
+        self.unnoted += (count - self.read) - n
         values = host[:self.cap * 4].view(self.cap, 4)[:, 0]
-        first = count - n
-        for i, (key, step, contents) in enumerate(self.pending):
-            log({**contents, key: float(values[(first + i) % self.cap])}, step=step)
+        for (key, step, contents, _), idx in zip(self.pending, index):
+            log({**contents, key: float(values[idx % self.cap])}, step=step)
         self.read = count
         self.pending = []
 
@@ -148,6 +163,10 @@ class SRGANTrainer:
         self.vgg_weights = getattr(args, 'vgg_weights', None)
         # issue the gradient all-reduces even at world size 1 (a one-GPU rehearsal of the RCCL path)
         self.force_collectives = bool(getattr(args, 'force_collectives', False))
+        # compute units the launch plans leave to RCCL's channel workgroups while a large gradient bucket is on the wire
+        # (ddp.configure_comm decides; 0 at world size 1) and an optional rehearsal hook around those windows
+        self.comm_reserved_cus = int(getattr(args, 'comm_reserved_cus', 0) or 0)
+        self.comm_window_hook = getattr(args, 'comm_window_hook', None)
         if self.device.type != 'cuda':
             raise RuntimeError('torchsr_amd trains on an MI355X (device "cuda"); there is no CPU path')
         if self.device.index is None:
@@ -157,6 +176,8 @@ class SRGANTrainer:
         if self.save_image and self.main_process and not os.path.exists('output'):
             os.makedirs('output')
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+        self._graph_tables: Dict[str, tuple] = {}  # pack-table generations each graph was captured with
+        self._eager_steps = 0                      # steps to run without graphs (after a phase switch)
         self._graph_pool = None
         self._calls: Dict[str, int] = {}
         self._static: Dict[str, Tensor] = {}
@@ -183,6 +204,11 @@ class SRGANTrainer:
         precision, so switching costs nothing; each phase has its own captured hipGraphs."""
         if phase == self._phase:
             return
+        if self._graphs:
+            # A replayed graph repacks, after its Adam step, exactly the weights ITS phase's kernels read (a phase whose dense
+            # blocks run fused keeps their fp32 packs out of its table); the other phase's graphs would then start on stale
+            # packs.  One eager step after a switch goes through the lazy per-layer check and refreshes whatever is stale.
+            self._eager_steps = 1
         self._phase = phase
         precision = 'bf16' if (self.amp and phase in self.amp_phases) else 'fp32'
         for module in (self.generator, self.discriminator, self.vgg_loss):
@@ -200,9 +226,9 @@ class SRGANTrainer:
         # gradient buckets in parameter order: [0] = the body (complete LAST in the backward pass), [1] = the slice
         # autograd completes first (the generator's sub-pixel tail, the discriminator's classifier)
         force = self.force_collectives
-        self.gen_sync = GradBuckets(self.gen_flat, (self.gen_tail_bucket,), self.generator, force=force) \
-            if self.distributed else None
-        self.disc_sync = GradBuckets(self.disc_flat, (self.disc_head_bucket,), self.discriminator, force=force) \
+        kw = {'force': force, 'reserve_cus': self.comm_reserved_cus, 'window_hook': self.comm_window_hook}
+        self.gen_sync = GradBuckets(self.gen_flat, (self.gen_tail_bucket,), self.generator, **kw) if self.distributed else None
+        self.disc_sync = GradBuckets(self.disc_flat, (self.disc_head_bucket,), self.discriminator, **kw) \
             if self.distributed else None
 
     def _initialize_loss(self) -> None:
@@ -299,10 +325,18 @@ class SRGANTrainer:
 
     def _exec(self, key: str, fn: Callable[[], None]) -> None:
         """Run ``fn`` eagerly (first two calls: warm-up) and from then on as a replayed hipGraph."""
-        if not self.use_graphs:
+        if not self.use_graphs or self._eager_steps > 0:
             fn()
             return
         g = self._graphs.get(key)
+        if g is not None and self._graph_tables.get(key) != self._table_generations():
+            # a pack table was rebuilt since the capture (the set of fused-only convs changed): the graph holds the freed
+            # table's address and record count -- drop it, run this call eagerly and capture again at the next one
+            del self._graphs[key]
+            self._calls[key] = 2
+            g = None
+            fn()
+            return
         if g is not None:
             g.replay()
             F.bump_pack_epoch()  # the replay ran Adam: packed weights seen by eager code are stale
@@ -334,7 +368,17 @@ class SRGANTrainer:
             fn()
             return
         self._graphs[key] = g
+        self._graph_tables[key] = self._table_generations()
         g.replay()  # capture records without executing; run this step's work now
+
+    def _table_generations(self):
+        """(re)build counters of the pack tables a captured step replays (functional.PackTable.generation)"""
+        return tuple(getattr(opt, 'pack_table', None).generation if getattr(opt, 'pack_table', None) is not None else -1
+                     for opt in (self.gen_optimizer, self.disc_optimizer))
+
+    def _end_step(self) -> None:
+        if self._eager_steps > 0:
+            self._eager_steps -= 1
 
     def _stage(self, name: str, value: Tensor) -> Tensor:
         """Copy a batch into a persistent device buffer (graph replays read fixed addresses)."""
@@ -351,8 +395,12 @@ class SRGANTrainer:
     def _backward(self, loss: Tensor) -> None:
         """``loss.backward()`` with the conv weight gradients of the pass collected and issued together at its end
         (``functional.WeightGradQueue``): they are off the critical path until the optimiser step."""
+        # (the root gradient is a persistent 1.0 on the device: autograd's own ones_like is a fill launch per backward pass)
+        one = self.__dict__.get('_one')
+        if one is None:
+            one = self._one = torch.ones((), dtype=torch.float32, device=self.device)
         with F.deferred_weight_grads():
-            loss.backward()
+            loss.backward(one)
 
     def _resume(self, cut: str) -> None:
         with F.deferred_weight_grads():
@@ -405,6 +453,9 @@ class SRGANTrainer:
         else:
             self._exec('psnr.all', lambda: (self._pretrain_body(), self.psnr_optimizer.step(),
                                             self._push_loss('psnr/train-loss')))
+        self._end_step()
+        if self._ring is not None:
+            self._ring.mark_push()
         return self._losses['psnr/train-loss']
 
     def _pretrain(self) -> None:
@@ -451,10 +502,9 @@ class SRGANTrainer:
             self._high4 = F.to_nhwc(self._static['high_res'], 4)
         self.disc_optimizer.zero_grad()                                      # :442
         self._super_res = self.generator.forward_nhwc(low4)                  # :444
-        p_real, p_fake = self.discriminator.forward_pair_nhwc(self._high4, self._super_res.detach())  # :446-447 as one batch
-        d_real = self.bce_loss(p_real, 1.0)                                  # :446
-        d_fake = self.bce_loss(p_fake, 0.0)                                  # :447
-        disc_loss = F.axpby(d_real, d_fake, 1.0, 1.0)                        # :448
+        # :446-448 -- D(real) and D(fake) as one batch; classifier tail, Sigmoid, both BCE terms and their sum are one launch
+        # forward and one backward (functional.gan_head)
+        disc_loss, _ = self.discriminator.pair_loss_nhwc(self._high4, self._super_res.detach())
         self._backward(disc_loss)                                            # :450
         self._losses['gan/disc-loss'] = disc_loss.detach()
 
@@ -471,11 +521,11 @@ class SRGANTrainer:
         'g.tail' cut when data parallel)."""
         self.disc_optimizer.step()                                           # :451
         with no_weight_grad():  # C5: D's weight gradients are never consumed here
-            adversarial = self.bce_loss(self.discriminator.forward_nhwc(self._super_res), 1.0)  # :456
-        gen_loss = F.axpby(self._content, adversarial, 1.0, 0.001)           # :457
+            # :456-457 -- gen_loss = content + 0.001 * BCELoss(D(G(lr)), 1), formed in the discriminator head's launch
+            gen_loss, aux = self.discriminator.adversarial_loss_nhwc(self._super_res, self._content, 0.001)
         self._backward(gen_loss)                                             # :468
         self._losses['gan/content-loss'] = self._content.detach()
-        self._losses['gan/adversarial-loss'] = adversarial.detach()
+        self._losses['gan/adversarial-loss'] = aux[1]
         self._losses['gan/train-loss'] = gen_loss.detach()
         self._super_res = self._content = self._high4 = None
 
@@ -520,6 +570,9 @@ class SRGANTrainer:
                 self._cuts.clear()  # a segment that raised between a cut and its resume must not leak into the next step
         else:
             self._exec('gan.all', self._gan_all)
+        self._end_step()
+        if self._ring is not None:
+            self._ring.mark_push()
         return self._losses
 
     def _gan_loop(self, low_res: Tensor, high_res: Tensor, step: int) -> None:

@@ -143,10 +143,13 @@ def main(argv=None) -> None:
             os.environ['MASTER_ADDR'] = args.master_addr
         if args.master_port:
             os.environ['MASTER_PORT'] = args.master_port
-        dist.init_process_group(backend='nccl' if device.type == 'cuda' else 'gloo')
+        from torchsr_amd.ddp import configure_comm, describe_group
+        backend = 'nccl' if device.type == 'cuda' else 'gloo'
+        comm = configure_comm(int(args.world_size), backend)  # RCCL channel bounds + CUs left to them, BEFORE the group exists
+        args.comm_reserved_cus = comm['reserved_cus_in_comm_window']
+        dist.init_process_group(backend=backend)
         if args.rank == 0:
-            from torchsr_amd.ddp import describe_group
-            print(f'process group: {describe_group()}')
+            print(f'process group: {describe_group()}; communication: {comm}')
     args.use_graphs = not args.no_graphs
     from torchsr_amd.dataset import initialize_datasets, initialize_device_datasets
     if args.device_data:
