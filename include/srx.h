@@ -438,6 +438,29 @@ int srx_bn_act_bwd(const float* dout, const float* y, const float* mean, const f
                    const float* prelu, int training, float* dgamma_acc, float* dbeta_acc, float* dprelu_acc,
                    float* ws, size_t ws_floats, void* stream);
 
+/* ------------------------------------------------- Winograd F(2x2, 3x3) (round 5) */
+/* nn.Conv2d(Cin, Cout, 3, 1, 1) of wide layers -- the VGG19 feature extractor of the perceptual loss (srgan/loss.py:30-54;
+ * torchvision cfg 'E') -- with 2.25x fewer multiplications than the direct form, all in fp32 (results differ from the direct
+ * fp32 convolution by rounding only: ~5e-7 of the tensor's scale).  Layers: 3x3 / stride 1 / pad 1, precision 0, Cin and Cout
+ * multiples of 32 with channel strides equal to them, even H and W, act NONE or RELU (srx_wino_applicable).
+ *   pack:     upk = G g G^T of every channel pair, srx_wino_packed_floats(d) floats, in the order the kernel's waves load it;
+ *             transpose = 1 packs the layer's DATA GRADIENT (a 3x3 / pad 1 conv of dy with the channels swapped and the taps flipped)
+ *   fwd:      y = act(conv(x) + bias)
+ *   bwd_data: dx = conv^T(dy), multiplied by the ReLU mask (relu_out > 0, laid out like dx; NULL: none) of the layer below -- the
+ *             fold srx_conv2d_bwd_data_act does for the direct kernel
+ * ws: srx_wino_ws_floats(d, which) floats (which: 0 forward, 1 data gradient; non-zero when the planner splits the input
+ * channels over several workgroups).  x != y.  srx_wino_plan: out[6] = {BN, channel splits, workgroups, tile blocks, chunks per
+ * workgroup, 0} (host only). */
+int srx_wino_applicable(const srx_conv2d_t* d);
+size_t srx_wino_packed_floats(const srx_conv2d_t* d);
+size_t srx_wino_ws_floats(const srx_conv2d_t* d, int which);
+int srx_wino_plan(const srx_conv2d_t* d, int which, int* out);
+int srx_wino_pack(const srx_conv2d_t* d, const float* w_oihw, float* upk, int transpose, void* stream);
+int srx_wino_fwd(const srx_conv2d_t* d, const float* x, const float* upk, const float* bias, float* y, float* ws, size_t ws_floats,
+                 void* stream);
+int srx_wino_bwd_data(const srx_conv2d_t* d, const float* dy, const float* upk_t, const float* relu_out, float* dx, float* ws,
+                      size_t ws_floats, void* stream);
+
 /* ----------------------------------------------------------------- pooling */
 /* nn.MaxPool2d(2,2) of VGG19 (torchvision cfg 'E', srgan/loss.py:30-31); H, W even */
 int srx_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);

@@ -446,3 +446,44 @@ def test_rrdb_modules_alone_equal_the_trunk_node(dev, bf16):
             assert rel2(a, b) < max(far_a, far_b) and far_b < max(2 * far_a, 1e-2), (name, rel2(a, b), far_a, far_b)
         else:
             assert rel(a, b) < 2e-5, (name, rel(a, b))
+
+
+def test_graphs_survive_a_switch_between_phases_with_other_pack_tables(dev):
+    """Round-4 advice: a pre-training graph captured with fused dense blocks (bf16 products: their convs' fp32 packs are left
+    out of the repack table) and a GAN graph captured in exact fp32 (all convs in the table) replay different repack work after
+    their Adam steps; switching between them must neither replay a graph that holds a freed table nor start a step on stale
+    packed weights.  A trainer that autocasts ONLY the pre-training phase (as the reference's SRGAN trainer does) alternates
+    the two with hipGraphs on; every loss must equal the graph-free trainer's, which repacks lazily per layer."""
+    from torchsr_amd.esrgan.trainer import ESRGANTrainer
+
+    class PsnrOnlyAmp(ESRGANTrainer):
+        amp_phases = ('psnr',)
+
+    def build(use_graphs):
+        torch.manual_seed(0)
+        args = Namespace(disable_amp=False, batch_size=2, epochs=8, gan_checkpoint=None, local_rank=0, pretrain_epochs=1,
+                         psnr_checkpoint=None, skip_image_save=True, world_size=1, rank=-1, use_graphs=use_graphs,
+                         vgg_weights='random')
+        t = PsnrOnlyAmp(dev, args, [], [], 2, 2, distributed=False)
+        t.generator.load_state_dict(step_state(t.generator.state_dict(), 'esrgan.G'))
+        t.discriminator.load_state_dict(step_state(t.discriminator.state_dict(), 'esrgan.D'))
+        t.generator.train()
+        t.discriminator.train()
+        return t
+
+    lr, hr = seeded_input((2, 3, 32, 32), 5).to(dev), seeded_input((2, 3, 128, 128), 6).to(dev)
+    plan = ['psnr'] * 4 + ['gan'] * 4 + ['psnr'] * 3 + ['gan'] * 3 + ['psnr', 'gan', 'psnr', 'gan']
+    out = {}
+    for use_graphs in (False, True):
+        t = build(use_graphs)
+        vals = []
+        for ph in plan:
+            if ph == 'psnr':
+                vals.append(float(t.pretrain_step(lr, hr)))
+            else:
+                vals.append(float(t.gan_step(lr, hr)['gan/train-loss']))
+        out[use_graphs] = vals
+        if use_graphs:
+            assert t._graphs, 'the graph trainer never captured'
+    for i, (a, b) in enumerate(zip(out[False], out[True])):
+        assert abs(a - b) <= 1e-6 * max(abs(a), 1e-6), (i, plan[i], a, b)  # (same kernels, same order: equal unless a pack was stale)

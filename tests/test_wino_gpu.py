@@ -1,0 +1,115 @@
+"""Winograd F(2x2, 3x3) convolution (csrc/wino.hip) through the C ABI against stock torch fp64 on CPU: forward with bias + ReLU
+(torchvision VGG19 cfg 'E' layers, srgan/loss.py:30-31) and the data gradient with the ReLU mask of the layer below folded in.
+The arithmetic is fp32 throughout; what differs from the direct convolution is the order of operations, so the tolerance is a
+few fp32 roundings of the tensor's scale (2e-5), as for the exact-fp32 direct kernels."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-9)).item()
+
+
+CASES = [
+    # N, H, W, Cin, Cout
+    (2, 24, 24, 64, 64),     # VGG conv1_2 geometry (2304-tile rows cut into 32-tile blocks)
+    (2, 12, 12, 256, 256),   # conv3_x
+    (1, 6, 6, 512, 512),     # conv5_x: 9 tiles, the planner splits the input channels
+    (1, 10, 6, 128, 96),     # 15 tiles (a partial block), 96 output channels -> 32-column workgroups
+    (3, 8, 20, 32, 160),     # one chunk of input channels
+    (16, 24, 24, 256, 256),  # the training batch's data-gradient size
+]
+
+
+@pytest.mark.parametrize('cfg', CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_winograd_forward_and_data_gradient(dev, cfg):
+    from torchsr_amd import _lib
+    n, h, w, cin, cout = cfg
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, cin, h, w, generator=g).relu()             # a ReLU output, like every VGG layer's input
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    dy = torch.randn(n, cout, h, w, generator=g)
+    xr = x.double().requires_grad_(True)
+    yr = TF.relu(TF.conv2d(xr, wt.double(), bias.double(), padding=1))
+    pre = TF.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    # data gradient of the conv alone for an output gradient dy, then the mask of the ReLU that produced x
+    dx_plain = torch.autograd.grad(TF.conv2d(xr, wt.double(), None, padding=1), xr, dy.double())[0]
+    dx_masked = dx_plain * (x.double() > 0)
+
+    d = _lib.Conv2dDesc(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, _lib.ACT_RELU, 0.0, 0, 0)
+    dref = C.byref(d)
+    assert L.srx_wino_applicable(dref) == 1
+    s = torch.cuda.current_stream().cuda_stream
+    nf = L.srx_wino_packed_floats(dref)
+    assert nf == 16 * cin * cout
+    wg = wt.to(dev)
+    uf, ub = torch.empty(nf, device=dev), torch.empty(nf, device=dev)
+    _lib.call('srx_wino_pack', dref, wg.data_ptr(), uf.data_ptr(), 0, s)
+    _lib.call('srx_wino_pack', dref, wg.data_ptr(), ub.data_ptr(), 1, s)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    y = torch.empty(n, h, w, cout, device=dev)
+    nws = L.srx_wino_ws_floats(dref, 0)
+    ws = torch.empty(max(nws, 4), device=dev)
+    _lib.call('srx_wino_fwd', dref, xg.data_ptr(), uf.data_ptr(), bias.to(dev).data_ptr(), y.data_ptr(), ws.data_ptr(), nws, s)
+    assert rel(y.permute(0, 3, 1, 2), yr) < 2e-5
+    # no activation, no bias: the raw convolution
+    d0 = _lib.Conv2dDesc(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, _lib.ACT_NONE, 0.0, 0, 0)
+    _lib.call('srx_wino_fwd', C.byref(d0), xg.data_ptr(), uf.data_ptr(), None, y.data_ptr(), ws.data_ptr(), nws, s)
+    assert rel(y.permute(0, 3, 1, 2), pre - bias.double().view(1, -1, 1, 1)) < 2e-5
+    # data gradient, plain and with the ReLU mask of the layer below
+    dyg = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    dx = torch.empty(n, h, w, cin, device=dev)
+    nwb = L.srx_wino_ws_floats(dref, 1)
+    wsb = torch.empty(max(nwb, 4), device=dev)
+    _lib.call('srx_wino_bwd_data', dref, dyg.data_ptr(), ub.data_ptr(), None, dx.data_ptr(), wsb.data_ptr(), nwb, s)
+    assert rel(dx.permute(0, 3, 1, 2), dx_plain) < 2e-5
+    _lib.call('srx_wino_bwd_data', dref, dyg.data_ptr(), ub.data_ptr(), xg.data_ptr(), dx.data_ptr(), wsb.data_ptr(), nwb, s)
+    assert rel(dx.permute(0, 3, 1, 2), dx_masked) < 2e-5
+    plan = (C.c_int * 6)()
+    _lib.call('srx_wino_plan', dref, 0, plan)
+    assert plan[0] in (32, 64) and plan[1] >= 1 and (nws > 0) == (plan[1] > 1)
+
+
+def test_winograd_refuses_what_it_does_not_implement(dev):
+    from torchsr_amd import _lib
+    L = _lib.lib()
+    for desc in (_lib.Conv2dDesc(2, 24, 24, 64, 64, 64, 64, 3, 3, 2, 1, 0, 0, 0.0, 0, 0),    # stride 2
+                 _lib.Conv2dDesc(2, 24, 24, 3, 4, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0),      # 3 input channels
+                 _lib.Conv2dDesc(2, 23, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0),    # odd height
+                 _lib.Conv2dDesc(2, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 1),    # bf16 products
+                 _lib.Conv2dDesc(2, 24, 24, 64, 192, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)):  # strided input rows (dense block)
+        assert L.srx_wino_applicable(C.byref(desc)) == 0
+        assert L.srx_wino_packed_floats(C.byref(desc)) == 0
+
+
+def test_vgg_stack_on_winograd_equals_the_direct_kernels(dev, monkeypatch):
+    """The perceptual-loss node (functional.frozen_conv_stack) with its wide layers on Winograd against the same node on the
+    direct gather-GEMM kernels (developer switch): loss and input gradient agree to fp32 rounding of their scale."""
+    import torch
+    from torchsr_amd import _dev, functional as F
+    from torchsr_amd.srgan.loss import VGGLoss
+    torch.manual_seed(0)
+    vgg = VGGLoss(weights='random').to(dev)
+    src = torch.rand(2, 3, 96, 96, device=dev)
+    tgt = torch.rand(2, 3, 96, 96, device=dev)
+    out = {}
+    for direct in (False, True):
+        monkeypatch.setattr(_dev, 'NO_WINO', direct)
+        s = src.clone().requires_grad_(True)
+        loss = vgg(s, tgt)
+        loss.backward()
+        out[direct] = (loss.detach().clone(), s.grad.clone())
+    assert rel(out[False][0], out[True][0]) < 1e-5
+    # the gradient passes through 16 ReLUs and 4 max-pools: a pre-activation within rounding of 0 (or a tie in a pooling window)
+    # takes the other branch in any two fp32 evaluations, so single pixels differ; the tensors as a whole must not
+    a, b = out[False][1].double().flatten(), out[True][1].double().flatten()
+    assert float((a - b).norm() / b.norm()) < 2e-3
+    assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.99999

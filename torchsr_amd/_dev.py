@@ -12,3 +12,4 @@ NO_BN_DGRAD_FUSE = _on('SRX_NO_BN_DGRAD_FUSE')  # residual tower: separate Batch
 NO_RDB_FUSED = _on('SRX_NO_RDB_FUSED')          # ESRGAN dense blocks: five conv launches instead of srx_rdb_fwd / srx_rdb_bwd
 NO_C64 = _on('SRX_NO_C64')                      # bf16 inference: fp32-stored activations (round 3's path) instead of the bf16-native chain
 NO_T9 = _on('SRX_NO_T9')                        # bf16 inference: the 9x9 output conv on the 4x4x4 MFMA kernel instead of thin9.hip
+NO_WINO = _on('SRX_NO_WINO')                    # VGG19's wide 3x3 layers on the direct gather-GEMM instead of Winograd F(2x2, 3x3)

@@ -12,7 +12,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('SRX_LIB') or os.path.join(CSRC, 'libsrx_hip.so')  # SRX_LIB: developer A/B builds on one GPU box
-SOURCES = ['api.cpp', 'gconv.hip', 'c64.hip', 'thin9.hip', 'rdb.hip', 'thin.hip', 'rowtile.hip', 'augment.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'head.hip', 'optim.hip']
+SOURCES = ['api.cpp', 'gconv.hip', 'c64.hip', 'thin9.hip', 'rdb.hip', 'thin.hip', 'rowtile.hip', 'augment.hip', 'norm.hip', 'eltwise.hip', 'linear.hip', 'loss.hip', 'head.hip', 'wino.hip', 'optim.hip']
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
 
@@ -237,12 +237,19 @@ _SIGS = {
     'srx_bce_bwd': (_I, [_P, _F, _P, _P, _L, _P]),
     'srx_bce_logits_fwd': (_I, [_P, _P, _F, _P, _L, _P, _P]),
     'srx_bce_logits_bwd': (_I, [_P, _P, _F, _P, _P, _L, _P]),
+    'srx_wino_applicable': (_I, [_D]),
+    'srx_wino_packed_floats': (_Z, [_D]),
+    'srx_wino_ws_floats': (_Z, [_D, _I]),
+    'srx_wino_plan': (_I, [_D, _I, C.POINTER(C.c_int)]),
+    'srx_wino_pack': (_I, [_D, _P, _P, _I, _P]),
+    'srx_wino_fwd': (_I, [_D, _P, _P, _P, _P, _P, _Z, _P]),
+    'srx_wino_bwd_data': (_I, [_D, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_gan_head_fwd': (_I, [C.POINTER(GanHead), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'srx_gan_head_bwd': (_I, [C.POINTER(GanHead), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'srx_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
 }
 # functions whose int return value is data, not a status
-_UNCHECKED = {'srx_conv2d_bwd_data_bn_rows', 'srx_conv2d_fwd_bn_in_ok', 'srx_conv2d_bwd_data_bn_in_ok', 'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_plan_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows', 'srx_bn_rows_per_block'}
+_UNCHECKED = {'srx_wino_applicable', 'srx_conv2d_bwd_data_bn_rows', 'srx_conv2d_fwd_bn_in_ok', 'srx_conv2d_bwd_data_bn_in_ok', 'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_plan_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows', 'srx_bn_rows_per_block'}
 
 EXPORTS = tuple(_SIGS.keys())
 

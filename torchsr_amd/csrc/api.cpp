@@ -51,6 +51,9 @@ static SrxDevSwitches read_switches() {
   s.reserved_cus = num("SRX_RESERVED_CUS");
   s.c64_ablate = num("SRX_C64_ABLATE");
   s.rdb_ablate = num("SRX_RDB_ABLATE");
+  s.no_wino = flag("SRX_NO_WINO");
+  s.wino_zsplit = num("SRX_WINO_ZSPLIT");
+  s.wino_bn = num("SRX_WINO_BN");
   if (const char* f = getenv("SRX_FORCE_PLAN")) {
     int v[4] = {0, 0, 1, 1};
     if (sscanf(f, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) { s.force_plan = true; for (int i = 0; i < 4; ++i) s.plan[i] = v[i]; }

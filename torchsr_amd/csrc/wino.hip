@@ -1,0 +1,435 @@
+// 3x3 / stride 1 / pad 1 convolutions of wide layers as Winograd F(2x2, 3x3) on the fp32 matrix cores (round 5).
+//
+// The direct gather-GEMM (gconv.hip) runs the VGG19 layers of the perceptual loss (srgan/loss.py:30-54: 344 of the SRGAN
+// step's 692 GFLOP) at 0.95 of what v_mfma_f32_32x32x2_f32 gives at the clock the part holds under that load -- the only
+// way to make them faster is to multiply less.  Winograd's minimal filtering computes a 2x2 output tile from a 4x4 input
+// tile with 16 multiplications per (input channel, output channel) pair instead of 36:
+//
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A
+//     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// i.e. sixteen independent GEMMs  M_xi[tile][co] = sum_ci V_xi[tile][ci] U_xi[ci][co]  (xi = the 16 positions of the
+// transformed 4x4 tile) with 2.25x fewer multiply-adds than the direct form, all in fp32: the result differs from the
+// direct fp32 convolution by rounding only (measured 2-3x its own rounding error against fp64, i.e. ~5e-7 of the tensor's
+// scale: tools/experiments/wino_error.py), far inside the 1e-3 the parity tests allow.
+//
+// One workgroup = 32 tiles (128 output pixels) x BN output channels x all 16 xi, 512 threads:
+//   * waves 0..3 gather the 4x4 input patches of the 32 tiles for a chunk of 32 input channels (16 pixels x 16 bytes per
+//     thread, padding pixels through an out-of-range descriptor offset), apply B^T d B in registers (32 float4 adds) and
+//     write the sixteen V_xi rows of the chunk to a two-stage LDS ring (64 KB per stage, XOR-swizzled 128-byte rows);
+//   * every wave owns two xi and multiplies them for all 32 tiles and BN channels: U fragments come STRAIGHT from global memory
+//     into MFMA operand registers (each xi belongs to exactly one wave, so nothing is shared through LDS; srx_wino_pack lays
+//     U out so that a wave's load is 1 KB contiguous), V fragments are one ds_read_b128 per eight MFMAs;
+//   * epilogue: the accumulators (U as the A operand, so a lane holds four consecutive channels of one tile) go to LDS as
+//     M[xi][tile][channel], every thread takes one (tile, channel quad), applies A^T M A, adds the bias, applies ReLU or the
+//     ReLU mask of the layer below (data gradients: the fold of srx_conv2d_bwd_data_act) and stores four pixels x 16 bytes.
+// The data gradient of such a layer IS such a layer (channels swapped, taps flipped): srx_wino_pack(..., transpose = 1).
+// Small layers split the input channels over several workgroups (partial outputs + a streaming fix-up), the planner picks the
+// split and BN (64 or 32) that fill whole rounds of the chip.
+#include "srx_common.h"
+#include <algorithm>
+#include <mutex>
+
+namespace {
+
+constexpr int WT = 32;       // tiles per workgroup
+constexpr int WKC = 32;      // input channels per chunk
+constexpr int STAGE_BYTES = 16 * WT * WKC * 4;  // 65536: V of one chunk
+constexpr int WINO_LDS = 2 * STAGE_BYTES;       // the epilogue's M[16][32][BN <= 64] reuses both stages
+
+struct WinoArgs {
+  const float* in; const float* upk; const float* bias; const float* mask; float* out; float* part;
+  int N, H, W, Cin, Cout;
+  int TH, TW, T, tblocks, ncb, nch, zsplit;
+  int relu;
+  unsigned in_bytes, upk_bytes;
+  size_t out_elems;  // N * H * W * Cout (stride between the partial outputs of two splits)
+};
+
+template <int BN>
+__global__ __launch_bounds__(512) void wino_kernel(const WinoArgs a) {
+  constexpr int NJ = BN / 32;  // channel tiles per workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  int b = blockIdx.x;
+  const int tb = b % a.tblocks; b /= a.tblocks;
+  const int cb = b % a.ncb;
+  const int z = b / a.ncb;
+  // this split's chunks of input channels: [kc0, kc1)
+  const int kc0 = srx_uniform((int)((long long)z * a.nch / a.zsplit)), kc1 = srx_uniform((int)((long long)(z + 1) * a.nch / a.zsplit));
+  const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes);
+  const __amdgpu_buffer_rsrc_t ru = srx_rsrc(a.upk, a.upk_bytes);
+
+  // ---- loader state (waves 0..3): tile tl of the block, channel quad q of the chunk; byte offsets of the 16 patch pixels
+  const bool loader = wave < 4;
+  const int tl = tid >> 3, q = tid & 7;  // (tid < 256 for loaders)
+  unsigned poff[16];
+  {
+    const int t = tb * WT + (tl & 31);
+    const bool tok = loader && t < a.T;
+    const int tw = t % a.TW, r = t / a.TW, th = r % a.TH, n = r / a.TH;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ih = 2 * th - 1 + i, iw = 2 * tw - 1 + j;
+        const bool ok = tok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        poff[4 * i + j] = ok ? 4u * (unsigned)((((n * a.H + ih) * a.W + iw) * a.Cin) + 4 * q) : 0xffffffffu;  // out of range reads 0
+      }
+  }
+  // ---- multiplier state: this wave's two xi; U fragments of a sub-step s: [xi][j] one float4 per lane
+  //      packed U: (((xi * (Cout / 32) + jg) * nch + kc) * 4 + s) * 64 + lane, in float4 units
+  const int xi0 = 2 * wave;
+  const int cot = a.Cout >> 5;
+  unsigned uoff[2][NJ];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      uoff[x][j] = 16u * (unsigned)((((xi0 + x) * cot + cb * NJ + j) * a.nch) * 256 + lane);
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][j][r] = 0.f;
+
+  f32x4 pd[16];        // the patch of the chunk being staged
+  f32x4 uf[4][2][NJ];  // U fragments, one slot per sub-step
+  auto load_patch = [&](int kc) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) pd[p] = srx_bload(rin, poff[p], (unsigned)srx_uniform(kc * (WKC * 4)));
+  };
+  auto load_u = [&](int kc, int s) {
+    const unsigned so = (unsigned)srx_uniform((kc * 4 + s) * 1024);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) uf[s][x][j] = srx_bload(ru, uoff[x][j], so);
+  };
+  // B^T d B of this thread's patch, the sixteen results to row (xi, tl) of stage `st` at quad q (XOR swizzle as in gconv.hip)
+  auto stage_patch = [&](int st) {
+    // in place, so that no second copy of the patch is ever live: rows first (d B: every input row on its own), then the
+    // columns (B^T .), each column's four results written as soon as they exist
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 r0 = pd[4 * i + 0] - pd[4 * i + 2], r1 = pd[4 * i + 1] + pd[4 * i + 2], r2 = pd[4 * i + 2] - pd[4 * i + 1],
+                  r3 = pd[4 * i + 1] - pd[4 * i + 3];
+      pd[4 * i + 0] = r0; pd[4 * i + 1] = r1; pd[4 * i + 2] = r2; pd[4 * i + 3] = r3;
+    }
+    float* base = reinterpret_cast<float*>(smem + st * STAGE_BYTES) + tl * WKC + ((q ^ ((tl >> 1) & 7)) << 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 v0 = pd[0 + j] - pd[8 + j], v1 = pd[4 + j] + pd[8 + j], v2 = pd[8 + j] - pd[4 + j], v3 = pd[4 + j] - pd[12 + j];
+      *reinterpret_cast<f32x4*>(base + (0 + j) * (WT * WKC)) = v0;   // xi = 4 i + j
+      *reinterpret_cast<f32x4*>(base + (4 + j) * (WT * WKC)) = v1;
+      *reinterpret_cast<f32x4*>(base + (8 + j) * (WT * WKC)) = v2;
+      *reinterpret_cast<f32x4*>(base + (12 + j) * (WT * WKC)) = v3;
+    }
+  };
+  // sub-step s of the chunk in stage st: quads 2s (lanes 0..31) and 2s + 1 (lanes 32..63) of this wave's two xi
+  const int vrow = l31 * WKC, vsw = (l31 >> 1) & 7;
+  auto mma = [&](int st, int s) {
+    const float* sv = reinterpret_cast<const float*>(smem + st * STAGE_BYTES) + vrow + (((2 * s + h) ^ vsw) << 2);
+    f32x4 vf[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) vf[x] = *reinterpret_cast<const f32x4*>(sv + (xi0 + x) * (WT * WKC));
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[x][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[s][x][j][e], vf[x][e], acc[x][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: first chunk staged, its U fragments requested
+  if (loader) load_patch(kc0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) load_u(kc0, s);
+  if (loader) stage_patch(0);
+  __syncthreads();
+  // ---- chunk loop: the patch of chunk c + 1 is requested at the top, transformed and written between the second and third
+  // sub-step (the partner wave on the SIMD keeps the matrix pipe busy meanwhile); a sub-step's U slot is refilled for
+  // chunk c + 1 as soon as its MFMAs are issued
+  int st = 0;
+  for (int kc = kc0; kc < kc1; ++kc) {
+    const bool more = kc + 1 < kc1;  // (workgroup-uniform)
+    if (loader && more) load_patch(kc + 1);
+    mma(st, 0);
+    if (more) load_u(kc + 1, 0);
+    mma(st, 1);
+    if (more) load_u(kc + 1, 1);
+    if (loader && more) stage_patch(st ^ 1);
+    mma(st, 2);
+    if (more) load_u(kc + 1, 2);
+    mma(st, 3);
+    if (more) load_u(kc + 1, 3);
+    __syncthreads();
+    st ^= 1;
+  }
+
+  // ---- epilogue: M[xi][tile][channel] through LDS (16-byte chunk c of row (xi, t) at chunk c ^ (t & 15): the 32 lanes of
+  // a store hit 16 different chunk columns), then A^T M A per (tile, channel quad)
+  constexpr int MROW = BN;  // floats per (xi, tile) row
+  float* sM = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // accumulator rows (channels) 8 g + 4 h + 0..3 of channel tile j, column (tile) l31
+        const int c = (j * 32 + 8 * g + 4 * h) >> 2;  // 16-byte chunk of the row
+        const f32x4 v = {acc[x][j][4 * g + 0], acc[x][j][4 * g + 1], acc[x][j][4 * g + 2], acc[x][j][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(sM + ((xi0 + x) * WT + l31) * MROW + ((c ^ (l31 & (BN / 4 - 1))) << 2)) = v;
+      }
+  __syncthreads();
+  constexpr int CQ = BN / 4;            // channel quads per row
+  constexpr int ITEMS = WT * CQ;        // 512 (BN = 64) or 256 (BN = 32)
+  if (tid >= ITEMS) return;
+  const int et = tid / CQ, cq = tid % CQ;
+  const int t = tb * WT + et;
+  if (t >= a.T) return;
+  f32x4 m[16];
+#pragma unroll
+  for (int x = 0; x < 16; ++x) m[x] = *reinterpret_cast<const f32x4*>(sM + (x * WT + et) * MROW + ((cq ^ (et & (CQ - 1))) << 2));
+  f32x4 s0[4], s1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s0[j] = m[0 + j] + m[4 + j] + m[8 + j];
+    s1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+  }
+  f32x4 y[4];
+  y[0] = s0[0] + s0[1] + s0[2];
+  y[1] = s0[1] - s0[2] - s0[3];
+  y[2] = s1[0] + s1[1] + s1[2];
+  y[3] = s1[1] - s1[2] - s1[3];
+  const int tw = t % a.TW, r = t / a.TW, th = r % a.TH, n = r / a.TH;
+  const int co = cb * BN + 4 * cq;
+  const size_t p00 = (((size_t)n * a.H + 2 * th) * a.W + 2 * tw) * a.Cout + co;
+  const size_t offs[4] = {p00, p00 + a.Cout, p00 + (size_t)a.W * a.Cout, p00 + (size_t)a.W * a.Cout + a.Cout};
+  if (a.part) {  // one of several splits of the input channels: the raw partial output; bias / activation in the fix-up pass
+    float* o = a.part + (size_t)z * a.out_elems;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(o + offs[p]) = y[p];
+    return;
+  }
+  f32x4 mk[4];
+  if (a.mask) {  // (all loads before the first store)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) mk[p] = *reinterpret_cast<const f32x4*>(a.mask + offs[p]);
+  }
+  if (a.bias) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) y[p] += bv;
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = y[p][e];
+      if (a.relu) v = fmaxf(v, 0.f);
+      if (a.mask) v = mk[p][e] > 0.f ? v : 0.f;
+      y[p][e] = v;
+    }
+    *reinterpret_cast<f32x4*>(a.out + offs[p]) = y[p];
+  }
+}
+
+// out = act(sum_z part[z] + bias) [masked]: finishes a layer whose input channels were split over several workgroups
+__global__ __launch_bounds__(256) void wino_fixup_kernel(const float* __restrict__ part, int zsplit, size_t n4, size_t stride,
+                                                         const float* __restrict__ bias, const float* __restrict__ mask,
+                                                         float* __restrict__ out, int cq, int relu) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 v[8];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z0 = 0; z0 < zsplit; z0 += 8) {  // eight partials per trip, loads first, added in order
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(part + (size_t)min(z0 + u, zsplit - 1) * stride + i * 4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (z0 + u < zsplit) s += v[u];
+    }
+    if (bias) s += *reinterpret_cast<const f32x4*>(bias + (i % cq) * 4);
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = fmaxf(s[e], 0.f);
+    }
+    if (mask) {
+      const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = mk[e] > 0.f ? s[e] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = s;
+  }
+}
+
+// U = G g G^T of every (output channel, input channel) pair, laid out as wino_kernel's waves load it.
+// transpose = 0: the layer itself (g = w[co][ci]); 1: its data gradient (output channels = the layer's inputs, g =
+// w[ci][co] with both taps flipped).  One thread per (row channel, contraction channel) pair.
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ upk, int Cout, int Cin, int transpose) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int R = transpose ? Cin : Cout, K = transpose ? Cout : Cin;  // rows (the GEMM's channels out) and contraction length
+  if (idx >= (int64_t)R * K) return;
+  const int r = (int)(idx / K), k = (int)(idx - (int64_t)r * K);
+  float g[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      g[i][j] = transpose ? w[(((size_t)k * Cin + r) * 3 + (2 - i)) * 3 + (2 - j)] : w[(((size_t)r * Cin + k) * 3 + i) * 3 + j];
+  float t[4][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    t[0][j] = g[0][j];
+    t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+    t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+    t[3][j] = g[2][j];
+  }
+  const int nch = K / WKC, rt = R / 32;
+  const int jg = r >> 5, mrow = r & 31, kc = k / WKC, kk = k % WKC, quad = kk >> 2, e = kk & 3, s = quad >> 1, hh = quad & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u[4] = {t[i][0], 0.5f * (t[i][0] + t[i][1] + t[i][2]), 0.5f * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xi = 4 * i + j;
+      upk[(((((size_t)xi * rt + jg) * nch + kc) * 4 + s) * 64 + hh * 32 + mrow) * 4 + e] = u[j];
+    }
+  }
+}
+
+struct WinoPlan { int bn, zsplit; float cost; };
+
+// rounds of the chip x (chunks per workgroup x time per chunk + fixed cost), plus the fix-up pass of a split
+WinoPlan wino_plan(int T, int Cin, int Cout) {
+  const int P = srx_plan_cus();
+  const int nch = Cin / WKC, tblocks = (int)srx_cdiv(T, WT);
+  WinoPlan best{64, 1, 1e30f};
+  for (int bn = 64; bn >= 32; bn -= 32) {
+    if (Cout % bn) continue;
+    const int ncb = Cout / bn;
+    for (int zs = 1; zs <= nch && zs <= 16; ++zs) {
+      const int64_t wgs = (int64_t)tblocks * ncb * zs;
+      const float rounds = (float)srx_cdiv(wgs, P);
+      const float chunks = (float)srx_cdiv(nch, zs);
+      const float t_chunk = bn == 64 ? 4.4f : 2.5f;  // us: 128 / 64 fp32 MFMAs per SIMD pair and chunk at ~2 GHz, 32-column tiles a little over half
+      const float fixed = bn == 64 ? 4.5f : 3.5f;    // prologue (first patch + U round trip) and the epilogue through LDS
+      float cost = rounds * (chunks * t_chunk + fixed);
+      if (zs > 1) cost += 3.0f + (float)(zs + 1) * T * 4.0f * Cout * 4.0f / 4.0e6f;  // fix-up: (zs + 1) passes over the output at ~4 TB/s
+      if (cost < best.cost) best = WinoPlan{bn, zs, cost};
+    }
+  }
+  if (const int v = srx_dev().wino_zsplit; v > 0 && v <= nch) best.zsplit = v;
+  if (const int v = srx_dev().wino_bn; (v == 32 || v == 64) && Cout % v == 0) best.bn = v;
+  return best;
+}
+
+bool wino_shape_ok(const srx_conv2d_t* d) {
+  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->shuffle && d->up != 2 && d->precision == 0 &&
+         d->Cin % WKC == 0 && d->Cout % 32 == 0 && d->Cin_s == d->Cin && d->Cout_s == d->Cout && d->H % 2 == 0 && d->W % 2 == 0 &&
+         (int64_t)d->N * d->H * d->W * std::max(d->Cin, d->Cout) < (1LL << 30);
+}
+
+}  // namespace
+
+extern "C" int srx_wino_applicable(const srx_conv2d_t* d) {
+  return (!srx_dev().no_wino && d && wino_shape_ok(d)) ? 1 : 0;
+}
+
+extern "C" size_t srx_wino_packed_floats(const srx_conv2d_t* d) {
+  return (d && wino_shape_ok(d)) ? (size_t)16 * d->Cout * d->Cin : 0;
+}
+
+extern "C" int srx_wino_pack(const srx_conv2d_t* d, const float* w, float* upk, int transpose, void* stream) {
+  SRX_REQUIRE(d && w && upk, "wino_pack: null pointer");
+  if (!wino_shape_ok(d)) SRX_FAIL(SRX_E_UNSUPPORTED, "wino_pack: 3x3 / stride 1 / pad 1 fp32 layers with Cin, Cout multiples of 32 and even H, W only");
+  const int64_t n = (int64_t)d->Cout * d->Cin;
+  hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, srx_stream(stream), w, upk, d->Cout, d->Cin,
+                     transpose ? 1 : 0);
+  SRX_CHECK_LAUNCH("wino_pack_kernel");
+  return SRX_OK;
+}
+
+// workspace (floats) of a forward (which = 0) or data-gradient (which = 1) call: the partial outputs of a channel split
+extern "C" size_t srx_wino_ws_floats(const srx_conv2d_t* d, int which) {
+  if (!d || !wino_shape_ok(d)) return 0;
+  const int cin = which ? d->Cout : d->Cin, cout = which ? d->Cin : d->Cout;
+  const WinoPlan p = wino_plan(d->N * (d->H / 2) * (d->W / 2), cin, cout);
+  return p.zsplit > 1 ? (size_t)p.zsplit * d->N * d->H * d->W * cout : 0;
+}
+
+// out[6] = {BN, channel splits, workgroups, tile blocks, chunks per workgroup (max), 0}
+extern "C" int srx_wino_plan(const srx_conv2d_t* d, int which, int* out) {
+  SRX_REQUIRE(d && out && wino_shape_ok(d), "wino_plan: not a Winograd layer");
+  const int cin = which ? d->Cout : d->Cin, cout = which ? d->Cin : d->Cout;
+  const int T = d->N * (d->H / 2) * (d->W / 2);
+  const WinoPlan p = wino_plan(T, cin, cout);
+  out[0] = p.bn; out[1] = p.zsplit; out[3] = (int)srx_cdiv(T, WT); out[2] = out[3] * (cout / p.bn) * p.zsplit;
+  out[4] = (int)srx_cdiv(cin / WKC, p.zsplit); out[5] = 0;
+  return SRX_OK;
+}
+
+static int wino_run(const srx_conv2d_t* d, int which, const float* x, const float* upk, const float* bias, const float* mask,
+                    int relu, float* y, float* ws, size_t ws_floats, void* stream) {
+  SRX_REQUIRE(d && x && upk && y, "wino: null pointer");
+  if (!wino_shape_ok(d)) SRX_FAIL(SRX_E_UNSUPPORTED, "wino: 3x3 / stride 1 / pad 1 fp32 layers with Cin, Cout multiples of 32 and even H, W only");
+  SRX_REQUIRE(x != y && (!mask || mask != y), "wino: in place is not possible (neighbouring tiles read their halo)");
+  WinoArgs a{};
+  a.in = x; a.upk = upk; a.bias = bias; a.mask = mask; a.out = y;
+  a.N = d->N; a.H = d->H; a.W = d->W;
+  a.Cin = which ? d->Cout : d->Cin;
+  a.Cout = which ? d->Cin : d->Cout;
+  a.TH = d->H / 2; a.TW = d->W / 2; a.T = d->N * a.TH * a.TW;
+  a.tblocks = (int)srx_cdiv(a.T, WT);
+  a.nch = a.Cin / WKC;
+  a.relu = relu;
+  a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * a.Cin * sizeof(float));
+  a.upk_bytes = (unsigned)((size_t)16 * a.Cin * a.Cout * sizeof(float));
+  a.out_elems = (size_t)d->N * d->H * d->W * a.Cout;
+  const WinoPlan p = wino_plan(a.T, a.Cin, a.Cout);
+  a.zsplit = p.zsplit;
+  a.ncb = a.Cout / p.bn;
+  if (p.zsplit > 1) {
+    if (!ws || ws_floats < (size_t)p.zsplit * a.out_elems) SRX_FAIL(SRX_E_WORKSPACE, "wino: workspace %zu < %zu floats", ws_floats, (size_t)p.zsplit * a.out_elems);
+    a.part = ws;
+  }
+  hipStream_t st = srx_stream(stream);
+  const dim3 grid((unsigned)((int64_t)a.tblocks * a.ncb * a.zsplit));
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  char nm[112];
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "wino_kernel<%d> MxNxK=%dx%dx%d", p.bn, a.N * a.H * a.W, a.Cout, 9 * a.Cin);
+  const double fl = 2.0 * a.N * a.H * a.W * (double)a.Cout * 9.0 * a.Cin;  // algorithmic FLOPs of the convolution (the direct form's)
+  if (p.bn == 64) SRX_LAUNCH_PROF(nm, fl, wino_kernel<64>, grid, dim3(512), WINO_LDS, st, a);
+  else SRX_LAUNCH_PROF(nm, fl, wino_kernel<32>, grid, dim3(512), WINO_LDS, st, a);
+  SRX_CHECK_LAUNCH("wino_kernel");
+  if (p.zsplit > 1) {
+    const size_t n4 = a.out_elems / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>(srx_cdiv((int64_t)n4, 256), 4096);
+    hipLaunchKernelGGL(wino_fixup_kernel, dim3(blocks), dim3(256), 0, st, ws, p.zsplit, n4, a.out_elems, bias, mask, y, a.Cout / 4, relu);
+    SRX_CHECK_LAUNCH("wino_fixup_kernel");
+  }
+  return SRX_OK;
+}
+
+extern "C" int srx_wino_fwd(const srx_conv2d_t* d, const float* x, const float* upk, const float* bias, float* y, float* ws,
+                            size_t ws_floats, void* stream) {
+  SRX_REQUIRE(d && (d->act == SRX_ACT_NONE || d->act == SRX_ACT_RELU), "wino_fwd: no activation or ReLU");
+  return wino_run(d, 0, x, upk, bias, nullptr, d->act == SRX_ACT_RELU, y, ws, ws_floats, stream);
+}
+
+extern "C" int srx_wino_bwd_data(const srx_conv2d_t* d, const float* dy, const float* upk_t, const float* relu_out, float* dx,
+                                 float* ws, size_t ws_floats, void* stream) {
+  return wino_run(d, 1, dy, upk_t, nullptr, relu_out, 0, dx, ws, ws_floats, stream);
+}

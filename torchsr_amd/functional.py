@@ -346,6 +346,28 @@ class ConvState:
         self._key = key
         self.last_desc = d
 
+    def pack_wino(self, weight: Tensor, d: Conv2dDesc, need_bwd: bool) -> None:
+        """The Winograd-domain weights (``srx_wino_pack``: U = G g G^T of the layer and, for its data gradient, of the
+        transposed / tap-flipped layer), rebuilt when the master weight changed -- same key as ``pack``."""
+        key = self.pack_key(weight)
+        fresh = key == self.__dict__.get('_wino_key')
+        if fresh and (self.__dict__.get('wino_bwd') is not None or not need_bwd):
+            return
+        dref = C.byref(d)
+        n = _lib.lib().srx_wino_packed_floats(dref)
+        w = _chk(weight.detach(), 'conv2d.weight')
+        if not fresh or self.__dict__.get('wino_fwd') is None:
+            if self.__dict__.get('wino_fwd') is None or self.wino_fwd.device != weight.device:
+                self.wino_fwd = torch.empty(n, dtype=torch.float32, device=weight.device)
+                self.wino_bwd = None
+            call('srx_wino_pack', dref, _p(w), _p(self.wino_fwd), 0, _stream())
+            if self.wino_bwd is not None:
+                call('srx_wino_pack', dref, _p(w), _p(self.wino_bwd), 1, _stream())
+        if need_bwd and self.wino_bwd is None:
+            self.wino_bwd = torch.empty(n, dtype=torch.float32, device=weight.device)
+            call('srx_wino_pack', dref, _p(w), _p(self.wino_bwd), 1, _stream())
+        self._wino_key = key
+
 
 class PackTable:
     """Every conv of a model repacked by ONE launch after an optimiser step (``srx_pack_table_*``).
@@ -447,17 +469,28 @@ class _Conv2d(Function):
             raise RuntimeError(f'conv2d: input has {cs} channels (stride), layer expects {st.cin_s}')
         d = st.desc(n, h, w)
         dref = C.byref(d)
-        st.pack(master, d)
         L = _lib.lib()
         y = torch.empty(st.out_shape(n, h, w), dtype=torch.float32, device=x.device)
-        part = None
-        if want_stats:
-            rows = L.srx_conv2d_stat_rows(dref)
-            part = torch.empty((rows, st.cout, 2), dtype=torch.float32, device=x.device)
-        nws = L.srx_conv2d_fwd_ws_floats(dref)
-        ws = _ws(nws, x) if nws else None
         b = None if bias is None else _chk(bias.detach(), 'conv2d.bias')
-        call('srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(b), _p(y), _p(part), _p(ws), nws, _stream())
+        # Frozen wide 3x3 layers (the VGG19 features called layer by layer) take the same Winograd kernel as the one-node
+        # stack.  Trainable layers do not: their Winograd-domain weights would have to be refreshed inside the captured
+        # step after every Adam update (PackTable repacks the direct layouts only).
+        ctx.wino = (not _dev.NO_WINO and not want_stats and not master.requires_grad and st.act in (ACT_NONE, ACT_RELU)
+                    and L.srx_wino_applicable(dref) == 1)
+        part = None
+        if ctx.wino:
+            st.pack_wino(master, d, need_bwd=ctx.needs_input_grad[0])
+            nws = L.srx_wino_ws_floats(dref, 0)
+            call('srx_wino_fwd', dref, _p(x), _p(st.wino_fwd), _p(b), _p(y), _p(_ws(nws, x)) if nws else None, nws, _stream())
+        else:
+            st.pack(master, d)
+            if want_stats:
+                rows = L.srx_conv2d_stat_rows(dref)
+                part = torch.empty((rows, st.cout, 2), dtype=torch.float32, device=x.device)
+            nws = L.srx_conv2d_fwd_ws_floats(dref)
+            ws = _ws(nws, x) if nws else None
+            call('srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(b), _p(y), _p(part), _p(ws), nws, _stream())
+        ctx.master = master
         ctx.st, ctx.d = st, d
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)
@@ -484,7 +517,17 @@ class _Conv2d(Function):
             call('srx_act_bwd_from_out', _p(dy), _p(y), _p(g), dy.numel(), st.act, st.slope, s)
             dy = g
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.wino and (ctx.in_act is None or ctx.in_act.act == ACT_RELU) and st.wino_bwd is not None:
+            dx = torch.empty_like(x)
+            nws = L.srx_wino_ws_floats(dref, 1)
+            call('srx_wino_bwd_data', dref, _p(dy), _p(st.wino_bwd), _p(x) if ctx.in_act is not None else None, _p(dx),
+                 _p(_ws(nws, x)) if nws else None, nws, s)
+            if ctx.in_act is not None:
+                ctx.in_act.masked = True
+        elif ctx.needs_input_grad[0]:
+            if ctx.wino:  # (a Winograd forward whose data gradient takes the direct kernel: its packed copy is made now)
+                st.pack(ctx.master, d)
+                ctx.wpk_bwd = st.wpk_bwd
             dx = torch.empty_like(x)
             nws = L.srx_conv2d_bwd_data_ws_floats(dref)
             ws = _ws(nws, x) if nws else None
@@ -1122,17 +1165,27 @@ class _FrozenConvStack(Function):
                 if st.act not in (ACT_RELU, ACT_LRELU) or st.stride != 1 or st.shuffle:
                     raise RuntimeError('conv_stack: stride-1 conv + ReLU / LeakyReLU layers only')
                 d = st.desc(n, h, w)
-                st.pack(conv.weight, d)
                 dref = C.byref(d)
                 y = torch.empty(st.out_shape(n, h, w), dtype=torch.float32, device=x.device)
-                nws = L.srx_conv2d_fwd_ws_floats(dref)
-                ws = _ws(nws, x) if nws else None
                 b = None if conv.bias is None else _chk(conv.bias.detach(), 'conv_stack.bias')
-                call('srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(b), _p(y), None, _p(ws), nws, s)
-                plan.append(('conv', st, st.wpk_bwd))
+                # wide 3x3 layers: Winograd F(2x2, 3x3), 2.25x fewer fp32 multiplications (csrc/wino.hip)
+                wino = not _dev.NO_WINO and st.act in (ACT_NONE, ACT_RELU) and L.srx_wino_applicable(dref) == 1
+                if wino:
+                    st.pack_wino(conv.weight, d, need_bwd=ctx.needs_input_grad[0])
+                    nws = L.srx_wino_ws_floats(dref, 0)
+                    ws = _ws(nws, x) if nws else None
+                    call('srx_wino_fwd', dref, _p(x), _p(st.wino_fwd), _p(b), _p(y), _p(ws), nws, s)
+                    plan.append(('conv', st, ('wino', st.wino_bwd)))
+                else:
+                    st.pack(conv.weight, d)
+                    nws = L.srx_conv2d_fwd_ws_floats(dref)
+                    ws = _ws(nws, x) if nws else None
+                    call('srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(b), _p(y), None, _p(ws), nws, s)
+                    plan.append(('conv', st, st.wpk_bwd))
             saved.append(y)
             x = y
         ctx.plan, ctx.n_src = plan, n_src
+        ctx.masters = [conv.weight if kind == 'conv' else None for kind, conv in layers]
         ctx.save_for_backward(*saved)
         if target is None:
             return x, None
@@ -1175,9 +1228,19 @@ class _FrozenConvStack(Function):
             d = st.desc(n, h, w)
             dref = C.byref(d)
             dx = torch.empty_like(x)
+            fold = below is not None and below[0] == 'conv'   # x = act(conv below): fold that activation's backward in
+            if isinstance(wpk_bwd, tuple) and (not fold or below[1].act == ACT_RELU) and wpk_bwd[1] is not None:
+                nws = L.srx_wino_ws_floats(dref, 1)
+                ws = _ws(nws, x) if nws else None
+                call('srx_wino_bwd_data', dref, _p(g), _p(wpk_bwd[1]), _p(x) if fold else None, _p(dx), _p(ws), nws, s)
+                g = dx
+                continue
+            if isinstance(wpk_bwd, tuple):  # (a Winograd forward whose data gradient takes the direct kernel: pack it now)
+                st.pack(ctx.masters[i], d)
+                wpk_bwd = st.wpk_bwd
             nws = L.srx_conv2d_bwd_data_ws_floats(dref)
             ws = _ws(nws, x) if nws else None
-            if below is not None and below[0] == 'conv':   # x = act(conv below): fold that activation's backward in
+            if fold:
                 slope = 0.0 if below[1].act == ACT_RELU else below[1].slope
                 call('srx_conv2d_bwd_data_act', dref, _p(g), _p(wpk_bwd), _p(x), slope, 0, st.cin_s, 0, _p(dx), _p(ws), nws, s)
             else:
