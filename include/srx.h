@@ -144,6 +144,10 @@ size_t srx_pack_table_bytes(int n_layers);
 int srx_pack_table_build(const srx_conv2d_t* descs, int n, const float* const* w_oihw, float* const* wpk_fwd,
                          float* const* wpk_bwd, void* host_table, int* n_records, long long* max_elems);
 int srx_pack_table_run(const void* dev_table, int n_records, long long max_elems, void* stream);
+/* appends to a host table under construction (srx_pack_table_build's output; room: srx_pack_table_bytes) the record that refreshes a
+ * layer's Winograd-domain weights (srx_wino_pack(d, w, upk, transpose)) in the same launch */
+int srx_pack_table_add_wino(void* host_table, int* nrec, long long* max_elems, const srx_conv2d_t* d, const float* w, float* upk,
+                            int transpose);
 
 /* y = act(conv(x, W) + bias).  bias may be NULL.  bn_partials may be NULL; when
  * given it receives per-row-block sums for the training-mode BatchNorm that
@@ -460,6 +464,12 @@ int srx_wino_fwd(const srx_conv2d_t* d, const float* x, const float* upk, const 
                  void* stream);
 int srx_wino_bwd_data(const srx_conv2d_t* d, const float* dy, const float* upk_t, const float* relu_out, float* dx, float* ws,
                       size_t ws_floats, void* stream);
+/* forward of a linear layer that a training-mode BatchNorm2d follows (srgan/discriminator.py:35-61): stats
+ * [srx_wino_stat_rows(d)][Cout][2] = per tile block of 128 output pixels (32 consecutive 2x2 tiles, image-major) the per-channel
+ * (sum, sum of squares) of y -- the table srx_bn_finalize / srx_bn_train_fwd take, as srx_conv2d_fwd's bn_partials */
+int srx_wino_stat_rows(const srx_conv2d_t* d);
+int srx_wino_fwd_stats(const srx_conv2d_t* d, const float* x, const float* upk, const float* bias, float* y, float* stats,
+                       void* stream);
 
 /* ----------------------------------------------------------------- pooling */
 /* nn.MaxPool2d(2,2) of VGG19 (torchvision cfg 'E', srgan/loss.py:30-31); H, W even */

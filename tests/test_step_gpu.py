@@ -217,6 +217,9 @@ def test_graph_replay_equals_eager(dev):
     assert 'gan.all' in tg._graphs
     for (k, a), (_, b) in zip(te.generator.state_dict().items(), tg.generator.state_dict().items()):
         assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6), k
+    for (k, a), (_, b) in zip(te.discriminator.state_dict().items(), tg.discriminator.state_dict().items()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6), k  # (its Winograd-domain weights are refreshed in the graph too)
+    assert tg.disc_optimizer.pack_table.table is not None and tg.disc_optimizer.pack_table.wino_items
     tg.generator.eval()
     te.generator.eval()
     with torch.no_grad():  # eager eval forward after replays must see the freshly packed weights
@@ -262,8 +265,11 @@ def test_pack_tables_take_over_after_the_first_step(dev):
     for opt, model in ((t.gen_optimizer, t.generator), (t.disc_optimizer, t.discriminator)):
         assert opt.pack_table.table is not None and opt.pack_table.nrec >= len(opt.pack_table.items)
         for m in model.modules():
-            if isinstance(m, Conv2d):
-                assert m._st._key == m._st.pack_key(m.weight)
+            if isinstance(m, Conv2d):  # the copies a layer's kernels read are current: the direct packs, the Winograd-domain ones, or both
+                key, st = m._st.pack_key(m.weight), m._st
+                assert st.wpk_fwd is not None or st.__dict__.get('wino_fwd') is not None
+                assert st.wpk_fwd is None or st._key == key
+                assert st.__dict__.get('wino_fwd') is None or st._wino_key == key
     assert t.psnr_optimizer.pack_table is t.gen_optimizer.pack_table
 
 

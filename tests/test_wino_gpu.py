@@ -46,7 +46,7 @@ def test_winograd_forward_and_data_gradient(dev, cfg):
 
     d = _lib.Conv2dDesc(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, _lib.ACT_RELU, 0.0, 0, 0)
     dref = C.byref(d)
-    assert L.srx_wino_applicable(dref) == 1
+    # (srx_wino_applicable also asks whether the layer is large enough to be worth it; the kernel itself takes any such shape)
     s = torch.cuda.current_stream().cuda_stream
     nf = L.srx_wino_packed_floats(dref)
     assert nf == 16 * cin * cout
@@ -88,6 +88,9 @@ def test_winograd_refuses_what_it_does_not_implement(dev):
                  _lib.Conv2dDesc(2, 24, 24, 64, 192, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0)):  # strided input rows (dense block)
         assert L.srx_wino_applicable(C.byref(desc)) == 0
         assert L.srx_wino_packed_floats(C.byref(desc)) == 0
+    # large enough and of the right shape: yes; the residual tower's small 64 -> 64 layers keep their row-tile kernel
+    assert L.srx_wino_applicable(C.byref(_lib.Conv2dDesc(32, 24, 24, 256, 256, 256, 256, 3, 3, 1, 1, 0, 1, 0.0, 0, 0))) == 1
+    assert L.srx_wino_applicable(C.byref(_lib.Conv2dDesc(16, 24, 24, 64, 64, 64, 64, 3, 3, 1, 1, 0, 0, 0.0, 0, 0))) == 0
 
 
 def test_vgg_stack_on_winograd_equals_the_direct_kernels(dev, monkeypatch):
@@ -113,3 +116,35 @@ def test_vgg_stack_on_winograd_equals_the_direct_kernels(dev, monkeypatch):
     a, b = out[False][1].double().flatten(), out[True][1].double().flatten()
     assert float((a - b).norm() / b.norm()) < 2e-3
     assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.99999
+
+
+@pytest.mark.parametrize('cfg', [(4, 24, 24, 64, 128), (2, 12, 12, 256, 512), (1, 10, 6, 128, 96)], ids=lambda c: 'x'.join(map(str, c)))
+def test_winograd_forward_with_batchnorm_partials(dev, cfg):
+    """srx_wino_fwd_stats: the conv's output plus, per block of 32 consecutive 2x2 tiles, the per-channel (sum, sum of squares)
+    that a training-mode BatchNorm2d behind the layer reduces (srgan/discriminator.py:35-61)."""
+    from torchsr_amd import _lib
+    n, h, w, cin, cout = cfg
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    yr = TF.conv2d(x.double(), wt.double(), None, padding=1)
+    d = _lib.Conv2dDesc(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, _lib.ACT_NONE, 0.0, 0, 0)
+    dref = C.byref(d)
+    s = torch.cuda.current_stream().cuda_stream
+    uf = torch.empty(L.srx_wino_packed_floats(dref), device=dev)
+    _lib.call('srx_wino_pack', dref, wt.to(dev).data_ptr(), uf.data_ptr(), 0, s)
+    rows = L.srx_wino_stat_rows(dref)
+    assert rows == -(-(n * (h // 2) * (w // 2)) // 32)
+    y = torch.empty(n, h, w, cout, device=dev)
+    part = torch.full((rows, cout, 2), float('nan'), device=dev)
+    _lib.call('srx_wino_fwd_stats', dref, x.permute(0, 2, 3, 1).contiguous().to(dev).data_ptr(), uf.data_ptr(), None, y.data_ptr(),
+              part.data_ptr(), s)
+    assert rel(y.permute(0, 3, 1, 2), yr) < 2e-5
+    # reference partials: tiles in (image, tile row, tile column) order, 32 per block
+    tiles = yr.reshape(n, cout, h // 2, 2, w // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(-1, cout, 4)   # [T][C][4 pixels]
+    pad = rows * 32 - tiles.shape[0]
+    tiles = torch.cat([tiles, torch.zeros(pad, cout, 4, dtype=tiles.dtype)]) if pad else tiles
+    blocks = tiles.reshape(rows, 32, cout, 4)
+    s1, s2 = blocks.sum(dim=(1, 3)), blocks.square().sum(dim=(1, 3))
+    assert rel(part[..., 0], s1) < 2e-5 and rel(part[..., 1], s2) < 2e-5

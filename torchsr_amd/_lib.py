@@ -155,6 +155,7 @@ _SIGS = {
     'srx_conv2d_plan': (_I, [_D, _I, C.POINTER(C.c_int)]),
     'srx_pack_table_bytes': (_Z, [_I]),
     'srx_pack_table_build': (_I, [_P, _I, _P, _P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    'srx_pack_table_add_wino': (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_longlong), _D, _P, _P, _I]),
     'srx_pack_table_run': (_I, [_P, _I, C.c_longlong, _P]),
     'srx_conv2d_pack': (_I, [_D, _P, _P, _P, _P]),
     'srx_conv2d_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
@@ -244,12 +245,14 @@ _SIGS = {
     'srx_wino_pack': (_I, [_D, _P, _P, _I, _P]),
     'srx_wino_fwd': (_I, [_D, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_wino_bwd_data': (_I, [_D, _P, _P, _P, _P, _P, _Z, _P]),
+    'srx_wino_stat_rows': (_I, [_D]),
+    'srx_wino_fwd_stats': (_I, [_D, _P, _P, _P, _P, _P, _P]),
     'srx_gan_head_fwd': (_I, [C.POINTER(GanHead), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'srx_gan_head_bwd': (_I, [C.POINTER(GanHead), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'srx_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
 }
 # functions whose int return value is data, not a status
-_UNCHECKED = {'srx_wino_applicable', 'srx_conv2d_bwd_data_bn_rows', 'srx_conv2d_fwd_bn_in_ok', 'srx_conv2d_bwd_data_bn_in_ok', 'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_plan_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows', 'srx_bn_rows_per_block'}
+_UNCHECKED = {'srx_wino_applicable', 'srx_wino_stat_rows', 'srx_conv2d_bwd_data_bn_rows', 'srx_conv2d_fwd_bn_in_ok', 'srx_conv2d_bwd_data_bn_in_ok', 'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_plan_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows', 'srx_bn_rows_per_block'}
 
 EXPORTS = tuple(_SIGS.keys())
 

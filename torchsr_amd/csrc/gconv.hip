@@ -2067,6 +2067,10 @@ __global__ void pack_table_kernel(const PackRec* __restrict__ table) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= r.n_elems) return;
   float v = 0.f;
+  if (r.kind >= 4) {  // Winograd-domain weights (wino.hip): 4 the layer, 5 its data gradient
+    srx_wino_pack_one(r.w, r.dst, r.Cout, r.Cin, r.kind == 5, idx);
+    return;
+  }
   if (r.kind >= 2) {  // thin.hip layout: p[c][tap][ch]
     const int taps = r.KH * r.KW;
     const int ch = (int)(idx & 63), tap = (int)((idx >> 6) % taps), c = (int)(idx / (64 * taps));
@@ -2167,6 +2171,20 @@ extern "C" int srx_pack_table_build(const srx_conv2d_t* descs, int n, const floa
   }
   *nrec_out = nrec;
   *max_elems_out = maxn;
+  return SRX_OK;
+}
+
+// appends the record that refreshes a layer's Winograd-domain weights (srx_wino_pack) to a host table under construction
+extern "C" int srx_pack_table_add_wino(void* host_table, int* nrec, long long* max_elems, const srx_conv2d_t* d, const float* w,
+                                       float* upk, int transpose) {
+  SRX_REQUIRE(host_table && nrec && max_elems && d && w && upk && *nrec >= 0, "pack_table_add_wino: bad argument");
+  SRX_REQUIRE(srx_wino_applicable(d) || srx_wino_packed_floats(d) > 0, "pack_table_add_wino: not a Winograd layer");
+  PackRec r{};
+  r.dst = upk; r.w = w; r.kind = transpose ? 5 : 4;
+  r.Cout = d->Cout; r.Cin = d->Cin; r.KH = 3; r.KW = 3; r.stride = 1; r.pad = 1;
+  r.n_elems = (long long)d->Cout * d->Cin;
+  static_cast<PackRec*>(host_table)[(*nrec)++] = r;
+  if (r.n_elems > *max_elems) *max_elems = r.n_elems;
   return SRX_OK;
 }
 

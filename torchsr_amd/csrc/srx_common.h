@@ -119,3 +119,37 @@ __device__ __forceinline__ float srx_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// wino.hip's weight transform for ONE (row channel, contraction channel) pair `idx` (U = G g G^T, sixteen values scattered to
+// where wino_kernel's waves load them); shared with gconv.hip's pack_table_kernel, which refreshes the Winograd-domain weights
+// of trainable layers after an optimiser step.  transpose = 1: the layer's data gradient (channels swapped, taps flipped).
+__device__ __forceinline__ void srx_wino_pack_one(const float* __restrict__ w, float* __restrict__ upk, int Cout, int Cin,
+                                                  int transpose, int64_t idx) {
+  const int R = transpose ? Cin : Cout, K = transpose ? Cout : Cin;  // rows (the GEMM's channels out) and contraction length
+  const int r = (int)(idx / K), k = (int)(idx - (int64_t)r * K);
+  float g[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      g[i][j] = transpose ? w[(((size_t)k * Cin + r) * 3 + (2 - i)) * 3 + (2 - j)] : w[(((size_t)r * Cin + k) * 3 + i) * 3 + j];
+  float t[4][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    t[0][j] = g[0][j];
+    t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+    t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+    t[3][j] = g[2][j];
+  }
+  const int nch = K / 32, rt = R / 32;
+  const int jg = r >> 5, mrow = r & 31, kc = k / 32, kk = k % 32, quad = kk >> 2, e = kk & 3, s = quad >> 1, hh = quad & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u[4] = {t[i][0], 0.5f * (t[i][0] + t[i][1] + t[i][2]), 0.5f * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xi = 4 * i + j;
+      upk[(((((size_t)xi * rt + jg) * nch + kc) * 4 + s) * 64 + hh * 32 + mrow) * 4 + e] = u[j];
+    }
+  }
+}

@@ -367,6 +367,13 @@ class ConvState:
             self.wino_bwd = torch.empty(n, dtype=torch.float32, device=weight.device)
             call('srx_wino_pack', dref, _p(w), _p(self.wino_bwd), 1, _stream())
         self._wino_key = key
+        self._wino_desc = d
+
+
+def wino_layer_ok(st: ConvState, d: Conv2dDesc) -> bool:
+    """Does this layer's forward (and data gradient) run on Winograd F(2x2, 3x3) (csrc/wino.hip) at this size?  Wide 3x3 /
+    stride 1 / pad 1 fp32 layers without a fused LeakyReLU; small 64 -> 64 layers keep the row-tile kernel."""
+    return (not _dev.NO_WINO and st.act in (ACT_NONE, ACT_RELU) and _lib.lib().srx_wino_applicable(C.byref(d)) == 1)
 
 
 class PackTable:
@@ -386,18 +393,31 @@ class PackTable:
 
     def _build(self) -> bool:
         # (convs whose packed fp32 copies nothing reads -- dense blocks running as fused bf16 launches, RDBPack -- are left out)
-        items = [(c._st, c.weight) for c in self.convs if c.weight.requires_grad and not c._st.fused_only]
-        if not items or any(st.wpk_fwd is None or getattr(st, 'last_desc', None) is None for st, _ in items):
+        every = [(c._st, c.weight) for c in self.convs if c.weight.requires_grad and not c._st.fused_only]
+        # a layer is ready once it has run: it then has its direct packs (gconv / thin / row-tile kernels), its Winograd-domain
+        # copies (wino.hip: such a layer needs no direct pack at all), or both (it took both paths at different sizes)
+        direct = [(st, wt) for st, wt in every if st.wpk_fwd is not None and getattr(st, 'last_desc', None) is not None]
+        wino = [(st, wt) for st, wt in every if st.__dict__.get('wino_fwd') is not None]
+        seen = {id(st) for st, _ in direct} | {id(st) for st, _ in wino}
+        if not direct or any(id(st) not in seen for st, _ in every):
             return False
+        items = direct
         n = len(items)
         descs = (Conv2dDesc * n)(*[st.last_desc for st, _ in items])
         arr = lambda ptrs: (C.c_void_p * n)(*ptrs)  # noqa: E731
         w, f, b = (arr([wt.data_ptr() for _, wt in items]), arr([st.wpk_fwd.data_ptr() for st, _ in items]),
                    arr([st.wpk_bwd.data_ptr() for st, _ in items]))
-        nbytes = _lib.lib().srx_pack_table_bytes(n)
+        nbytes = _lib.lib().srx_pack_table_bytes(n + len(wino))
         host = torch.empty(nbytes, dtype=torch.uint8)
         nrec, maxn = C.c_int(0), C.c_longlong(0)
         call('srx_pack_table_build', descs, n, w, f, b, host.data_ptr(), C.byref(nrec), C.byref(maxn))
+        # layers that run on Winograd: their transformed weights are refreshed by the same launch
+        self.wino_items = wino
+        for st, wt in self.wino_items:
+            dref = C.byref(st._wino_desc)
+            call('srx_pack_table_add_wino', host.data_ptr(), C.byref(nrec), C.byref(maxn), dref, wt.data_ptr(), st.wino_fwd.data_ptr(), 0)
+            if st.wino_bwd is not None:
+                call('srx_pack_table_add_wino', host.data_ptr(), C.byref(nrec), C.byref(maxn), dref, wt.data_ptr(), st.wino_bwd.data_ptr(), 1)
         self.table = host.to(items[0][1].device)
         self.items, self.nrec, self.maxn = items, nrec.value, maxn.value
         self.fused_sig = self._fused_signature()
@@ -405,7 +425,9 @@ class PackTable:
         return True
 
     def _fused_signature(self):
-        return tuple(bool(c._st.fused_only) for c in self.convs)
+        """what decides the table's records: which convs are left out (fused dense blocks) and which carry Winograd copies"""
+        return tuple((bool(c._st.fused_only), c._st.wpk_fwd is not None, c._st.__dict__.get('wino_fwd') is not None,
+                      c._st.__dict__.get('wino_bwd') is not None) for c in self.convs)
 
     def run(self) -> bool:
         """False (and nothing done) until every layer is ready: the lazy per-layer path still covers that."""
@@ -421,6 +443,8 @@ class PackTable:
         call('srx_pack_table_run', self.table.data_ptr(), self.nrec, self.maxn, _stream())
         for st, wt in self.items:
             st._key = st.pack_key(wt)
+        for st, wt in self.wino_items:
+            st._wino_key = st.pack_key(wt)
         return True
 
 
@@ -472,16 +496,19 @@ class _Conv2d(Function):
         L = _lib.lib()
         y = torch.empty(st.out_shape(n, h, w), dtype=torch.float32, device=x.device)
         b = None if bias is None else _chk(bias.detach(), 'conv2d.bias')
-        # Frozen wide 3x3 layers (the VGG19 features called layer by layer) take the same Winograd kernel as the one-node
-        # stack.  Trainable layers do not: their Winograd-domain weights would have to be refreshed inside the captured
-        # step after every Adam update (PackTable repacks the direct layouts only).
-        ctx.wino = (not _dev.NO_WINO and not want_stats and not master.requires_grad and st.act in (ACT_NONE, ACT_RELU)
-                    and L.srx_wino_applicable(dref) == 1)
+        # wide 3x3 layers: Winograd F(2x2, 3x3), 2.25x fewer fp32 multiplications (csrc/wino.hip) -- the VGG19 features called
+        # layer by layer, the discriminators' stride-1 layers (with the BatchNorm partial statistics in the epilogue)
+        ctx.wino = wino_layer_ok(st, d) and (not want_stats or st.act == ACT_NONE)
         part = None
         if ctx.wino:
+            # (trainable layers: PackTable refreshes the Winograd-domain weights inside the captured step)
             st.pack_wino(master, d, need_bwd=ctx.needs_input_grad[0])
-            nws = L.srx_wino_ws_floats(dref, 0)
-            call('srx_wino_fwd', dref, _p(x), _p(st.wino_fwd), _p(b), _p(y), _p(_ws(nws, x)) if nws else None, nws, _stream())
+            if want_stats:
+                part = torch.empty((L.srx_wino_stat_rows(dref), st.cout, 2), dtype=torch.float32, device=x.device)
+                call('srx_wino_fwd_stats', dref, _p(x), _p(st.wino_fwd), _p(b), _p(y), _p(part), _stream())
+            else:
+                nws = L.srx_wino_ws_floats(dref, 0)
+                call('srx_wino_fwd', dref, _p(x), _p(st.wino_fwd), _p(b), _p(y), _p(_ws(nws, x)) if nws else None, nws, _stream())
         else:
             st.pack(master, d)
             if want_stats:
@@ -670,6 +697,8 @@ def bn_groups_ok(m: int, tile_rows: Optional[int], groups: int) -> bool:
 def conv_stat_tile_rows(st: ConvState, n: int, h: int, w: int) -> int:
     """Output rows (pixels) summarised by one row of the partial-statistics table ``conv2d(..., want_stats=True)``
     returns for this layer at this input size: the tile height of the launch plan."""
+    if wino_layer_ok(st, st.desc(n, h, w)):
+        return 128  # a Winograd tile block: 32 consecutive 2x2 tiles (image-major)
     out = (C.c_int * 6)()
     call('srx_conv2d_plan', C.byref(st.desc(n, h, w)), 0, out)
     return int(out[0])
@@ -1169,7 +1198,7 @@ class _FrozenConvStack(Function):
                 y = torch.empty(st.out_shape(n, h, w), dtype=torch.float32, device=x.device)
                 b = None if conv.bias is None else _chk(conv.bias.detach(), 'conv_stack.bias')
                 # wide 3x3 layers: Winograd F(2x2, 3x3), 2.25x fewer fp32 multiplications (csrc/wino.hip)
-                wino = not _dev.NO_WINO and st.act in (ACT_NONE, ACT_RELU) and L.srx_wino_applicable(dref) == 1
+                wino = wino_layer_ok(st, d)
                 if wino:
                     st.pack_wino(conv.weight, d, need_bwd=ctx.needs_input_grad[0])
                     nws = L.srx_wino_ws_floats(dref, 0)
