@@ -36,16 +36,21 @@ _BF16_THIN_OUT = [False]  # inference (test.upscale(precision='bf16')): the 64 -
 # (`x + ...` of a residual block, `conv1 + conv2` of the generator) are rounded too.  ``storage=True`` rounds every such
 # tensor where the product writes it.
 _BF16_STORAGE = [False]
+# round 5 (a yardstick, not a product mode): the products of the bf16-rounded operands summed EXACTLY (fp64, one rounding to fp32
+# at the end) instead of in fp32 in torch's order.  Two evaluations of one bf16 recipe differ by their fp32 summation order; the
+# exact-sum result is the recipe's own value, and an implementation's distance from it is judged against the distance of this
+# oracle's fp32-sum evaluation from it (tests/test_esrgan_gpu.py: the rule DESIGN.md section 4 uses for the fp32 kinks).
+_BF16_EXACT_SUMS = [False]
 
 
 @contextlib.contextmanager
-def bf16_products(thin_out: bool = False, storage: bool = False):
-    old = _BF16[0], _BF16_THIN_OUT[0], _BF16_STORAGE[0]
-    _BF16[0], _BF16_THIN_OUT[0], _BF16_STORAGE[0] = True, thin_out, storage
+def bf16_products(thin_out: bool = False, storage: bool = False, exact_sums: bool = False):
+    old = _BF16[0], _BF16_THIN_OUT[0], _BF16_STORAGE[0], _BF16_EXACT_SUMS[0]
+    _BF16[0], _BF16_THIN_OUT[0], _BF16_STORAGE[0], _BF16_EXACT_SUMS[0] = True, thin_out, storage, exact_sums
     try:
         yield
     finally:
-        _BF16[0], _BF16_THIN_OUT[0], _BF16_STORAGE[0] = old
+        _BF16[0], _BF16_THIN_OUT[0], _BF16_STORAGE[0], _BF16_EXACT_SUMS[0] = old
 
 
 def _r(t: Tensor) -> Tensor:
@@ -64,8 +69,11 @@ class _ConvBF16(torch.autograd.Function):
         ctx.cfg = (stride, pad, b is not None)
         ctx.thin_in, ctx.thin_out = (cin <= 4 and cout == 64), (cout <= 4 and cin == 64)
         ctx.save_for_backward(x, w)
+        ctx.exact = _BF16_EXACT_SUMS[0]
         if ctx.thin_out and not _BF16_THIN_OUT[0]:  # the product's thin forward kernel is exact fp32 (training paths)
             return F.conv2d(x, w, b, stride, pad)
+        if ctx.exact:
+            return F.conv2d(_r(x).double(), _r(w).double(), None if b is None else b.double(), stride, pad).float()
         return F.conv2d(_r(x), _r(w), b, stride, pad)
 
     @staticmethod
@@ -73,12 +81,15 @@ class _ConvBF16(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, pad, has_b = ctx.cfg
         dx = dw = db = None
+        up = (lambda t: t.double()) if ctx.exact else (lambda t: t)  # exact sums: fp64 accumulation of the same rounded operands
         if ctx.needs_input_grad[0]:
             exact = ctx.thin_in  # (round 4: the strided data gradients multiply bf16 operands too)
-            dx = torch.nn.grad.conv2d_input(x.shape, w if exact else _r(w), dy if exact else _r(dy), stride=stride, padding=pad)
+            dx = torch.nn.grad.conv2d_input(x.shape, up(w if exact else _r(w)), up(dy if exact else _r(dy)), stride=stride,
+                                            padding=pad).to(x.dtype)
         if ctx.needs_input_grad[1]:
             exact = ctx.thin_in or ctx.thin_out
-            dw = torch.nn.grad.conv2d_weight(x if exact else _r(x), w.shape, dy if exact else _r(dy), stride=stride, padding=pad)
+            dw = torch.nn.grad.conv2d_weight(up(x if exact else _r(x)), w.shape, up(dy if exact else _r(dy)), stride=stride,
+                                             padding=pad).to(w.dtype)
         if has_b and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
         return dx, dw, db, None, None

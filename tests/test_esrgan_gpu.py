@@ -232,72 +232,77 @@ def test_esrgan_config4_full_batch_step_vs_reference_trainer(dev):
         assert abs(lb[k].item() - w) <= 2e-2 * max(abs(w), 1e-3), (k, lb[k].item(), w)
 
 
-def _bf16_budget_elementwise(got_sd, ref_sd, name, frac, skip=()):
-    """``assert_elementwise`` with the bf16 noise floor: after ONE Adam step every element within 2e-6 of the reference except
-    a fraction ``frac`` of a tensor (an operand on a bf16 rounding boundary flips with the last fp32 bit of a sum)."""
+def _bf16_oracle_pair(t, lr, hr):
+    """Two CPU evaluations of ONE bf16 recipe (oracle.srgan.bf16_products) from the trainer's state: ``fp32sum`` accumulates the
+    products of the rounded operands in fp32 in torch's order (what round 3 / 4 compared against), ``exact`` accumulates them
+    exactly (fp64, one rounding) -- the recipe's own value.  Returns (oracle fp32sum, its losses, oracle exact, its losses)."""
+    from oracle import esrgan as OE
+    from oracle import srgan as O
+    vgg_sd = {k: v.detach().cpu().clone() for k, v in t.vgg_loss.features.state_dict().items()}
+    out = []
+    for exact in (False, True):
+        orc = OE.ESRGANStepOracle(step_state(t.generator.state_dict(), 'esrgan.G'), step_state(t.discriminator.state_dict(), 'esrgan.D'),
+                                  vgg_sd)
+        with O.bf16_products(exact_sums=exact):
+            losses = orc.gan_step(lr, hr)
+        out += [orc, losses]
+    return out
+
+
+def _bf16_within_yardstick(got_sd, fp32sum_sd, exact_sd, name, skip=()):
+    """The bf16 step's parameters after ONE Adam step, judged by a yardstick computed here instead of a budget set by hand
+    (round-4 review, item 7): any fp32-accumulating evaluation of the recipe -- this package's kernels, the oracle's own conv
+    calls -- sits some distance from the exact-sum value, because an intermediate one fp32 ulp apart rounds to the other bf16
+    neighbour in the next layer and Adam turns a gradient at the noise floor into a +-lr step either way.  The product may be
+    no further from the exact-sum result than the ORACLE'S fp32-sum evaluation is, times 1.5: per tensor the count of elements
+    more than 2e-6 away (plus the sampling noise of that count), the largest deviation (one Adam step: 2.1e-4),
+    and for the BatchNorm running statistics the largest deviation relative to the tensor's scale."""
     for k, v in got_sd.items():
-        r = ref_sd[k].detach()
         if not v.is_floating_point() or k in skip:
             continue
-        diff = (v.detach().cpu() - r.cpu()).abs()
+        e, a = exact_sd[k].detach().cpu(), fp32sum_sd[k].detach().cpu()
+        dp, da = (v.detach().cpu() - e).abs(), (a - e).abs()
         if 'running_' in k:
-            # (forward statistics of up to ten bf16-product convs in a row: 2^-9 per product, and the two launch shapes sum in
-            # another order -- measured 4.7e-3 of the largest mean on the last BatchNorm once the batch-16 plan took the
-            # 256 x 128 tile; 1e-2 = five bf16 ulps)
-            assert (diff.max() / r.abs().max().clamp_min(1e-6)).item() < 1e-2, (name, k)
-        else:
-            n_bad = int((diff > 2e-6).sum())
-            # (the per-channel vectors -- conv biases, BatchNorm gamma / beta of 32..512 entries -- are sums over the whole
-            # batch that nearly cancel under the relativistic losses: their elements at the noise floor take Adam's +-lr step
-            # the other way between two launch shapes; measured 4 of 64 and 11 of 128 on the discriminator: 15 % for them)
-            small = diff.numel() <= 512
-            assert n_bad <= max(6, int((0.15 if small else frac) * diff.numel())), (name, k, n_bad, diff.numel(), diff.max().item())
-            assert diff.max().item() <= 2.1e-4, (name, k, diff.max().item())
+            scale = e.abs().max().clamp_min(1e-6)
+            assert (dp.max() / scale).item() <= 1.5 * (da.max() / scale).item() + 2e-3, (name, k, (dp.max() / scale).item(), (da.max() / scale).item())
+            continue
+        bad_p, bad_a = int((dp > 2e-6).sum()), int((da > 2e-6).sum())
+        # (which elements sit at the noise floor is a draw: the count of flipped ones scatters like a Poisson variable, three
+        # standard deviations of the yardstick's own count are allowed on top -- it matters for the 32..512-entry vectors only)
+        assert bad_p <= 1.5 * bad_a + 3.0 * max(bad_a, 1) ** 0.5 + 2, (name, k, bad_p, bad_a, dp.numel())
+        assert dp.max().item() <= 2.1e-4, (name, k, dp.max().item())
 
 
 def test_esrgan_config4_bf16_launch_geometry(dev):
     """The configuration ``bench.py`` times for BASELINE configs[3] -- 23 RRDBs, 128x128 crops, batch 16, bf16 products: the
     fused dense-block kernels on 16 x 32 x 32 pixels (256 workgroups), the image-row weight gradient on 16 384 rows, the
-    paired problems -- pinned at that geometry, not only through its losses:
-      (a) batch 16 (the fixture's four crops x 4) ELEMENT BY ELEMENT against the bf16 batch-4 step of the crops themselves:
-          the same recipe on another launch shape.  Not bit-equal and not "to fp32 rounding": the order of the fp32 sums
-          differs between the two tile plans, an activation one ulp apart rounds to the other bf16 neighbour in the next
-          layer (2^-9 of a product) -- measured 2.6e-4 / 3.1e-4 on the content / adversarial loss -- so the losses are
-          held to 1e-3 (the fp32 tolerance of north_star, 20x tighter than the 2e-2 that held this geometry before) and
-          the parameters to the bf16 noise floor of (b);
-      (b) the bf16 batch-4 step against ``oracle.srgan.bf16_products()`` -- losses at 2e-3, parameters element by element
-          within the bf16 noise floor (measured 2.1 % at batch 2, ``test_esrgan_bf16_step_vs_bf16_oracle``)."""
-    from oracle import esrgan as OE
-    from oracle import srgan as O
+    paired problems -- pinned at that geometry, not only through its losses.  Both the batch-16 step (the fixture's four crops x 4:
+    every loss a batch mean, BatchNorm statistics those of the four crops) and the batch-4 step of the crops themselves are held
+    against the EXACT-SUM evaluation of the bf16 recipe on the CPU (``oracle.srgan.bf16_products(exact_sums=True)``): losses at
+    2e-3, parameters element by element no further from it than the oracle's own fp32-sum evaluation is (x 1.5,
+    ``_bf16_within_yardstick``) -- the yardstick is computed in the test, not raised to what a tile plan happens to produce
+    (rounds 3 / 4 held 5 %, then 8 % and 15 %, then 1e-2 on the running statistics)."""
     gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
     s_lr, s_hr = (int(v) for v in gold['b4_seeds'])
     lr4, hr4 = seeded_input((4, 3, 32, 32), s_lr), seeded_input((4, 3, 128, 128), s_hr)
     t4 = make_trainer(dev, batch=4, disable_amp=False)
-    vgg_sd = {k: v.detach().cpu().clone() for k, v in t4.vgg_loss.features.state_dict().items()}
-    orc = OE.ESRGANStepOracle(step_state(t4.generator.state_dict(), 'esrgan.G'), step_state(t4.discriminator.state_dict(), 'esrgan.D'),
-                              vgg_sd)
+    orc_a, want_a, orc_e, want_e = _bf16_oracle_pair(t4, lr4, hr4)
     l4 = t4.gan_step(lr4.to(dev), hr4.to(dev))
     got4 = [l4[k].item() for k in LOSS_KEYS]
     t16 = make_trainer(dev, batch=16, disable_amp=False)
     l16 = t16.gan_step(lr4.repeat(4, 1, 1, 1).to(dev), hr4.repeat(4, 1, 1, 1).to(dev))
     got16 = [l16[k].item() for k in LOSS_KEYS]
-    # (a) the same recipe on another launch shape
-    for a, b in zip(got16, got4):
+    for got in (got4, got16):
+        for g, w, wa in zip(got, want_e, want_a):
+            # 2e-3 of the exact-sum loss, or 1.5 x the oracle's own fp32-sum distance where that is larger
+            assert abs(g - w) <= max(2e-3 * max(abs(w), 1e-3), 1.5 * abs(wa - w)), (got, want_e, want_a)
+    for a, b in zip(got16, got4):  # the same recipe on two launch shapes
         assert abs(a - b) <= 1e-3 * max(abs(b), 1e-3), (got16, got4)
-    _bf16_budget_elementwise(t16.generator.state_dict(), t4.generator.state_dict(), 'G bf16 b16 vs b4', 5e-2)
-    ref_d = {k: v for k, v in t4.discriminator.state_dict().items()}
-    got_d = {k: v for k, v in t16.discriminator.state_dict().items() if 'running_var' not in k}
-    _bf16_budget_elementwise(got_d, ref_d, 'D bf16 b16 vs b4', 5e-2, skip=('classifier.2.bias',))
-    del t16
-    # (b) the batch-4 step against the restated recipe
-    with O.bf16_products():
-        want = orc.gan_step(lr4, hr4)
-    for g, w in zip(got4, want):
-        assert abs(g - w) <= 2e-3 * max(abs(w), 1e-3), (got4, want)
-    # (against the oracle's own summation order the flipped share is larger than between two launch shapes of one product:
-    # 5.4 % on blocks.5.RDB2.conv4.0.weight, the worst of the generator's 351 tensors -- 8 %)
-    _bf16_budget_elementwise(t4.generator.state_dict(), orc.g, 'G bf16 b4 vs oracle', 8e-2)
-    _bf16_budget_elementwise(t4.discriminator.state_dict(), orc.d, 'D bf16 b4 vs oracle', 8e-2, skip=('classifier.2.bias',))
+    _bf16_within_yardstick(t4.generator.state_dict(), orc_a.g, orc_e.g, 'G bf16 b4')
+    _bf16_within_yardstick(t4.discriminator.state_dict(), orc_a.d, orc_e.d, 'D bf16 b4', skip=('classifier.2.bias',))
+    _bf16_within_yardstick(t16.generator.state_dict(), orc_a.g, orc_e.g, 'G bf16 b16')
+    got_d = {k: v for k, v in t16.discriminator.state_dict().items() if 'running_var' not in k}  # (unbiased: n / (n - 1) differs)
+    _bf16_within_yardstick(got_d, orc_a.d, orc_e.d, 'D bf16 b16', skip=('classifier.2.bias',))
 
 
 def test_esrgan_gan_step_with_bf16_products(dev):
@@ -322,35 +327,22 @@ def test_esrgan_gan_step_with_bf16_products(dev):
 
 def test_esrgan_bf16_step_vs_bf16_oracle(dev):
     """The autocast step against an oracle that rounds the SAME operands (oracle.srgan.bf16_products: both factors of
-    every product in the forward pass, the stride-1 data gradients and the weight gradients to bf16, everything else
-    fp32): the five losses of the first step within 2e-3, and the first Adam step of every parameter in the oracle's
-    direction -- what 'within bf16 rounding of the fp32 golden' (2e-2) could not show."""
-    from oracle import esrgan as OE
-    from oracle import srgan as O
+    every product in the forward pass, the data gradients and the weight gradients to bf16, everything else fp32), summed
+    exactly: the five losses of the first step within 2e-3, and every parameter after the first Adam step no further from
+    the exact-sum result than the oracle's own fp32-sum evaluation of the recipe is (x 1.5) -- what 'within bf16 rounding
+    of the fp32 golden' (2e-2) could not show."""
     gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
     t = make_trainer(dev, disable_amp=False)
-    vgg_sd = {k: v.detach().cpu().clone() for k, v in t.vgg_loss.features.state_dict().items()}
-    orc = OE.ESRGANStepOracle(step_state(t.generator.state_dict(), 'esrgan.G'), step_state(t.discriminator.state_dict(), 'esrgan.D'),
-                              vgg_sd)
     lr, hr = torch.from_numpy(gold['low_res']), torch.from_numpy(gold['high_res'])
-    with O.bf16_products():
-        want = orc.gan_step(lr, hr)
+    orc_a, want_a, orc_e, want_e = _bf16_oracle_pair(t, lr, hr)
     losses = t.gan_step(lr.to(dev), hr.to(dev))
     got = [losses[k].item() for k in LOSS_KEYS]
-    for g, w in zip(got, want):
-        assert abs(g - w) <= 2e-3 * max(abs(w), 1e-3), (got, want)
+    for g, w, wa in zip(got, want_e, want_a):
+        assert abs(g - w) <= max(2e-3 * max(abs(w), 1e-3), 1.5 * abs(wa - w)), (got, want_e, want_a)
     fp32 = gold['gan_losses'][0]
-    assert max(abs(w - f) / max(abs(f), 1e-3) for w, f in zip(want, fp32)) > 2e-4   # the oracle did change its arithmetic
-    moved_wrong = total = 0
-    for mod, ref in ((t.generator, orc.g), (t.discriminator, orc.d)):
-        for k, v in mod.state_dict().items():
-            if v.is_floating_point() and 'running_' not in k and k != 'classifier.2.bias':
-                diff = (v.cpu() - ref[k].detach()).abs()
-                moved_wrong += int((diff > 1e-5).sum())
-                total += diff.numel()
-    # (an operand that sits on a bf16 rounding boundary rounds the other way when it differs in its last fp32 bit, which
-    # moves that product by 2^-9: the noise floor under Adam's normalisation is higher than in fp32 -- measured 2.1 %)
-    assert moved_wrong <= 5e-2 * total, (moved_wrong, total)
+    assert max(abs(w - f) / max(abs(f), 1e-3) for w, f in zip(want_e, fp32)) > 2e-4   # the oracle did change its arithmetic
+    _bf16_within_yardstick(t.generator.state_dict(), orc_a.g, orc_e.g, 'G bf16 b2')
+    _bf16_within_yardstick(t.discriminator.state_dict(), orc_a.d, orc_e.d, 'D bf16 b2', skip=('classifier.2.bias',))
 
 
 def test_esrgan_segmented_step_equals_fused(dev):
