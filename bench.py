@@ -175,7 +175,9 @@ def dominant_shape_in_graph(device, reps=20, replays=10):
     times.sort()
     us = times[len(times) // 2]
     gf = 2.0 * 18432 * 256 * 2304 / 1e9
-    return {'MxNxK': '18432x256x2304', 'launches_per_replay': reps, 'us_per_launch_in_graph': round(us, 2),
+    return {'MxNxK': '18432x256x2304', 'what': 'VGG19 block 3 (3x3 256->256 + bias + ReLU, batch 32 at 24x24) on the kernel the step runs it on '
+                                            '(Winograd F(2x2,3x3) since round 5; SRX_NO_WINO=1: the direct gather-GEMM)',
+            'launches_per_replay': reps, 'us_per_launch_in_graph': round(us, 2),
             'gflop_per_launch': round(gf, 3), 'tflops': round(gf / us * 1e3, 2), 'frac': round(gf / us * 1e3 / PEAK_TFLOPS, 4)}
 
 
@@ -217,6 +219,7 @@ def dominant_of(step_fn, peak_tflops, reps=2, slots=4096):
     tf = fl / (ms * 1e-3) / 1e12
     return {'kernel': kname, 'ms': round(ms / reps, 3), 'launches': cnt // reps, 'avg_launch_us': round(ms / cnt * 1e3, 2),
             'tflops': round(tf, 2), 'frac': round(tf / peak_tflops, 4),
+            'timing': 'eager event pair per launch (dispatch gaps included: the sum can exceed the replayed wall time by ~10 %)',
             'conv_kernel_ms': round(sum(v[0] for v in kernels.values()) / reps, 3),
             'conv_launches': sum(v[2] for v in kernels.values()) // reps}
 
@@ -245,7 +248,7 @@ def roofline_pass(trainer, lr, hr, reps=2):
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE: tools/pmc_run.sh) of
     # tools/pmc_workloads.py restricted to ONE layer shape; counters cannot be read from inside the process
     measured = {}
-    for tname in ('r03_traffic.json', 'r04_traffic.json'):  # (later rounds add shapes / supersede entries)
+    for tname in ('r03_traffic.json', 'r04_traffic.json', 'r05_traffic.json'):  # (later rounds add shapes / supersede entries)
         tpath = os.path.join(ROOT, 'profiles', tname)
         if os.path.exists(tpath):
             measured.update(json.load(open(tpath)))
@@ -259,9 +262,18 @@ def roofline_pass(trainer, lr, hr, reps=2):
                        'traffic': round(ent['hbm_bytes_per_launch']) if ent else None,
                        'algorithmic_bytes': ent.get('algorithmic_bytes_per_launch')})
     top = shapes[0] if shapes else {}
+    wino = kname.startswith('wino_kernel')
     return {
         'bound': 'mfma', 'kernel': kname, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(achieved / PEAK_TFLOPS, 4),
+        # Winograd F(2x2, 3x3) executes 16 multiplications where the direct convolution executes 36: `achieved` counts the
+        # ALGORITHMIC FLOPs of the convolution (2 x M x N x K, as for every other kernel), so it can exceed what the matrix
+        # cores could do on the direct form; `mfma_frac` is the share of the fp32 MFMA peak the kernel's own MFMAs reach
+        'algorithm': 'Winograd F(2x2,3x3), fp32' if wino else 'direct gather-GEMM, fp32',
+        'executed_over_algorithmic_flops': round(16.0 / 36.0, 4) if wino else 1.0,
+        'mfma_frac': round(achieved * (16.0 / 36.0 if wino else 1.0) / PEAK_TFLOPS, 4),
+        'timing': 'eager pass, one HIP event pair per launch on the launch stream (srx_prof_*): dispatch gaps included, a few per cent pessimistic against the replayed graph',
+
         'traffic': top.get('traffic'), 'traffic_shape_MxNxK': top.get('MxNxK'),
         'algorithmic_bytes_per_launch': top.get('algorithmic_bytes'),
         'avg_launch_us': round(ms / cnt * 1e3, 2), 'launches_per_step': cnt // reps,
@@ -469,7 +481,10 @@ class _WindowHolder:
 
     def __init__(self, device, k, whole_cu):
         self.k, self.whole_cu = k, whole_cu
-        self.side = torch.cuda.Stream(device)
+        # (high priority: HIP maps streams onto a few hardware queues and packets of one queue run in order -- on a queue
+        # shared with RCCL's stream the holder kept the all-reduce kernel, and through its wait() the whole step, waiting for
+        # the holder's 50 ms deadline: 58 ms per step, measured; streams of another priority take another queue)
+        self.side = torch.cuda.Stream(device, priority=-1)
         self.flags = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(2)]
         self.i, self.windows = 0, 0
         self.ev = torch.cuda.Event()
@@ -735,8 +750,7 @@ def main():
                 try:
                     out['roofline'] = roofline_pass(trainer, lr, hr)
                     out['roofline']['north_star'] = north_star_in_graph(device)
-                    if out['roofline'].get('traffic_shape_MxNxK') == '18432x256x2304':
-                        out['roofline']['dominant_shape_in_graph'] = dominant_shape_in_graph(device)
+                    out['roofline']['dominant_shape_in_graph'] = dominant_shape_in_graph(device)
                 except Exception as exc:  # noqa: BLE001
                     print(f'bench.py: roofline pass failed: {type(exc).__name__}: {exc}', file=sys.stderr)
                     out.setdefault('roofline', None)
