@@ -471,6 +471,34 @@ int srx_wino_stat_rows(const srx_conv2d_t* d);
 int srx_wino_fwd_stats(const srx_conv2d_t* d, const float* x, const float* upk, const float* bias, float* y, float* stats,
                        void* stream);
 
+/* ------------------------------------------------- bf16 storage of activations on the training path (round 5) */
+/* Under autocast (esrgan/trainer.py:446,461) the reference's convs read and write half tensors.  These entry points keep the
+ * activations and gradients BETWEEN the 3x3 / stride 1 / pad 1 convs of a frozen stack (VGG19[:36], srgan/loss.py:30-34,52-53)
+ * as bf16 NHWC tensors.  The arithmetic is that of precision = 1 (bf16 products, fp32 accumulation): an operand is rounded
+ * once, by its producer, instead of by every consumer's loader.  d->precision must be 1, Cin and Cout multiples of 64.
+ * Packed weights are bf16: srx_conv3x3_bf16s_packed_bytes(d) bytes per copy (forward; data gradient = transposed, taps flipped).
+ * which: 0 forward, 1 data gradient.  Tensors: `void*` = bf16. */
+int srx_conv3x3_bf16s_applicable(const srx_conv2d_t* d);
+size_t srx_conv3x3_bf16s_packed_bytes(const srx_conv2d_t* d);
+int srx_conv3x3_bf16s_pack(const srx_conv2d_t* d, const float* w, void* wpk_fwd, void* wpk_bwd /* may be NULL */, void* stream);
+size_t srx_conv3x3_bf16s_ws_floats(const srx_conv2d_t* d, int which);
+/* y = [relu](conv(x) + bias): x bf16 [N][H][W][Cin]; y bf16 (y_is_bf16) or fp32 [N][H][W][Cout] */
+int srx_conv3x3_bf16s_fwd(const srx_conv2d_t* d, const void* x, const void* wpk_fwd, const float* bias, int relu, void* y,
+                          int y_is_bf16, float* ws, size_t ws_floats, void* stream);
+/* dx = conv^T(dy) [* (relu_out > 0)]: dy bf16 [N][H][W][Cout]; relu_out (may be NULL): the bf16 output of the ReLU that produced
+ * this layer's input; dx bf16 (dx_is_bf16) or fp32 [N][H][W][Cin] */
+int srx_conv3x3_bf16s_bwd_data(const srx_conv2d_t* d, const void* dy, const void* wpk_bwd, const void* relu_out, void* dx,
+                               int dx_is_bf16, float* ws, size_t ws_floats, void* stream);
+/* the 3 -> 64 first layer in front of such a stack: srx_conv2d_fwd's kernel for it (precision = 1) with a bf16 output;
+ * x fp32 [N][H][W][4], wpk_fwd: the layer's ordinary forward pack, y bf16 [N][H][W][64] */
+int srx_conv2d_fwd_first3_to_bf16(const srx_conv2d_t* d, const float* x, const float* wpk_fwd, const float* bias, void* y,
+                                  void* stream);
+/* pools and the topmost activation backward of such a stack.  The pools read the fp32 output of the conv below them (the
+ * choice of the maximum must not depend on bf16 rounding) and round what they hand on. */
+int srx_maxpool2x2_fwd_to_bf16(const float* x, void* y, int N, int H, int W, int C, void* stream);
+int srx_maxpool2x2_relu_bwd_bf16(const void* dy, const float* x, void* dx, int N, int H, int W, int C, void* stream);
+int srx_act_bwd_from_out_to_bf16(const float* dy, const float* y, void* dx, int64_t n, int act, float slope, void* stream);
+
 /* ----------------------------------------------------------------- pooling */
 /* nn.MaxPool2d(2,2) of VGG19 (torchvision cfg 'E', srgan/loss.py:30-31); H, W even */
 int srx_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);

@@ -294,6 +294,94 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const float* __
   }
 }
 
+// ---- bf16-storage forms (round 5: the frozen VGG19 stack under autocast keeps its activations and gradients as bf16 between
+// convs, gconv.hip "bf16 STORAGE").  The pools keep reading the fp32 output of the conv below them: which of two window
+// entries is the maximum must not depend on bf16 rounding (ties would route the gradient to another pixel than the
+// recipe's fp32 comparison does); their OUTPUTS feed convs only and are rounded here instead of in the consumer's loader.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 pack_bf16x4(const f32x4& v) {
+  const bf16x2_t lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
+  return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+}
+__device__ __forceinline__ f32x4 unpack_bf16x4(const uint2 u) {
+  return (f32x4){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                 __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+}
+
+__global__ void maxpool_fwd_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int N, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, cq = C / 4;
+  const int64_t total = (int64_t)N * Ho * Wo * cq;
+  GRID_STRIDE(i, total) {
+    const int q = (int)(i % cq);
+    int64_t t = i / cq;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const float* p = x + (((int64_t)n * H + 2 * oh) * W + 2 * ow) * C + q * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + C);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)W * C);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(p + (int64_t)W * C + C);
+    f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+    *reinterpret_cast<uint2*>(y + i * 4) = pack_bf16x4(m);
+  }
+}
+
+// maxpool_bwd_kernel<true> with a bf16 gradient in and out (the values are routed, never added: rounding commutes)
+__global__ void maxpool_relu_bwd_bf16_kernel(const unsigned short* __restrict__ dy, const float* __restrict__ x,
+                                             unsigned short* __restrict__ dx, int N, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, cq = C / 4;
+  const int64_t total = (int64_t)N * Ho * Wo * cq;
+  GRID_STRIDE(i, total) {
+    const int q = (int)(i % cq);
+    int64_t t = i / cq;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const int64_t base = (((int64_t)n * H + 2 * oh) * W + 2 * ow) * C + q * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + base);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(x + base + C);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(x + base + (int64_t)W * C);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(x + base + (int64_t)W * C + C);
+    const f32x4 g = unpack_bf16x4(*reinterpret_cast<const uint2*>(dy + i * 4));
+    f32x4 ga, gb, gc, gd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int idx = 0;
+      float m = a[e];
+      if (b[e] > m) { m = b[e]; idx = 1; }
+      if (c[e] > m) { m = c[e]; idx = 2; }
+      if (d[e] > m) { m = d[e]; idx = 3; }
+      if (!(m > 0.f)) idx = -1;
+      ga[e] = idx == 0 ? g[e] : 0.f;
+      gb[e] = idx == 1 ? g[e] : 0.f;
+      gc[e] = idx == 2 ? g[e] : 0.f;
+      gd[e] = idx == 3 ? g[e] : 0.f;
+    }
+    *reinterpret_cast<uint2*>(dx + base) = pack_bf16x4(ga);
+    *reinterpret_cast<uint2*>(dx + base + C) = pack_bf16x4(gb);
+    *reinterpret_cast<uint2*>(dx + base + (int64_t)W * C) = pack_bf16x4(gc);
+    *reinterpret_cast<uint2*>(dx + base + (int64_t)W * C + C) = pack_bf16x4(gd);
+  }
+}
+
+// act_bwd_from_out_kernel with a bf16 result (n a multiple of 4)
+__global__ void act_bwd_from_out_to_bf16_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                unsigned short* __restrict__ dx, int64_t n4, int act, float slope) {
+  GRID_STRIDE(i, n4) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+    const f32x4 o = *reinterpret_cast<const f32x4*>(y + i * 4);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = o[e] > 0.f ? g[e] : (act == SRX_ACT_RELU ? 0.f : g[e] * slope);
+    *reinterpret_cast<uint2*>(dx + i * 4) = pack_bf16x4(r);
+  }
+}
+
 // dst[m][dst_off + c] (+)= src[m][src_off + c], c < C: channel concat / split of NHWC tensors
 __global__ void copy_channels_kernel(const float* __restrict__ src, int scs, int soff, float* __restrict__ dst, int dcs,
                                      int doff, int C, int64_t M, int accumulate) {
@@ -524,6 +612,36 @@ extern "C" int srx_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W,
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid((int64_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
                      srx_stream(stream), x, y, N, H, W, C);
   SRX_CHECK_LAUNCH("maxpool_fwd_kernel");
+  return SRX_OK;
+}
+
+// y = bf16(maxpool2x2(x)): x fp32 NHWC, y bf16 NHWC (bf16-storage conv stacks)
+extern "C" int srx_maxpool2x2_fwd_to_bf16(const float* x, void* y, int N, int H, int W, int C, void* stream) {
+  SRX_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "maxpool2x2_fwd_to_bf16: bad argument");
+  SRX_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2x2_fwd_to_bf16: H, W must be even and C a multiple of 4");
+  hipLaunchKernelGGL(maxpool_fwd_to_bf16_kernel, dim3(stream_grid((int64_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                     srx_stream(stream), x, static_cast<unsigned short*>(y), N, H, W, C);
+  SRX_CHECK_LAUNCH("maxpool_fwd_to_bf16_kernel");
+  return SRX_OK;
+}
+
+// srx_maxpool2x2_relu_bwd with bf16 gradients: dy bf16 [N][H/2][W/2][C], x fp32 [N][H][W][C] (a ReLU output), dx bf16 like x
+extern "C" int srx_maxpool2x2_relu_bwd_bf16(const void* dy, const float* x, void* dx, int N, int H, int W, int C, void* stream) {
+  SRX_REQUIRE(dy && x && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool2x2_relu_bwd_bf16: bad argument");
+  SRX_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2x2_relu_bwd_bf16: H, W must be even and C a multiple of 4");
+  hipLaunchKernelGGL(maxpool_relu_bwd_bf16_kernel, dim3(stream_grid((int64_t)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                     srx_stream(stream), static_cast<const unsigned short*>(dy), x, static_cast<unsigned short*>(dx), N, H, W, C);
+  SRX_CHECK_LAUNCH("maxpool_relu_bwd_bf16_kernel");
+  return SRX_OK;
+}
+
+// srx_act_bwd_from_out with a bf16 result: dx = bf16(dy * act'(y)), n a multiple of 4
+extern "C" int srx_act_bwd_from_out_to_bf16(const float* dy, const float* y, void* dx, int64_t n, int act, float slope, void* stream) {
+  SRX_REQUIRE(dy && y && dx && n > 0 && n % 4 == 0, "act_bwd_from_out_to_bf16: bad argument");
+  SRX_REQUIRE(act == SRX_ACT_RELU || act == SRX_ACT_LRELU, "act_bwd_from_out_to_bf16: act must be RELU or LRELU");
+  hipLaunchKernelGGL(act_bwd_from_out_to_bf16_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, srx_stream(stream), dy, y,
+                     static_cast<unsigned short*>(dx), n / 4, act, slope);
+  SRX_CHECK_LAUNCH("act_bwd_from_out_to_bf16_kernel");
   return SRX_OK;
 }
 

@@ -75,6 +75,9 @@ struct GArgs {
   const float* mask;
   float mask_slope;
   int mask_lo, mask_hi;
+  // PR = 2 (bf16 STORAGE, round 5): `in` and `w` hold bf16 values -- described to the kernel as fp32 tensors of half the
+  // channel count, so every gather offset below is the fp32 code's -- and `out` / `mask` are bf16 tensors when these are set
+  int out16, mask16;
 };
 
 
@@ -106,8 +109,8 @@ template <int BM, int BN, int WM, int WN, int KS, int XR, int PR, int UP = 0, in
 __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   static_assert(XR == 0 || (XR == 16 && KS == 1), "extra rows: 16, without the in-workgroup K split");
   static_assert(PR == 0 || XR == 0, "the 16-row extension is fp32 only");
-  constexpr int BKL = PR ? BK / 2 : BK;  // floats per LDS row
-  constexpr int NS = PR ? 2 : 4;         // MFMA sub-steps per chunk
+  constexpr int BKL = PR == 1 ? BK / 2 : BK;  // floats per LDS row
+  constexpr int NS = PR == 1 ? 2 : 4;         // MFMA sub-steps per chunk
   constexpr int BMT = BM + XR;  // rows of the tile
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
@@ -276,9 +279,9 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   };
   // fp32: 16-byte quad q of the row at quad q ^ ((row>>1)&7).  bf16: the quad shrinks to 8 bytes; quads 2g, 2g+1
   // form the 16-byte group g (k = 8g..8g+7, one MFMA operand), stored at group g ^ ((row>>2)&3).
-  const int wchunk = PR ? (((q >> 1) ^ ((r0 >> 2) & 3)) * 4 + (q & 1) * 2) : (q ^ ((r0 >> 1) & 7)) * 4;
+  const int wchunk = PR == 1 ? (((q >> 1) ^ ((r0 >> 2) & 3)) * 4 + (q & 1) * 2) : (q ^ ((r0 >> 1) & 7)) * 4;
   auto put = [&](float* dst, const f32x4& v) {
-    if (PR) {
+    if (PR == 1) {
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       const bf16x2 lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
       *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
@@ -298,7 +301,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   };
 
   const int h = lane >> 5, l31 = lane & 31;
-  const int xr = PR ? (l31 >> 2) & 3 : (l31 >> 1) & 7;
+  const int xr = PR == 1 ? (l31 >> 2) & 3 : (l31 >> 1) & 7;
   const int arow = (wm * WM + l31) * BKL, brow = (wn * WN + l31) * BKL;
   // extra 16 rows: wave w < BN/16 owns the 16x16 block of columns 16w..16w+15
   //   v_mfma_f32_16x16x4_f32: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D: col = l&15, row = 4(l>>4) + reg
@@ -330,7 +333,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   };
   auto mma = [&](int set) {
     __builtin_amdgcn_s_setprio(1);
-    if (PR) {
+    if (PR) {  // (PR = 2: a 16-byte quad of the stored tensor IS eight bf16 k-values, one MFMA operand)
       typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -469,7 +472,11 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   const size_t tile_base = out_elem(m0);
   const unsigned tb_lo = (unsigned)srx_uniform((int)(unsigned)(tile_base & 0xffffffffu));
   const unsigned tb_hi = (unsigned)srx_uniform((int)(unsigned)(tile_base >> 32));
-  const __amdgpu_buffer_rsrc_t rout = srx_rsrc(a.out + (((size_t)tb_hi << 32) | tb_lo), 0xfffffff0u);
+  // (PR = 2: bf16 outputs / masks -- offsets below stay 4 x the element index and are halved at the access)
+  // (a bf16-storage launch's mask is always bf16; its output type picks one of two copies of the epilogue below)
+  const bool out16 = PR == 2 && a.out16;
+  constexpr bool mask16 = PR == 2;
+  const __amdgpu_buffer_rsrc_t rout = srx_rsrc(reinterpret_cast<char*>(a.out) + ((((size_t)tb_hi << 32) | tb_lo) << (out16 ? 1 : 2)), 0xfffffff0u);
   // (the addend's tile base differs from the output's when it has its own row stride -- linear outputs only; built
   // inside the add-mode paths so that the other epilogues do not carry its scalars)
   auto make_radd = [&]() {
@@ -478,7 +485,8 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
     const unsigned ab_hi = (unsigned)srx_uniform((int)(unsigned)(add_base >> 32));
     return srx_rsrc(a.add + (((size_t)ab_hi << 32) | ab_lo), 0xfffffff0u);
   };
-  const __amdgpu_buffer_rsrc_t rmask = srx_rsrc((a.mask ? a.mask : a.out) + (((size_t)tb_hi << 32) | tb_lo), 0xfffffff0u);
+  const __amdgpu_buffer_rsrc_t rmask = srx_rsrc(reinterpret_cast<const char*>(a.mask ? a.mask : a.out) +
+                                                    ((((size_t)tb_hi << 32) | tb_lo) << (mask16 ? 1 : 2)), 0xfffffff0u);
 
   float bv[TN];
   unsigned ocol[TN];  // byte offset of the column inside its output row
@@ -502,8 +510,9 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
 
-  auto store_tile = [&](auto linear, auto accum) {  // one copy per addressing / epilogue mode (bit 0: addend, bit 1: mask), chosen by ONE branch
+  auto store_tile = [&](auto linear, auto accum, auto o16) {  // one copy per addressing / epilogue mode (bit 0: addend, bit 1: mask), chosen by ONE branch
     constexpr int MODE = decltype(accum)::value;
+    constexpr bool OUT16 = decltype(o16)::value;
     __amdgpu_buffer_rsrc_t radd = rout;
     bool cak[TN];  // the column takes the addend
     if constexpr ((MODE & 1) != 0) {
@@ -535,8 +544,13 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
             av[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                 radd, (int)((mok && cok[j] && cak[j]) ? arow + ocol[j] : 0xffffffffu), 0, 0));
           // (a column outside the mask range reads nothing: its offset is pointed out of range)
-          if (MODE & 2)
-            mv[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)(cmk[j] ? off : 0xffffffffu), 0, 0));
+          if (MODE & 2) {
+            const unsigned moff = cmk[j] ? off : 0xffffffffu;
+            if (mask16)
+              mv[r][j] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rmask, (int)(moff == 0xffffffffu ? moff : moff >> 1), 0, 0) << 16);
+            else
+              mv[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)moff, 0, 0));
+          }
         }
       }
 #pragma unroll
@@ -552,7 +566,11 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
           v = v > 0.f ? v : v * a.slope;
           if (MODE & 1) v = v * a.oscale + av[r][j] * a.ascale;
           if (MODE & 2) v = (cmk[j] && !(mv[r][j] > 0.f)) ? v * a.mask_slope : v;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, offs[r][j], 0, 0);
+          if (OUT16)
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), rout,
+                                                  (int)(offs[r][j] == 0xffffffffu ? 0xffffffffu : offs[r][j] >> 1), 0, 0);
+          else
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, offs[r][j], 0, 0);
         }
       }
     }
@@ -560,16 +578,24 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   using M0 = std::integral_constant<int, 0>; using M1 = std::integral_constant<int, 1>;
   using M2 = std::integral_constant<int, 2>; using M3 = std::integral_constant<int, 3>;
   const int emode = (a.add ? 1 : 0) | (a.mask ? 2 : 0);
-  if (a.linear_out) {
-    if (emode == 0) store_tile(std::true_type{}, M0{});
-    else if (emode == 1) store_tile(std::true_type{}, M1{});
-    else if (emode == 2) store_tile(std::true_type{}, M2{});
-    else store_tile(std::true_type{}, M3{});
+  if constexpr (PR == 2) {  // bf16 storage: linear outputs, no addend (the host code asks for nothing else)
+    if (out16) {
+      if (emode & 2) store_tile(std::true_type{}, M2{}, std::true_type{});
+      else store_tile(std::true_type{}, M0{}, std::true_type{});
+    } else {
+      if (emode & 2) store_tile(std::true_type{}, M2{}, std::false_type{});
+      else store_tile(std::true_type{}, M0{}, std::false_type{});
+    }
+  } else if (a.linear_out) {
+    if (emode == 0) store_tile(std::true_type{}, M0{}, std::false_type{});
+    else if (emode == 1) store_tile(std::true_type{}, M1{}, std::false_type{});
+    else if (emode == 2) store_tile(std::true_type{}, M2{}, std::false_type{});
+    else store_tile(std::true_type{}, M3{}, std::false_type{});
   } else {
-    if (emode == 0) store_tile(std::false_type{}, M0{});
-    else if (emode == 1) store_tile(std::false_type{}, M1{});
-    else if (emode == 2) store_tile(std::false_type{}, M2{});
-    else store_tile(std::false_type{}, M3{});
+    if (emode == 0) store_tile(std::false_type{}, M0{}, std::false_type{});
+    else if (emode == 1) store_tile(std::false_type{}, M1{}, std::false_type{});
+    else if (emode == 2) store_tile(std::false_type{}, M2{}, std::false_type{});
+    else store_tile(std::false_type{}, M3{}, std::false_type{});
   }
 
   float xs1 = 0.f, xs2 = 0.f;
@@ -705,7 +731,13 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const GArgs a) {
     ok[j] = r < BM && m0 + r < a.M;
     const int mc = min(m0 + (r < BM ? r : rl), a.M - 1);
     av[j] = has_add ? *reinterpret_cast<const f32x4*>(a.add + (size_t)mc * a.add_ld + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    mv[j] = has_mask ? *reinterpret_cast<const f32x4*>(a.mask + (size_t)mc * a.Co + col) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    if (has_mask && a.mask16) {  // (bf16 mask tensor: four values in 8 bytes)
+      const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.mask) + (size_t)mc * a.Co + col);
+      mv[j] = (f32x4){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                      __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+    } else {
+      mv[j] = has_mask ? *reinterpret_cast<const f32x4*>(a.mask + (size_t)mc * a.Co + col) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    }
     v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   for (int z0 = 0; z0 < a.tail_split; z0 += 4) {
@@ -742,7 +774,14 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const GArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = mv[j][e] > 0.f ? w[e] : w[e] * a.mask_slope;
       }
-      *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col) = w;
+      if (a.out16) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 lo = {(__bf16)w[0], (__bf16)w[1]}, hi = {(__bf16)w[2], (__bf16)w[3]};
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.out) + (size_t)m * a.Co + col) =
+            make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+      } else {
+        *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.Co + col) = w;
+      }
     }
   }
   if (a.part) {
@@ -1671,7 +1710,7 @@ size_t plan_ws_floats(const Plan& p) { return p.split > 1 ? (size_t)p.tail * p.s
 template <int BM, int BN, int WM, int WN, int KS, int XR, int PR = 0, int BIG = 0>
 int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
   const int ktab_chunks = p.full > 0 || p.split == 1 ? a.kchunks : p.kc_per_split;
-  const size_t lds = (size_t)(KS * 3 * (BM + XR + BN) * BK) * (PR ? 2 : 4) + (size_t)ktab_chunks * 8 * sizeof(int2);
+  const size_t lds = (size_t)(KS * 3 * (BM + XR + BN) * BK) * (PR == 1 ? 2 : 4) + (size_t)ktab_chunks * 8 * sizeof(int2);
   if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
   static std::once_flag once;
   std::call_once(once, [] {
@@ -1682,8 +1721,8 @@ int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
   char nm[112];  // kernel + GEMM shape: the roofline leg of bench.py groups launches by both
   if (srx_prof_on())
     snprintf(nm, sizeof(nm), "gconv_kernel<%d, %d, %d, %d, %d, %d, %d%s> MxNxK=%dx%dx%d", BM, BN, WM, WN, KS, XR, PR, BIG ? ", big" : "",
-             a.M, a.Cn, a.K);
-  SRX_LAUNCH_PROF(nm, 2.0 * a.M * a.Cn * a.K, (gconv_kernel<BM, BN, WM, WN, KS, XR, PR, BIG>), grid,
+             a.M, a.Cn, PR == 2 ? 2 * a.K : a.K);  // (PR = 2: K counts floats = pairs of bf16 values)
+  SRX_LAUNCH_PROF(nm, 2.0 * a.M * a.Cn * (PR == 2 ? 2 * a.K : a.K), (gconv_kernel<BM, BN, WM, WN, KS, XR, PR, BIG>), grid,
                   dim3((BM / WM) * (BN / WN) * 64 * KS), lds, st, a);
   SRX_CHECK_LAUNCH("gconv_kernel");
   if (p.split > 1) {
@@ -1807,6 +1846,14 @@ int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t 
       if (p.BM == 128 && p.BN == 32) return launch_gconv<128, 32, 32, 32, 1, 0, 0, 1>(a, p, st);
     }
     SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: no whole-frame kernel for tile %dx%d", p.BM, p.BN);
+  }
+  if (precision == 2) {  // bf16 storage (round 5): the tensors hold bf16, a chunk is 64 k-values
+    if (p.BM == 256 && p.BN == 128) return launch_gconv<256, 128, 64, 64, 1, 0, 2>(a, p, st);
+    if (p.BM == 128 && p.BN == 128) return launch_gconv<128, 128, 64, 32, 1, 0, 2>(a, p, st);
+    if (p.BM == 128 && p.BN == 64) return launch_gconv<128, 64, 32, 32, 1, 0, 2>(a, p, st);
+    if (p.BM == 64 && p.BN == 64)
+      return p.ks == 2 ? launch_gconv<64, 64, 32, 32, 2, 0, 2>(a, p, st) : launch_gconv<64, 64, 32, 32, 1, 0, 2>(a, p, st);
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: no bf16-storage kernel for tile %dx%d", p.BM, p.BN);
   }
   if (precision) {  // bf16 products (plans made with `bf16 = true` never ask for the 144-row tiles)
     if (p.BM == 256 && p.BN == 128) return launch_gconv<256, 128, 64, 64, 1, 0, 1>(a, p, st);
@@ -2642,4 +2689,116 @@ extern "C" int srx_conv2d_bwd_weight(const srx_conv2d_t* d, const float* x, cons
                                      float* db, float* ws, size_t ws_floats, void* stream) {
   SRX_REQUIRE(x && dy && dw && ws, "conv2d_bwd_weight: null pointer");
   return srx_conv2d_bwd_weight_multi(d, 1, 1, &x, &dy, &dw, accumulate, db ? &db : nullptr, ws, ws_floats, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 STORAGE of activations on the training path (round 5; round-4 review, item 2): 3x3 / stride 1 / pad 1 layers whose
+// input AND output tensors are bf16 NHWC.  The arithmetic is the bf16-product recipe of precision = 1 to the letter -- every
+// operand of such a layer was rounded to bf16 when it was staged; here the PRODUCER rounds it once instead of every consumer
+// -- so the oracle and its tolerances do not change; what changes is the traffic (half the bytes, no fp32 -> bf16 conversion
+// in the loader: 18.8 VALU instructions per MFMA on the 64-column layers, profiles/r04_pmc_esrgan.txt).  The kernel is
+// gconv_kernel<..., PR = 2>: the bf16 tensors are described as fp32 tensors of HALF the channel count, so a 128-byte k-chunk
+// is 64 channels of one tap and every gather offset is the fp32 code's; a 16-byte quad is one v_mfma_f32_32x32x16_bf16 operand.
+// Used by the frozen VGG19 stack of the perceptual loss under autocast (esrgan/trainer.py:461-467, srgan/loss.py:52-53).
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+bool bf16s_shape_ok(const srx_conv2d_t* d) {
+  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->shuffle && d->up != 2 && d->precision == 1 &&
+         d->Cin % 64 == 0 && d->Cout % 64 == 0 && d->Cin_s == d->Cin && d->Cout_s == d->Cout &&
+         (int64_t)d->N * d->H * d->W < (1 << 24) && (int64_t)d->N * d->H * d->W * std::max(d->Cin, d->Cout) < (1LL << 30);
+}
+
+// wf[co][(kh, kw, ci)] = bf16(w[co][ci][kh][kw]);  wb[ci][(kh, kw, co)] = bf16(w[co][ci][2 - kh][2 - kw])
+__global__ void bf16s_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wf, __bf16* __restrict__ wb, int Cout, int Cin) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)Cout * Cin * 9) return;
+  const int ci = (int)(idx % Cin);
+  const int t = (int)((idx / Cin) % 9);
+  const int co = (int)(idx / ((int64_t)Cin * 9));
+  const __bf16 v = (__bf16)w[((size_t)co * Cin + ci) * 9 + t];
+  wf[idx] = v;  // ((co * 9 + t) * Cin + ci)
+  if (wb) wb[((size_t)ci * 9 + (8 - t)) * Cout + co] = v;
+}
+
+Plan bf16s_plan(const srx_conv2d_t* d, int which) {
+  const int cc = which ? d->Cout : d->Cin, cn = which ? d->Cin : d->Cout;
+  return make_plan(d->N * d->H * d->W, cn, 9 * cc / 64, true, true, false);
+}
+
+int bf16s_run(const srx_conv2d_t* d, int which, const void* in16, const void* wpk16, const float* bias, int relu,
+              const void* mask16, void* out, int out_is_bf16, float* ws, size_t ws_floats, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRX_REQUIRE(in16 && wpk16 && out && in16 != out, "conv3x3_bf16s: null pointer / in place");
+  if (!bf16s_shape_ok(d))
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv3x3_bf16s: 3x3 / stride 1 / pad 1 layers with precision = 1 and channel counts that are multiples of 64 only");
+  const int cc = which ? d->Cout : d->Cin, cn = which ? d->Cin : d->Cout;
+  GArgs a{};
+  a.in = static_cast<const float*>(in16); a.w = static_cast<const float*>(wpk16); a.bias = bias;
+  set_mgrid(a, d->N, d->H, d->W);
+  a.Hi = d->H; a.Wi = d->W; a.Ci = cc / 2;  // (floats = pairs of bf16 channels)
+  a.in_stride = 1; a.nth = 3; a.ntw = 3; a.dh0 = -1; a.dw0 = -1;
+  a.Ck = cc / 2; a.K = 9 * cc / 2; a.Kp = a.K;
+  a.Cn = cn; a.Cs = cn; a.Ho = d->H; a.Wo = d->W; a.Co = cn;
+  a.out_stride = 1; a.linear_out = 1;
+  a.act = relu ? SRX_ACT_RELU : SRX_ACT_NONE;
+  a.slope = relu ? 0.f : 1.f;
+  a.out = static_cast<float*>(out);
+  a.out16 = out_is_bf16 ? 1 : 0;
+  a.oscale = 1.f; a.add_ld = cn; a.add_hi = 0x7fffffff; a.ascale = 1.f;
+  if (mask16) { a.mask = static_cast<const float*>(mask16); a.mask16 = 1; a.mask_slope = 0.f; a.mask_lo = 0; a.mask_hi = cn; }
+  a.in_bytes = (size_t)d->N * d->H * d->W * cc * 2;
+  a.w_bytes = (unsigned)((size_t)cn * 9 * cc * 2);
+  a.in_margin = 4u * (unsigned)((a.Wi + 1) * a.Ci);
+  return run_gconv(a, bf16s_plan(d, which), ws, ws_floats, srx_stream(stream), 2);
+}
+
+}  // namespace
+
+extern "C" int srx_conv3x3_bf16s_applicable(const srx_conv2d_t* d) { return d && check_desc(d) == SRX_OK && bf16s_shape_ok(d) ? 1 : 0; }
+
+// bytes of ONE packed copy (forward or data gradient): Cout x 9 x Cin bf16 values
+extern "C" size_t srx_conv3x3_bf16s_packed_bytes(const srx_conv2d_t* d) {
+  return (d && bf16s_shape_ok(d)) ? (size_t)d->Cout * 9 * d->Cin * 2 : 0;
+}
+
+extern "C" int srx_conv3x3_bf16s_pack(const srx_conv2d_t* d, const float* w, void* wpk_fwd, void* wpk_bwd, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRX_REQUIRE(w && wpk_fwd, "conv3x3_bf16s_pack: null pointer");
+  if (!bf16s_shape_ok(d)) SRX_FAIL(SRX_E_UNSUPPORTED, "conv3x3_bf16s_pack: not a bf16-storage layer");
+  const int64_t n = (int64_t)d->Cout * d->Cin * 9;
+  hipLaunchKernelGGL(bf16s_pack_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, srx_stream(stream), w,
+                     static_cast<__bf16*>(wpk_fwd), static_cast<__bf16*>(wpk_bwd), d->Cout, d->Cin);
+  SRX_CHECK_LAUNCH("bf16s_pack_kernel");
+  return SRX_OK;
+}
+
+// workspace (floats) of the forward (which = 0) / data gradient (which = 1): K-split partial tiles of the last round
+extern "C" size_t srx_conv3x3_bf16s_ws_floats(const srx_conv2d_t* d, int which) {
+  if (!d || check_desc(d) != SRX_OK || !bf16s_shape_ok(d)) return 0;
+  return plan_ws_floats(bf16s_plan(d, which));
+}
+
+// the 3 -> 64 first layer in front of such a stack (srx_conv2d_fwd's first3x3 kernel, precision = 1) writing a bf16 tensor:
+// x fp32 [N][H][W][4], wpk: the layer's ordinary forward pack, y bf16 [N][H][W][64]
+extern "C" int srx_conv2d_fwd_first3_to_bf16(const srx_conv2d_t* d, const float* x, const float* wpk_fwd, const float* bias, void* y,
+                                             void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRX_REQUIRE(x && wpk_fwd && y, "conv2d_fwd_first3_to_bf16: null pointer");
+  if (!srx_first3_fwd_applicable(d) || d->precision != 1 || d->act == SRX_ACT_PRELU)
+    SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_fwd_first3_to_bf16: 3x3 / stride 1 / pad 1 layers from <= 4 to 64 channels with precision = 1 only");
+  return srx_first3_fwd(d, x, wpk_fwd, fwd_geo(d).Kp, bias, static_cast<float*>(y), srx_stream(stream), 1);
+}
+
+// y = [relu](conv(x) + bias): x bf16 [N][H][W][Cin]; y bf16 or fp32 [N][H][W][Cout]
+extern "C" int srx_conv3x3_bf16s_fwd(const srx_conv2d_t* d, const void* x, const void* wpk_fwd, const float* bias, int relu,
+                                     void* y, int y_is_bf16, float* ws, size_t ws_floats, void* stream) {
+  return bf16s_run(d, 0, x, wpk_fwd, bias, relu, nullptr, y, y_is_bf16, ws, ws_floats, stream);
+}
+
+// dx = conv^T(dy) [* (relu_out > 0)]: dy bf16 [N][H][W][Cout]; relu_out: the bf16 OUTPUT of the ReLU that produced this layer's
+// input (null: none) -- that activation's backward on the way out; dx bf16 or fp32 [N][H][W][Cin]
+extern "C" int srx_conv3x3_bf16s_bwd_data(const srx_conv2d_t* d, const void* dy, const void* wpk_bwd, const void* relu_out,
+                                          void* dx, int dx_is_bf16, float* ws, size_t ws_floats, void* stream) {
+  return bf16s_run(d, 1, dy, wpk_bwd, nullptr, 0, relu_out, dx, dx_is_bf16, ws, ws_floats, stream);
 }

@@ -60,7 +60,7 @@ int srx_thin_wgrad(const srx_conv2d_t* d, const float* x, const float* dy, float
 bool srx_thin_fwd_applicable(const srx_conv2d_t* d);
 // 3x3 / stride 1 / pad 1, <= 4 -> 64 channels, bias + ReLU / LeakyReLU: the first layers of the discriminators and of VGG19
 bool srx_first3_fwd_applicable(const srx_conv2d_t* d);
-int srx_first3_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, int Kp, const float* bias, float* out, hipStream_t st);
+int srx_first3_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, int Kp, const float* bias, float* out, hipStream_t st, int out_bf16 = 0);
 bool srx_thin_dgrad_applicable(const srx_conv2d_t* d);
 int srx_thin_pack(const srx_conv2d_t* d, const float* w, float* p, int mode, hipStream_t st);
 int srx_thin_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, const float* bias, float* out, int n_out,

@@ -391,7 +391,7 @@ struct First3 {
   unsigned in_bytes, out_bytes;
 };
 
-template <int PR>
+template <int PR, bool OUT16 = false>  // OUT16: the output tensor is bf16 (bf16-storage conv stacks, gconv.hip, round 5)
 __global__ __launch_bounds__(256) void first3x3_fwd_kernel(const First3 a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i31 = lane & 31, h2 = lane >> 5;
@@ -441,8 +441,13 @@ __global__ __launch_bounds__(256) void first3x3_fwd_kernel(const First3 a) {
       o0 = o0 > 0.f ? o0 : o0 * a.slope;
       o1 = o1 > 0.f ? o1 : o1 * a.slope;
       const int roff = ((r & 3) + 8 * (r >> 2)) * 256;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o0), rout, (int)obase, roff, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o1), rout, (int)obase, roff + 128, 0);
+      if (OUT16) {
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)o0), rout, (int)(obase >> 1), roff >> 1, 0);
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)o1), rout, (int)(obase >> 1), (roff + 128) >> 1, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o0), rout, (int)obase, roff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o1), rout, (int)obase, roff + 128, 0);
+      }
     }
   }
 }
@@ -570,7 +575,7 @@ bool srx_first3_fwd_applicable(const srx_conv2d_t* d) {
 }
 
 int srx_first3_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, int Kp, const float* bias, float* out,
-                   hipStream_t st) {
+                   hipStream_t st, int out_bf16) {
   First3 a;
   a.in = in; a.w = wpk; a.bias = bias; a.out = out;
   a.H = d->H; a.W = d->W; a.HW = d->H * d->W; a.M = d->N * a.HW; a.Kp = Kp;
@@ -578,13 +583,16 @@ int srx_first3_fwd(const srx_conv2d_t* d, const float* in, const float* wpk, int
   a.inv_HW = 1.0f / (float)a.HW; a.inv_W = 1.0f / (float)a.W;
   a.slope = d->act == SRX_ACT_RELU ? 0.f : (d->act == SRX_ACT_LRELU ? d->slope : 1.f);  // v > 0 ? v : v * slope
   a.in_bytes = (unsigned)((size_t)a.M * 4 * sizeof(float));
-  a.out_bytes = (unsigned)((size_t)a.M * 64 * sizeof(float));
+  a.out_bytes = (unsigned)((size_t)a.M * 64 * (out_bf16 ? 2 : sizeof(float)));
   // three workgroups per CU, each wave walking its share of the tiles: the weight prologue is paid 768 times, not 2304
   const int cus = srx_plan_cus(), gdev = srx_dev().first3_wgs_per_cu;
   const unsigned grid = (unsigned)std::min<int64_t>(srx_cdiv(a.ntiles, 4), (int64_t)cus * (gdev > 0 ? gdev : 3));
   char nm[64];
   if (srx_prof_on()) snprintf(nm, sizeof(nm), "first3x3_fwd_kernel<%d> MxNxK=%dx64x36", d->precision ? 1 : 0, a.M);
-  if (d->precision) SRX_LAUNCH_PROF(nm, 2.0 * a.M * 64 * 27, first3x3_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
+  if (out_bf16) {
+    if (!d->precision) SRX_FAIL(SRX_E_UNSUPPORTED, "first3_fwd: a bf16 output needs precision = 1");
+    SRX_LAUNCH_PROF(nm, 2.0 * a.M * 64 * 27, (first3x3_fwd_kernel<1, true>), dim3(grid), dim3(256), 0, st, a);
+  } else if (d->precision) SRX_LAUNCH_PROF(nm, 2.0 * a.M * 64 * 27, first3x3_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
   else SRX_LAUNCH_PROF(nm, 2.0 * a.M * 64 * 27, first3x3_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, a);
   SRX_CHECK_LAUNCH("first3x3_fwd_kernel");
   return SRX_OK;

@@ -369,6 +369,23 @@ class ConvState:
         self._wino_key = key
         self._wino_desc = d
 
+    def pack_bf16s(self, weight: Tensor, d: Conv2dDesc, need_bwd: bool) -> None:
+        """bf16 weight copies of a layer inside a bf16-storage stack (``srx_conv3x3_bf16s_pack``), same key as ``pack``."""
+        key = self.pack_key(weight)
+        have = self.__dict__.get('bf16s_fwd')
+        if key == self.__dict__.get('_bf16s_key') and have is not None and (self.__dict__.get('bf16s_bwd') is not None or not need_bwd):
+            return
+        dref = C.byref(d)
+        n = _lib.lib().srx_conv3x3_bf16s_packed_bytes(dref) // 2
+        if have is None or have.device != weight.device:
+            self.bf16s_fwd = torch.empty(n, dtype=torch.bfloat16, device=weight.device)
+            self.bf16s_bwd = None
+        if need_bwd and self.__dict__.get('bf16s_bwd') is None:
+            self.bf16s_bwd = torch.empty(n, dtype=torch.bfloat16, device=weight.device)
+        w = _chk(weight.detach(), 'conv2d.weight')
+        call('srx_conv3x3_bf16s_pack', dref, _p(w), _p(self.bf16s_fwd), _p(self.bf16s_bwd), _stream())
+        self._bf16s_key = key
+
 
 def wino_layer_ok(st: ConvState, d: Conv2dDesc) -> bool:
     """Does this layer's forward (and data gradient) run on Winograd F(2x2, 3x3) (csrc/wino.hip) at this size?  Wide 3x3 /
@@ -1182,6 +1199,9 @@ class _FrozenConvStack(Function):
         n_src = source.shape[0]
         x = source if target is None else torch.cat([source, _chk(target, 'conv_stack.target')], dim=0)
         L, s = _lib.lib(), _stream()
+        ctx.bf16s = _bf16_stack_ok(layers, x.shape)
+        if ctx.bf16s:
+            return _FrozenConvStack._forward_bf16s(ctx, x, n_src, target is None, layers)
         saved, plan = [x], []
         for kind, conv in layers:
             n, h, w, c = x.shape
@@ -1223,10 +1243,92 @@ class _FrozenConvStack(Function):
         return fs, ft
 
     @staticmethod
+    def _forward_bf16s(ctx, x: Tensor, n_src: int, single: bool, layers):
+        """Under autocast (``precision = 1`` on every layer; esrgan/trainer.py:461-467) the activations BETWEEN the convs are
+        stored as bf16 (csrc/gconv.hip "bf16 STORAGE"): the same bf16 products as before -- an operand is rounded once, by
+        its producer -- at half the bytes and without the loaders' fp32 -> bf16 conversion.  A conv in front of a pool and
+        the last conv write fp32: the pool compares fp32 values (as the recipe does), the features go to the fp32 MSE."""
+        L, s = _lib.lib(), _stream()
+        saved, plan = [x], []
+        need_bwd = ctx.needs_input_grad[0]
+        for i, (kind, conv) in enumerate(layers):
+            n, h, w, c = x.shape
+            to_f32 = i + 1 == len(layers) or layers[i + 1][0] == 'pool'
+            if kind == 'pool':
+                y = torch.empty((n, h // 2, w // 2, c), dtype=torch.bfloat16, device=x.device)
+                call('srx_maxpool2x2_fwd_to_bf16', _p(x), _p(y), n, h, w, c, s)
+                plan.append(('pool', None))
+            else:
+                st = conv._st
+                d = st.desc(n, h, w)
+                dref = C.byref(d)
+                y = torch.empty(st.out_shape(n, h, w), dtype=torch.float32 if to_f32 else torch.bfloat16, device=x.device)
+                b = None if conv.bias is None else _chk(conv.bias.detach(), 'conv_stack.bias')
+                if i == 0:   # the 3 -> 64 first layer: fp32 image in, its own kernel
+                    st.pack(conv.weight, d)
+                    call('srx_conv2d_fwd_first3_to_bf16', dref, _p(x), _p(st.wpk_fwd), _p(b), _p(y), s)
+                else:
+                    st.pack_bf16s(conv.weight, d, need_bwd)
+                    nws = L.srx_conv3x3_bf16s_ws_floats(dref, 0)
+                    ws = _ws(nws, x) if nws else None
+                    call('srx_conv3x3_bf16s_fwd', dref, _p(x), _p(st.bf16s_fwd), _p(b), 1, _p(y), 0 if to_f32 else 1, _p(ws), nws, s)
+                plan.append(('conv', st))
+            saved.append(y)
+            x = y
+        ctx.plan, ctx.n_src = plan, n_src
+        ctx.save_for_backward(*saved)
+        if single:
+            return x, None
+        fs, ft = x[:n_src], x[n_src:]
+        ctx.mark_non_differentiable(ft)
+        return fs, ft
+
+    @staticmethod
+    def _backward_bf16s(ctx, dfs: Tensor):
+        saved, plan, n = ctx.saved_tensors, ctx.plan, ctx.n_src
+        L, s = _lib.lib(), _stream()
+        g32 = _chk(dfs, 'conv_stack.grad')
+        top = saved[-1][:n]
+        g = torch.empty(g32.shape, dtype=torch.bfloat16, device=g32.device)
+        call('srx_act_bwd_from_out_to_bf16', _p(g32), _p(top), _p(g), g32.numel(), ACT_RELU, 0.0, s)
+        for i in range(len(plan) - 1, 0, -1):
+            kind, st = plan[i]
+            x = saved[i][:n]                      # this layer's input (source half)
+            if kind == 'pool':                    # x: the fp32 output of the conv + ReLU below
+                _, h, w, c = x.shape
+                dx = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+                call('srx_maxpool2x2_relu_bwd_bf16', _p(g), _p(x), _p(dx), n, h, w, c, s)
+                g = dx
+                continue
+            _, h, w, _c = x.shape
+            d = st.desc(n, h, w)
+            dref = C.byref(d)
+            fold = plan[i - 1][0] == 'conv'       # x = relu(conv below): that ReLU's backward on the way out
+            to_f32 = i == 1                       # the first layer's data gradient (3-channel kernel) reads fp32
+            dx = torch.empty(x.shape, dtype=torch.float32 if to_f32 else torch.bfloat16, device=x.device)
+            nws = L.srx_conv3x3_bf16s_ws_floats(dref, 1)
+            ws = _ws(nws, dx) if nws else None
+            call('srx_conv3x3_bf16s_bwd_data', dref, _p(g), _p(st.bf16s_bwd), _p(x) if fold else None, _p(dx), 0 if to_f32 else 1,
+                 _p(ws), nws, s)
+            g = dx
+        st = plan[0][1]
+        x = saved[0][:n]
+        _, h, w, _c = x.shape
+        d = st.desc(n, h, w)
+        dref = C.byref(d)
+        dx = torch.empty_like(x)
+        nws = L.srx_conv2d_bwd_data_ws_floats(dref)
+        ws = _ws(nws, x) if nws else None
+        call('srx_conv2d_bwd_data', dref, _p(g), _p(st.wpk_bwd), _p(dx), 0, _p(ws), nws, s)
+        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+    @staticmethod
     def backward(ctx, dfs: Tensor, _dft=None):
         saved, plan, n = ctx.saved_tensors, ctx.plan, ctx.n_src
         if dfs is None or not ctx.needs_input_grad[0]:
             return (None,) * len(ctx.needs_input_grad)
+        if ctx.bf16s:
+            return _FrozenConvStack._backward_bf16s(ctx, dfs)
         L, s = _lib.lib(), _stream()
         g = _chk(dfs, 'conv_stack.grad')
         # the topmost activation's backward is the only elementwise pass
@@ -1276,6 +1378,31 @@ class _FrozenConvStack(Function):
                 call('srx_conv2d_bwd_data', dref, _p(g), _p(wpk_bwd), _p(dx), 0, _p(ws), nws, s)
             g = dx
         return (g, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+def _bf16_stack_ok(layers, shape) -> bool:
+    """May this frozen stack keep its inner activations as bf16 (``_FrozenConvStack._forward_bf16s``)?  Every conv multiplies
+    bf16 products (autocast), starts with the 3 -> 64 layer, every other conv is a 3x3 / stride 1 / pad 1 + ReLU layer with
+    channel counts that are multiples of 64, pools sit between convs and the stack ends with a conv."""
+    if _dev.NO_BF16S or len(layers) < 2 or layers[0][0] != 'conv' or layers[-1][0] != 'conv' or layers[1][0] != 'conv':
+        return False
+    L = _lib.lib()
+    n, h, w, _c = shape
+    for i, (kind, conv) in enumerate(layers):
+        if kind == 'pool':
+            if layers[i - 1][0] != 'conv' or layers[i + 1][0] != 'conv' or h % 2 or w % 2:
+                return False
+            h, w = h // 2, w // 2
+            continue
+        st = conv._st
+        if st.precision != 1 or st.act != ACT_RELU or st.stride != 1 or st.shuffle or st.k != 3 or st.pad != 1:
+            return False
+        if i == 0:
+            if st.cin > 4 or st.cout != 64:
+                return False
+        elif L.srx_conv3x3_bf16s_applicable(C.byref(st.desc(n, h, w))) != 1:
+            return False
+    return True
 
 
 def frozen_conv_stack(source: Tensor, target: Optional[Tensor], layers):
