@@ -453,8 +453,9 @@ int srx_bn_act_bwd(const float* dout, const float* y, const float* mean, const f
  *   bwd_data: dx = conv^T(dy), multiplied by the ReLU mask (relu_out > 0, laid out like dx; NULL: none) of the layer below -- the
  *             fold srx_conv2d_bwd_data_act does for the direct kernel
  * ws: srx_wino_ws_floats(d, which) floats (which: 0 forward, 1 data gradient; non-zero when the planner splits the input
- * channels over several workgroups).  x != y.  srx_wino_plan: out[6] = {BN, channel splits, workgroups, tile blocks, chunks per
- * workgroup, 0} (host only). */
+ * channels over several workgroups, or cuts the tiles of the last, partly filled round of the chip along them).  x != y.
+ * srx_wino_plan: out[6] = {BN, channel splits of every tile, workgroups, tile blocks, chunks per workgroup, parts per tile of the
+ * last round (1: none)} (host only). */
 int srx_wino_applicable(const srx_conv2d_t* d);
 size_t srx_wino_packed_floats(const srx_conv2d_t* d);
 size_t srx_wino_ws_floats(const srx_conv2d_t* d, int which);
@@ -470,6 +471,13 @@ int srx_wino_bwd_data(const srx_conv2d_t* d, const float* dy, const float* upk_t
 int srx_wino_stat_rows(const srx_conv2d_t* d);
 int srx_wino_fwd_stats(const srx_conv2d_t* d, const float* x, const float* upk, const float* bias, float* y, float* stats,
                        void* stream);
+/* inference (functional.FoldedConv: conv with the eval-mode BatchNorm folded into weights and bias, srgan/residual.py:86-91):
+ * y = act(conv(x) + bias) [+ residual], act = none / ReLU / LeakyReLU(d->slope) (a single-parameter PReLU is that); residual laid
+ * out like y, a tensor of its own, may be NULL.  srx_wino_infer_applicable: as srx_wino_applicable, also for the 64 -> 64
+ * layers the training path leaves to its row-tile kernel */
+int srx_wino_infer_applicable(const srx_conv2d_t* d);
+int srx_wino_fwd_act(const srx_conv2d_t* d, const float* x, const float* upk, const float* bias, const float* residual, float* y,
+                     float* ws, size_t ws_floats, void* stream);
 
 /* ------------------------------------------------- bf16 storage of activations on the training path (round 5) */
 /* Under autocast (esrgan/trainer.py:446,461) the reference's convs read and write half tensors.  These entry points keep the

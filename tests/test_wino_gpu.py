@@ -23,7 +23,8 @@ CASES = [
     (1, 6, 6, 512, 512),     # conv5_x: 9 tiles, the planner splits the input channels
     (1, 10, 6, 128, 96),     # 15 tiles (a partial block), 96 output channels -> 32-column workgroups
     (3, 8, 20, 32, 160),     # one chunk of input channels
-    (16, 24, 24, 256, 256),  # the training batch's data-gradient size
+    (16, 24, 24, 256, 256),  # the training batch's data-gradient size: 2.25 rounds of tiles -> the last round's tiles are cut in parts
+    (16, 12, 12, 512, 512),  # the same with 32-column workgroups, 16 chunks per tile
 ]
 
 
@@ -75,7 +76,10 @@ def test_winograd_forward_and_data_gradient(dev, cfg):
     assert rel(dx.permute(0, 3, 1, 2), dx_masked) < 2e-5
     plan = (C.c_int * 6)()
     _lib.call('srx_wino_plan', dref, 0, plan)
-    assert plan[0] in (32, 64) and plan[1] >= 1 and (nws > 0) == (plan[1] > 1)
+    # (a workspace exactly when every tile's channels are split, or when the tiles of the last round of the chip are cut in parts)
+    assert plan[0] in (32, 64) and plan[1] >= 1 and plan[5] >= 1 and (nws > 0) == (plan[1] > 1 or plan[5] > 1)
+    if cfg == (16, 24, 24, 256, 256):
+        assert plan[1] == 1 and plan[5] > 1   # 576 tiles on 256 CUs: two rounds of whole tiles + a short third one
 
 
 def test_winograd_refuses_what_it_does_not_implement(dev):
@@ -148,3 +152,61 @@ def test_winograd_forward_with_batchnorm_partials(dev, cfg):
     blocks = tiles.reshape(rows, 32, cout, 4)
     s1, s2 = blocks.sum(dim=(1, 3)), blocks.square().sum(dim=(1, 3))
     assert rel(part[..., 0], s1) < 2e-5 and rel(part[..., 1], s2) < 2e-5
+
+
+@pytest.mark.parametrize('cfg', [(1, 24, 40, 64, 64), (2, 12, 12, 64, 128)], ids=lambda c: 'x'.join(map(str, c)))
+def test_winograd_inference_forms(dev, cfg):
+    """``srx_wino_fwd_act``: LeakyReLU (the folded single-parameter PReLU of a residual block) and the skip addend in the Winograd
+    epilogue (functional.FoldedConv at inference, srgan/residual.py:86-91) against fp64."""
+    from torchsr_amd import _lib
+    n, h, w, cin, cout = cfg
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(n, cout, h, w, generator=g)
+    pre = TF.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    s = torch.cuda.current_stream().cuda_stream
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    rg = res.permute(0, 2, 3, 1).contiguous().to(dev)
+    bg = bias.to(dev)
+    for act, slope, with_res in ((_lib.ACT_LRELU, 0.25, False), (_lib.ACT_NONE, 0.0, True), (_lib.ACT_LRELU, 0.1, True), (_lib.ACT_RELU, 0.0, True)):
+        d = _lib.Conv2dDesc(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, act, slope, 0, 0)
+        dref = C.byref(d)
+        uf = torch.empty(L.srx_wino_packed_floats(dref), device=dev)
+        _lib.call('srx_wino_pack', dref, wt.to(dev).data_ptr(), uf.data_ptr(), 0, s)
+        nws = L.srx_wino_ws_floats(dref, 0)
+        ws = torch.empty(max(nws, 4), device=dev)
+        y = torch.empty(n, h, w, cout, device=dev)
+        _lib.call('srx_wino_fwd_act', dref, xg.data_ptr(), uf.data_ptr(), bg.data_ptr(), rg.data_ptr() if with_res else None, y.data_ptr(),
+                  ws.data_ptr(), nws, s)
+        want = pre if act == _lib.ACT_NONE else (pre.clamp_min(0) if act == _lib.ACT_RELU else torch.where(pre > 0, pre, pre * slope))
+        if with_res:
+            want = want + res.double()
+        assert rel(y.permute(0, 3, 1, 2), want) < 2e-5, (act, slope, with_res)
+
+
+def test_winograd_forward_with_pixel_shuffle(dev):
+    """The sub-pixel conv of the generator at inference (srgan/residual.py:27-29: Conv2d(64, 256, 3, 1, 1), PixelShuffle(2), PReLU
+    -- the folded PReLU commutes with the shuffle): Winograd with the shuffle in its store against fp64."""
+    from torchsr_amd import _lib
+    n, h, w, cin, cout = 2, 12, 20, 64, 256
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    pre = TF.pixel_shuffle(TF.conv2d(x.double(), wt.double(), bias.double(), padding=1), 2)
+    want = torch.where(pre > 0, pre, pre * 0.25)
+    d = _lib.Conv2dDesc(n, h, w, cin, cin, cout, cout // 4, 3, 3, 1, 1, 2, _lib.ACT_LRELU, 0.25, 0, 0)
+    dref = C.byref(d)
+    assert L.srx_wino_applicable(dref) == 0          # (the training path keeps the direct kernel for these layers)
+    s = torch.cuda.current_stream().cuda_stream
+    uf = torch.empty(L.srx_wino_packed_floats(dref), device=dev)
+    assert uf.numel() == 16 * cin * cout
+    _lib.call('srx_wino_pack', dref, wt.to(dev).data_ptr(), uf.data_ptr(), 0, s)
+    y = torch.empty(n, 2 * h, 2 * w, cout // 4, device=dev)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    _lib.call('srx_wino_fwd_act', dref, xg.data_ptr(), uf.data_ptr(), bias.to(dev).data_ptr(), None, y.data_ptr(), None, 0, s)
+    assert rel(y.permute(0, 3, 1, 2), want) < 2e-5

@@ -34,7 +34,9 @@ SHAPES = {'rt36': (16, 24, 24, 64, 64), 'vgg256': (32, 24, 24, 256, 256), 'vgg25
           's2304x512x2304': (16, 12, 12, 256, 512)}
 if name in SHAPES:
     n, h, w, cin, cout = SHAPES[name][:5]
-    conv = Conv2d(cin, cout, 3, 1, 1, bias=False, shuffle=SHAPES[name][5] if len(SHAPES[name]) > 5 else 0).to(dev)
+    shuffle = SHAPES[name][5] if len(SHAPES[name]) > 5 else 0
+    # (round 5: bias + ReLU as the VGG19 layers have them -- the wide stride-1 layers then take the step's Winograd path)
+    conv = Conv2d(cin, cout, 3, 1, 1, bias=not shuffle, act=0 if shuffle else 1, shuffle=shuffle).to(dev)
     x = torch.rand(n, h, w, cin, device=dev)
     with torch.no_grad():
         for _ in range(reps):

@@ -255,6 +255,8 @@ _SIGS = {
     'srx_maxpool2x2_fwd_to_bf16': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'srx_maxpool2x2_relu_bwd_bf16': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'srx_act_bwd_from_out_to_bf16': (_I, [_P, _P, _P, C.c_int64, _I, C.c_float, _P]),
+    'srx_wino_infer_applicable': (_I, [_D]),
+    'srx_wino_fwd_act': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_wino_stat_rows': (_I, [_D]),
     'srx_wino_fwd_stats': (_I, [_D, _P, _P, _P, _P, _P, _P]),
     'srx_gan_head_fwd': (_I, [C.POINTER(GanHead), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -262,7 +264,7 @@ _SIGS = {
     'srx_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
 }
 # functions whose int return value is data, not a status
-_UNCHECKED = {'srx_wino_applicable', 'srx_conv3x3_bf16s_applicable', 'srx_wino_stat_rows', 'srx_conv2d_bwd_data_bn_rows', 'srx_conv2d_fwd_bn_in_ok', 'srx_conv2d_bwd_data_bn_in_ok', 'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_plan_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows', 'srx_bn_rows_per_block'}
+_UNCHECKED = {'srx_wino_applicable', 'srx_wino_infer_applicable', 'srx_conv3x3_bf16s_applicable', 'srx_wino_stat_rows', 'srx_conv2d_bwd_data_bn_rows', 'srx_conv2d_fwd_bn_in_ok', 'srx_conv2d_bwd_data_bn_in_ok', 'srx_pack_table_bytes', 'srx_version', 'srx_last_error', 'srx_device_cus', 'srx_plan_cus', 'srx_prof_stop', 'srx_conv2d_stat_rows', 'srx_bn_stat_rows', 'srx_bn_rows_per_block'}
 
 EXPORTS = tuple(_SIGS.keys())
 

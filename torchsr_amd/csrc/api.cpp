@@ -52,6 +52,8 @@ static SrxDevSwitches read_switches() {
   s.c64_ablate = num("SRX_C64_ABLATE");
   s.rdb_ablate = num("SRX_RDB_ABLATE");
   s.no_wino = flag("SRX_NO_WINO");
+  s.old_wgrad_reduce = flag("SRX_OLD_WGRAD_REDUCE");
+  s.wino_no_tail = flag("SRX_WINO_NO_TAIL");
   s.wino_zsplit = num("SRX_WINO_ZSPLIT");
   s.wino_bn = num("SRX_WINO_BN");
   if (const char* f = getenv("SRX_FORCE_PLAN")) {

@@ -31,7 +31,7 @@ void srx_set_error(const char* fmt, ...);
 
 // api.cpp: developer switches, read from the environment once at load time (never on a launch path)
 struct SrxDevSwitches {
-  bool no_rt36, no_wgrad_rows, no_bn_bwd_fuse, no_bn_fwd_fuse, no_first3, no_c64, force_plan, no_wgrad_dma, no_wino;
+  bool no_rt36, no_wgrad_rows, no_bn_bwd_fuse, no_bn_fwd_fuse, no_first3, no_c64, force_plan, no_wgrad_dma, no_wino, old_wgrad_reduce, wino_no_tail;
   int wgrad_nsplit, wgrad_rows_nsplit, first3_wgs_per_cu, thin_fwd_rows, reserved_cus, c64_ablate, rdb_ablate, wino_zsplit, wino_bn;
   int plan[4];  // SRX_FORCE_PLAN = "BM,BN,split,ks"
 };
@@ -125,14 +125,18 @@ __device__ __forceinline__ float srx_wave_sum(float v) {
 // of trainable layers after an optimiser step.  transpose = 1: the layer's data gradient (channels swapped, taps flipped).
 __device__ __forceinline__ void srx_wino_pack_one(const float* __restrict__ w, float* __restrict__ upk, int Cout, int Cin,
                                                   int transpose, int64_t idx) {
-  const int R = transpose ? Cin : Cout, K = transpose ? Cout : Cin;  // rows (the GEMM's channels out) and contraction length
+  // transpose: 0 the layer; 1 its data gradient; 2 the layer with a PixelShuffle(2) store: GEMM row r = (sub-pixel ij, channel cc)
+  // is the conv's output channel cc * 4 + ij (the order gconv.hip's packs use), so a lane's four consecutive rows are four
+  // consecutive channels of ONE output pixel
+  const int R = transpose == 1 ? Cin : Cout, K = transpose == 1 ? Cout : Cin;  // rows (the GEMM's channels out) and contraction length
   const int r = (int)(idx / K), k = (int)(idx - (int64_t)r * K);
+  const int rsrc = transpose == 2 ? (r % (Cout / 4)) * 4 + r / (Cout / 4) : r;
   float g[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      g[i][j] = transpose ? w[(((size_t)k * Cin + r) * 3 + (2 - i)) * 3 + (2 - j)] : w[(((size_t)r * Cin + k) * 3 + i) * 3 + j];
+      g[i][j] = transpose == 1 ? w[(((size_t)k * Cin + r) * 3 + (2 - i)) * 3 + (2 - j)] : w[(((size_t)rsrc * Cin + k) * 3 + i) * 3 + j];
   float t[4][3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {

@@ -43,6 +43,15 @@ struct WinoArgs {
   int N, H, W, Cin, Cout;
   int TH, TW, T, tblocks, ncb, nch, zsplit;
   int relu;
+  // inference forms (FoldedConv, round 5): `lrelu` != 0: LeakyReLU / single-parameter PReLU with slope `slope` instead of ReLU;
+  // `add`: a tensor laid out like `out`, added after the activation (the skip of a residual block, srgan/residual.py:86-91)
+  int lrelu; float slope; const float* add;
+  int shuffle;  // != 0: nn.PixelShuffle(2) in the store (forward only): the value is the channel count per sub-pixel, Cout / 4
+  // Tail split (round 5): work items [0, full) are whole (tile block, channel block) tiles; the tiles of the last, partly filled
+  // round of the chip -- item full + t is part t % tsplit of tile full + t / tsplit -- take 1 / tsplit of the input channels each and
+  // write raw partial outputs to tpart[t][32 tiles][4 pixels][BN]; wino_tail_fixup_kernel finishes those tiles only.
+  // (Without a tail: full = every item.)  2.25 rounds of whole tiles cost 3 rounds; 2 rounds + a quarter-length third cost ~2.4.
+  int full, tsplit; float* tpart;
   unsigned in_bytes, upk_bytes;
   size_t out_elems;  // N * H * W * Cout (stride between the partial outputs of two splits)
 };
@@ -57,16 +66,22 @@ __global__ __launch_bounds__(512) void wino_kernel(const WinoArgs a) {
   // remap gives every XCD a contiguous run of items (as gconv.hip's weight-gradient kernels do) -- the tile blocks of a run share
   // their U block and their halo rows in ONE L2 (a speed matter only: with the plain order every XCD pulled all of U through the
   // fabric, 142 MB of HBM reads for a 512 -> 512 layer whose operands are 22 MB; PMC, round 5)
-  int b;
-  {
-    const int W = (int)gridDim.x, b0 = (int)blockIdx.x, xcd = b0 & 7, slot = b0 >> 3, qq = W >> 3, rr = W & 7;
+  int b = (int)blockIdx.x;
+  const bool tailw = b >= a.full;  // (workgroup-uniform) a part of a tail tile
+  int tb, cb, z, zs;
+  if (!tailw) {
+    const int W = a.full, xcd = b & 7, slot = b >> 3, qq = W >> 3, rr = W & 7;
     b = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+    tb = b % a.tblocks; b /= a.tblocks;
+    cb = b % a.ncb;
+    z = b / a.ncb; zs = a.zsplit;
+  } else {
+    const int t = b - a.full, tile = a.full + t / a.tsplit;
+    z = t % a.tsplit; zs = a.tsplit;
+    tb = tile % a.tblocks; cb = tile / a.tblocks;
   }
-  const int tb = b % a.tblocks; b /= a.tblocks;
-  const int cb = b % a.ncb;
-  const int z = b / a.ncb;
   // this split's chunks of input channels: [kc0, kc1)
-  const int kc0 = srx_uniform((int)((long long)z * a.nch / a.zsplit)), kc1 = srx_uniform((int)((long long)(z + 1) * a.nch / a.zsplit));
+  const int kc0 = srx_uniform((int)((long long)z * a.nch / zs)), kc1 = srx_uniform((int)((long long)(z + 1) * a.nch / zs));
   const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes);
   const __amdgpu_buffer_rsrc_t ru = srx_rsrc(a.upk, a.upk_bytes);
 
@@ -228,20 +243,45 @@ __global__ __launch_bounds__(512) void wino_kernel(const WinoArgs a) {
   const int tw = t % a.TW, r = t / a.TW, th = r % a.TH, n = r / a.TH;
   const int co = cb * BN + 4 * cq;
   const size_t p00 = (((size_t)n * a.H + 2 * th) * a.W + 2 * tw) * a.Cout + co;
-  const size_t offs[4] = {p00, p00 + a.Cout, p00 + (size_t)a.W * a.Cout, p00 + (size_t)a.W * a.Cout + a.Cout};
+  size_t offs[4] = {p00, p00 + a.Cout, p00 + (size_t)a.W * a.Cout, p00 + (size_t)a.W * a.Cout + a.Cout};
+  if (a.shuffle) {  // GEMM column co = (sub-pixel ij, channel cc): pixel (y, x) of the conv lands at (2y + ij / 2, 2x + ij % 2), channel cc
+    const int ij = co / a.shuffle, cc = co - ij * a.shuffle;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const size_t oy = 2 * (size_t)(2 * th + (p >> 1)) + (ij >> 1), ox = 2 * (size_t)(2 * tw + (p & 1)) + (ij & 1);
+      offs[p] = (((size_t)n * 2 * a.H + oy) * (2 * (size_t)a.W) + ox) * a.shuffle + cc;
+    }
+  }
+  if (tailw) {  // a part of a tail tile: raw partial output, tile-local layout; finished by wino_tail_fixup_kernel
+    float* o = a.tpart + (size_t)((int)blockIdx.x - a.full) * (WT * 4 * BN) + (size_t)(et * 4) * BN + 4 * cq;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(o + p * BN) = y[p];
+    return;
+  }
   if (a.part) {  // one of several splits of the input channels: the raw partial output; bias / activation in the fix-up pass
     float* o = a.part + (size_t)z * a.out_elems;
 #pragma unroll
     for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(o + offs[p]) = y[p];
     return;
   }
-  f32x4 mk[4];
+  f32x4 mk[4], ad[4];
   if (a.mask && tvalid) {  // (all loads before the first store)
 #pragma unroll
     for (int p = 0; p < 4; ++p) mk[p] = *reinterpret_cast<const f32x4*>(a.mask + offs[p]);
   }
+  if (a.add && tvalid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ad[p] = *reinterpret_cast<const f32x4*>(a.add + offs[p]);
+  }
   if (a.bias) {
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+    f32x4 bv;
+    if (a.shuffle) {  // (the bias is in the conv's own channel order)
+      const int ij = co / a.shuffle, cc = co - ij * a.shuffle;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = a.bias[(cc + e) * 4 + ij];
+    } else {
+      bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) y[p] += bv;
   }
@@ -277,7 +317,9 @@ __global__ __launch_bounds__(512) void wino_kernel(const WinoArgs a) {
     for (int e = 0; e < 4; ++e) {
       float v = y[p][e];
       if (a.relu) v = fmaxf(v, 0.f);
+      if (a.lrelu) v = v > 0.f ? v : v * a.slope;
       if (a.mask) v = mk[p][e] > 0.f ? v : 0.f;
+      if (a.add) v += ad[p][e];
       y[p][e] = v;
     }
     *reinterpret_cast<f32x4*>(a.out + offs[p]) = y[p];
@@ -312,6 +354,61 @@ __global__ __launch_bounds__(256) void wino_fixup_kernel(const float* __restrict
   }
 }
 
+// finishes the tail tiles of a launch (WinoArgs::full / tsplit): one workgroup per tile, one thread per (2x2 tile, channel quad) as in
+// wino_kernel's epilogue; the parts are added in order, then bias, ReLU / mask, stores
+template <int BN>
+__global__ __launch_bounds__(512) void wino_tail_fixup_kernel(const WinoArgs a) {
+  constexpr int CQ = BN / 4, ITEMS = WT * CQ;
+  const int tid = threadIdx.x;
+  if (tid >= ITEMS) return;
+  const int tile = a.full + (int)blockIdx.x;
+  const int tb = tile % a.tblocks, cb = tile / a.tblocks;
+  const int et = tid / CQ, cq = tid % CQ;
+  const int t = tb * WT + et;
+  if (t >= a.T) return;
+  const float* src = a.tpart + (size_t)blockIdx.x * a.tsplit * (WT * 4 * BN) + (size_t)(et * 4) * BN + 4 * cq;
+  f32x4 y[4];
+  f32x4 v[4][4];
+  for (int z0 = 0; z0 < a.tsplit; z0 += 4) {  // four parts per trip: loads first, added in order
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        v[u][p] = *reinterpret_cast<const f32x4*>(src + (size_t)min(z0 + u, a.tsplit - 1) * (WT * 4 * BN) + p * BN);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (z0 + u < a.tsplit) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) y[p] = (z0 + u == 0) ? v[u][p] : y[p] + v[u][p];
+      }
+  }
+  const int tw = t % a.TW, r = t / a.TW, th = r % a.TH, n = r / a.TH;
+  const int co = cb * BN + 4 * cq;
+  const size_t p00 = (((size_t)n * a.H + 2 * th) * a.W + 2 * tw) * a.Cout + co;
+  const size_t offs[4] = {p00, p00 + a.Cout, p00 + (size_t)a.W * a.Cout, p00 + (size_t)a.W * a.Cout + a.Cout};
+  f32x4 mk[4];
+  if (a.mask) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) mk[p] = *reinterpret_cast<const f32x4*>(a.mask + offs[p]);
+  }
+  if (a.bias) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) y[p] += bv;
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float w = y[p][e];
+      if (a.relu) w = fmaxf(w, 0.f);
+      if (a.mask) w = mk[p][e] > 0.f ? w : 0.f;
+      y[p][e] = w;
+    }
+    *reinterpret_cast<f32x4*>(a.out + offs[p]) = y[p];
+  }
+}
+
 // U = G g G^T of every (output channel, input channel) pair, laid out as wino_kernel's waves load it.
 // transpose = 0: the layer itself (g = w[co][ci]); 1: its data gradient (output channels = the layer's inputs, g =
 // w[ci][co] with both taps flipped).  One thread per (row channel, contraction channel) pair.
@@ -321,7 +418,7 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
   srx_wino_pack_one(w, upk, Cout, Cin, transpose, idx);
 }
 
-struct WinoPlan { int bn, zsplit; float cost; };
+struct WinoPlan { int bn, zsplit; float cost; int tsplit; };  // tsplit > 1: the tiles of the last round are cut that many ways (zsplit = 1)
 
 // rounds of the chip x (chunks per workgroup x time per chunk + fixed cost), plus the fix-up pass of a split
 WinoPlan wino_plan(int T, int Cin, int Cout, bool no_split = false) {
@@ -339,18 +436,31 @@ WinoPlan wino_plan(int T, int Cin, int Cout, bool no_split = false) {
       const float fixed = bn == 64 ? 4.5f : 3.5f;    // prologue (first patch + U round trip) and the epilogue through LDS
       float cost = rounds * (chunks * t_chunk + fixed);
       if (zs > 1) cost += 3.0f + (float)(zs + 1) * T * 4.0f * Cout * 4.0f / 4.0e6f;  // fix-up: (zs + 1) passes over the output at ~4 TB/s
-      if (cost < best.cost) best = WinoPlan{bn, zs, cost};
+      if (cost < best.cost) best = WinoPlan{bn, zs, cost, 1};
+      // whole tiles for the full rounds, the tiles of the last round cut along the input channels so that it is a short one
+      const int tail = (int)(wgs % P);
+      if (zs == 1 && !no_split && !srx_dev().wino_no_tail && wgs > P && tail > 0) {
+        for (int ts = 2; ts <= nch && ts <= 8; ++ts) {
+          if ((int64_t)tail * ts > P) break;
+          const float c = (float)(wgs / P) * (nch * t_chunk + fixed) + (float)srx_cdiv(nch, ts) * t_chunk + fixed + 4.0f;  // (+ the fix-up launch)
+          if (c < best.cost) best = WinoPlan{bn, 1, c, ts};
+        }
+      }
     }
   }
-  if (const int v = srx_dev().wino_zsplit; v > 0 && v <= nch && !no_split) best.zsplit = v;
+  if (const int v = srx_dev().wino_zsplit; v > 0 && v <= nch && !no_split) { best.zsplit = v; best.tsplit = 1; }
   if (const int v = srx_dev().wino_bn; (v == 32 || v == 64) && Cout % v == 0) best.bn = v;
   return best;
 }
 
-bool wino_shape_ok(const srx_conv2d_t* d) {
-  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->shuffle && d->up != 2 && d->precision == 0 &&
-         d->Cin % WKC == 0 && d->Cout % 32 == 0 && d->Cin_s == d->Cin && d->Cout_s == d->Cout && d->H % 2 == 0 && d->W % 2 == 0 &&
-         (int64_t)d->N * d->H * d->W * std::max(d->Cin, d->Cout) < (1LL << 30);
+// shuffle_ok: also layers with nn.PixelShuffle(2) in their store (the forward of the sub-pixel convs, inference)
+bool wino_shape_ok(const srx_conv2d_t* d, bool shuffle_ok = false) {
+  const bool sh = d->shuffle == 2 && shuffle_ok && d->Cout % 128 == 0 && d->Cout_s * 4 == d->Cout;
+  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && (!d->shuffle || sh) && d->up != 2 && d->precision == 0 &&
+         d->Cin % WKC == 0 && d->Cout % 32 == 0 && d->Cin_s == d->Cin && (sh || d->Cout_s == d->Cout) && d->H % 2 == 0 && d->W % 2 == 0 &&
+         // 32-bit byte offsets into the INPUT (the output is addressed with 64 bits); without the shuffle the layer may also run
+         // as its own data gradient, whose input has Cout channels
+         (int64_t)d->N * d->H * d->W * (sh ? d->Cin : std::max(d->Cin, d->Cout)) < (1LL << 30) && (int64_t)d->N * d->H * d->W < (1LL << 31);
 }
 
 }  // namespace
@@ -365,24 +475,29 @@ extern "C" int srx_wino_applicable(const srx_conv2d_t* d) {
 }
 
 extern "C" size_t srx_wino_packed_floats(const srx_conv2d_t* d) {
-  return (d && wino_shape_ok(d)) ? (size_t)16 * d->Cout * d->Cin : 0;
+  return (d && wino_shape_ok(d, true)) ? (size_t)16 * d->Cout * d->Cin : 0;
 }
 
 extern "C" int srx_wino_pack(const srx_conv2d_t* d, const float* w, float* upk, int transpose, void* stream) {
   SRX_REQUIRE(d && w && upk, "wino_pack: null pointer");
-  if (!wino_shape_ok(d)) SRX_FAIL(SRX_E_UNSUPPORTED, "wino_pack: 3x3 / stride 1 / pad 1 fp32 layers with Cin, Cout multiples of 32 and even H, W only");
+  if (!wino_shape_ok(d, !transpose)) SRX_FAIL(SRX_E_UNSUPPORTED, "wino_pack: 3x3 / stride 1 / pad 1 fp32 layers with Cin, Cout multiples of 32 and even H, W only");
   const int64_t n = (int64_t)d->Cout * d->Cin;
   hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)srx_cdiv(n, 256)), dim3(256), 0, srx_stream(stream), w, upk, d->Cout, d->Cin,
-                     transpose ? 1 : 0);
+                     transpose ? 1 : (d->shuffle ? 2 : 0));  // (a PixelShuffle layer's forward: rows in (sub-pixel, channel) order)
   SRX_CHECK_LAUNCH("wino_pack_kernel");
   return SRX_OK;
 }
 
 // workspace (floats) of a forward (which = 0) or data-gradient (which = 1) call: the partial outputs of a channel split
 extern "C" size_t srx_wino_ws_floats(const srx_conv2d_t* d, int which) {
-  if (!d || !wino_shape_ok(d)) return 0;
+  if (!d || !wino_shape_ok(d, which == 0)) return 0;
   const int cin = which ? d->Cout : d->Cin, cout = which ? d->Cin : d->Cout;
-  const WinoPlan p = wino_plan(d->N * (d->H / 2) * (d->W / 2), cin, cout);
+  const int T = d->N * (d->H / 2) * (d->W / 2);
+  const WinoPlan p = wino_plan(T, cin, cout, d->shuffle != 0);
+  if (p.tsplit > 1) {
+    const int64_t wgs = srx_cdiv(T, WT) * (cout / p.bn);
+    return (size_t)(wgs % srx_plan_cus()) * p.tsplit * WT * 4 * p.bn;
+  }
   return p.zsplit > 1 ? (size_t)p.zsplit * d->N * d->H * d->W * cout : 0;
 }
 
@@ -393,15 +508,18 @@ extern "C" int srx_wino_plan(const srx_conv2d_t* d, int which, int* out) {
   const int T = d->N * (d->H / 2) * (d->W / 2);
   const WinoPlan p = wino_plan(T, cin, cout);
   out[0] = p.bn; out[1] = p.zsplit; out[3] = (int)srx_cdiv(T, WT); out[2] = out[3] * (cout / p.bn) * p.zsplit;
-  out[4] = (int)srx_cdiv(cin / WKC, p.zsplit); out[5] = 0;
+  out[4] = (int)srx_cdiv(cin / WKC, p.zsplit); out[5] = p.tsplit;
+  if (p.tsplit > 1) { const int tail = out[2] % srx_plan_cus(); out[2] += tail * (p.tsplit - 1); }
   return SRX_OK;
 }
 
 static int wino_run(const srx_conv2d_t* d, int which, const float* x, const float* upk, const float* bias, const float* mask,
-                    int relu, float* y, float* ws, size_t ws_floats, void* stream, float* stats = nullptr) {
+                    int relu, float* y, float* ws, size_t ws_floats, void* stream, float* stats = nullptr, const float* add = nullptr,
+                    int lrelu = 0, float slope = 0.f) {
   SRX_REQUIRE(d && x && upk && y, "wino: null pointer");
-  if (!wino_shape_ok(d)) SRX_FAIL(SRX_E_UNSUPPORTED, "wino: 3x3 / stride 1 / pad 1 fp32 layers with Cin, Cout multiples of 32 and even H, W only");
+  if (!wino_shape_ok(d, which == 0)) SRX_FAIL(SRX_E_UNSUPPORTED, "wino: 3x3 / stride 1 / pad 1 fp32 layers with Cin, Cout multiples of 32 and even H, W only");
   SRX_REQUIRE(x != y && (!mask || mask != y), "wino: in place is not possible (neighbouring tiles read their halo)");
+  SRX_REQUIRE(!d->shuffle || (!stats && !mask), "wino: PixelShuffle layers: plain forward only");
   WinoArgs a{};
   a.in = x; a.upk = upk; a.bias = bias; a.mask = mask; a.out = y;
   a.N = d->N; a.H = d->H; a.W = d->W;
@@ -414,7 +532,11 @@ static int wino_run(const srx_conv2d_t* d, int which, const float* x, const floa
   a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * a.Cin * sizeof(float));
   a.upk_bytes = (unsigned)((size_t)16 * a.Cin * a.Cout * sizeof(float));
   a.out_elems = (size_t)d->N * d->H * d->W * a.Cout;
-  const WinoPlan p = wino_plan(a.T, a.Cin, a.Cout, stats != nullptr);  // (statistics come from whole outputs: no channel split)
+  SRX_REQUIRE(!add || (add != y && add != x), "wino: the addend must be a tensor of its own");
+  a.add = add; a.lrelu = lrelu; a.slope = slope;
+  // (statistics come from whole outputs, and the fix-up pass knows neither an addend nor a LeakyReLU: no channel split then)
+  a.shuffle = d->shuffle ? d->Cout / 4 : 0;
+  const WinoPlan p = wino_plan(a.T, a.Cin, a.Cout, stats != nullptr || add != nullptr || lrelu != 0 || d->shuffle != 0);
   a.zsplit = p.zsplit;
   a.ncb = a.Cout / p.bn;
   a.stats = stats;
@@ -423,7 +545,17 @@ static int wino_run(const srx_conv2d_t* d, int which, const float* x, const floa
     a.part = ws;
   }
   hipStream_t st = srx_stream(stream);
-  const dim3 grid((unsigned)((int64_t)a.tblocks * a.ncb * a.zsplit));
+  int64_t items = (int64_t)a.tblocks * a.ncb * a.zsplit;
+  a.full = (int)items; a.tsplit = 1;
+  int tail = 0;
+  if (p.tsplit > 1) {
+    tail = (int)(items % srx_plan_cus());
+    const size_t need = (size_t)tail * p.tsplit * WT * 4 * p.bn;
+    if (!ws || ws_floats < need) SRX_FAIL(SRX_E_WORKSPACE, "wino: workspace %zu < %zu floats", ws_floats, need);
+    a.full = (int)items - tail; a.tsplit = p.tsplit; a.tpart = ws;
+    items = a.full + (int64_t)tail * p.tsplit;
+  }
+  const dim3 grid((unsigned)items);
   static std::once_flag once;
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -442,6 +574,11 @@ static int wino_run(const srx_conv2d_t* d, int which, const float* x, const floa
     hipLaunchKernelGGL(wino_fixup_kernel, dim3(blocks), dim3(256), 0, st, ws, p.zsplit, n4, a.out_elems, bias, mask, y, a.Cout / 4, relu);
     SRX_CHECK_LAUNCH("wino_fixup_kernel");
   }
+  if (tail > 0) {
+    if (p.bn == 64) hipLaunchKernelGGL(wino_tail_fixup_kernel<64>, dim3((unsigned)tail), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(wino_tail_fixup_kernel<32>, dim3((unsigned)tail), dim3(256), 0, st, a);
+    SRX_CHECK_LAUNCH("wino_tail_fixup_kernel");
+  }
   return SRX_OK;
 }
 
@@ -449,6 +586,22 @@ extern "C" int srx_wino_fwd(const srx_conv2d_t* d, const float* x, const float* 
                             size_t ws_floats, void* stream) {
   SRX_REQUIRE(d && (d->act == SRX_ACT_NONE || d->act == SRX_ACT_RELU), "wino_fwd: no activation or ReLU");
   return wino_run(d, 0, x, upk, bias, nullptr, d->act == SRX_ACT_RELU, y, ws, ws_floats, stream);
+}
+
+// inference forms (functional.FoldedConv: conv with the eval-mode BatchNorm folded in, srgan/residual.py:86-91): any of no
+// activation / ReLU / LeakyReLU(d->slope) (a single-parameter PReLU is that), then `+ residual` (may be NULL)
+extern "C" int srx_wino_fwd_act(const srx_conv2d_t* d, const float* x, const float* upk, const float* bias, const float* residual,
+                                float* y, float* ws, size_t ws_floats, void* stream) {
+  SRX_REQUIRE(d && (d->act == SRX_ACT_NONE || d->act == SRX_ACT_RELU || d->act == SRX_ACT_LRELU), "wino_fwd_act: no activation, ReLU or LeakyReLU");
+  return wino_run(d, 0, x, upk, bias, nullptr, d->act == SRX_ACT_RELU, y, ws, ws_floats, stream, nullptr, residual,
+                  d->act == SRX_ACT_LRELU, d->slope);
+}
+// Is the Winograd form of this layer's forward worth it at inference?  As srx_wino_applicable, for layers the training path
+// leaves to the 36-pixel row tile as well (3x3 64 -> 64 on a frame: thousands of tile blocks)
+extern "C" int srx_wino_infer_applicable(const srx_conv2d_t* d) {
+  if (srx_dev().no_wino || !d || !wino_shape_ok(d, true)) return 0;
+  const double direct_us = 2.0 * d->N * d->H * d->W * (double)d->Cout * 9.0 * d->Cin / 110.0e6 + 5.0;
+  return wino_plan(d->N * (d->H / 2) * (d->W / 2), d->Cin, d->Cout, true).cost < direct_us ? 1 : 0;
 }
 
 // forward of a layer followed by a training-mode BatchNorm2d (srgan/discriminator.py:35-61: conv without bias, BatchNorm,

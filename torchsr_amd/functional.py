@@ -1829,17 +1829,28 @@ class FoldedConv:
             raise RuntimeError(f'folded_conv: input has {cs} channels (stride), layer expects {st.cin_s}')
         d = st.desc(n, h, w)
         dref = C.byref(d)
-        st.pack(self.w, d)
         L = _lib.lib()
         y = torch.empty(st.out_shape(n, h, w), dtype=torch.float32, device=x.device)
+        r = None
+        if residual is not None:
+            r = _chk(residual, 'folded_conv.residual')
+            if r.shape != y.shape:
+                raise RuntimeError('folded_conv: residual must have the output shape')
+        # exact-fp32 inference: the 3x3 layers of the trunk as Winograd F(2x2, 3x3) (csrc/wino.hip; 4/9 of the multiplications,
+        # PReLU / skip in its epilogue) -- at 1080p each 64 -> 64 layer is 16 200 tile blocks
+        if (st.precision == 0 and not _dev.NO_WINO and st.act in (ACT_NONE, ACT_RELU, ACT_LRELU)
+                and L.srx_wino_infer_applicable(dref) == 1):
+            st.pack_wino(self.w, d, need_bwd=False)
+            nws = L.srx_wino_ws_floats(dref, 0)
+            ws = _ws(nws, x) if nws else None
+            call('srx_wino_fwd_act', dref, _p(x), _p(st.wino_fwd), _p(self.b), _p(r), _p(y), _p(ws), nws, _stream())
+            return y
+        st.pack(self.w, d)
         nws = L.srx_conv2d_fwd_ws_floats(dref)
         ws = _ws(nws, x) if nws else None
         if residual is None:
             call('srx_conv2d_fwd', dref, _p(x), _p(st.wpk_fwd), _p(self.b), _p(y), None, _p(ws), nws, _stream())
         else:
-            r = _chk(residual, 'folded_conv.residual')
-            if r.shape != y.shape:
-                raise RuntimeError('folded_conv: residual must have the output shape')
             call('srx_conv2d_fwd_residual', dref, _p(x), _p(st.wpk_fwd), _p(self.b), _p(r), 1.0, _p(y), _p(ws), nws, _stream())
         return y
 
