@@ -470,7 +470,7 @@ int srx_wino_bwd_data(const srx_conv2d_t* d, const float* dy, const float* upk_t
  * (sum, sum of squares) of y -- the table srx_bn_finalize / srx_bn_train_fwd take, as srx_conv2d_fwd's bn_partials */
 int srx_wino_stat_rows(const srx_conv2d_t* d);
 int srx_wino_fwd_stats(const srx_conv2d_t* d, const float* x, const float* upk, const float* bias, float* y, float* stats,
-                       void* stream);
+                       float* ws /* srx_wino_ws_floats(d, 2) floats */, size_t ws_floats, void* stream);
 /* inference (functional.FoldedConv: conv with the eval-mode BatchNorm folded into weights and bias, srgan/residual.py:86-91):
  * y = act(conv(x) + bias) [+ residual], act = none / ReLU / LeakyReLU(d->slope) (a single-parameter PReLU is that); residual laid
  * out like y, a tensor of its own, may be NULL.  srx_wino_infer_applicable: as srx_wino_applicable, also for the 64 -> 64

@@ -122,7 +122,9 @@ def test_vgg_stack_on_winograd_equals_the_direct_kernels(dev, monkeypatch):
     assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.99999
 
 
-@pytest.mark.parametrize('cfg', [(4, 24, 24, 64, 128), (2, 12, 12, 256, 512), (1, 10, 6, 128, 96)], ids=lambda c: 'x'.join(map(str, c)))
+@pytest.mark.parametrize('cfg', [(4, 24, 24, 64, 128), (2, 12, 12, 256, 512), (1, 10, 6, 128, 96),
+                                 (32, 24, 24, 128, 256), (31, 12, 12, 256, 512)],   # 2.25 rounds of tiles: the last round's are cut in parts
+                         ids=lambda c: 'x'.join(map(str, c)))
 def test_winograd_forward_with_batchnorm_partials(dev, cfg):
     """srx_wino_fwd_stats: the conv's output plus, per block of 32 consecutive 2x2 tiles, the per-channel (sum, sum of squares)
     that a training-mode BatchNorm2d behind the layer reduces (srgan/discriminator.py:35-61)."""
@@ -142,8 +144,10 @@ def test_winograd_forward_with_batchnorm_partials(dev, cfg):
     assert rows == -(-(n * (h // 2) * (w // 2)) // 32)
     y = torch.empty(n, h, w, cout, device=dev)
     part = torch.full((rows, cout, 2), float('nan'), device=dev)
+    nws = L.srx_wino_ws_floats(dref, 2)
+    ws = torch.empty(max(nws, 4), device=dev)
     _lib.call('srx_wino_fwd_stats', dref, x.permute(0, 2, 3, 1).contiguous().to(dev).data_ptr(), uf.data_ptr(), None, y.data_ptr(),
-              part.data_ptr(), s)
+              part.data_ptr(), ws.data_ptr(), nws, s)
     assert rel(y.permute(0, 3, 1, 2), yr) < 2e-5
     # reference partials: tiles in (image, tile row, tile column) order, 32 per block
     tiles = yr.reshape(n, cout, h // 2, 2, w // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(-1, cout, 4)   # [T][C][4 pixels]

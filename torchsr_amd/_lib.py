@@ -258,7 +258,7 @@ _SIGS = {
     'srx_wino_infer_applicable': (_I, [_D]),
     'srx_wino_fwd_act': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_wino_stat_rows': (_I, [_D]),
-    'srx_wino_fwd_stats': (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    'srx_wino_fwd_stats': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_gan_head_fwd': (_I, [C.POINTER(GanHead), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'srx_gan_head_bwd': (_I, [C.POINTER(GanHead), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'srx_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),

@@ -365,7 +365,8 @@ __global__ __launch_bounds__(512) void wino_tail_fixup_kernel(const WinoArgs a) 
   const int tb = tile % a.tblocks, cb = tile / a.tblocks;
   const int et = tid / CQ, cq = tid % CQ;
   const int t = tb * WT + et;
-  if (t >= a.T) return;
+  const bool tvalid = t < a.T;
+  if (!tvalid && !a.stats) return;
   const float* src = a.tpart + (size_t)blockIdx.x * a.tsplit * (WT * 4 * BN) + (size_t)(et * 4) * BN + 4 * cq;
   f32x4 y[4];
   f32x4 v[4][4];
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(512) void wino_tail_fixup_kernel(const WinoArgs a) 
   const size_t p00 = (((size_t)n * a.H + 2 * th) * a.W + 2 * tw) * a.Cout + co;
   const size_t offs[4] = {p00, p00 + a.Cout, p00 + (size_t)a.W * a.Cout, p00 + (size_t)a.W * a.Cout + a.Cout};
   f32x4 mk[4];
-  if (a.mask) {
+  if (a.mask && tvalid) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) mk[p] = *reinterpret_cast<const f32x4*>(a.mask + offs[p]);
   }
@@ -395,6 +396,31 @@ __global__ __launch_bounds__(512) void wino_tail_fixup_kernel(const WinoArgs a) 
     const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
     for (int p = 0; p < 4; ++p) y[p] += bv;
+  }
+  if (a.stats) {  // the tile block's BatchNorm partials, as wino_kernel's epilogue forms them
+    __shared__ f32x4 red[(ITEMS / 64) * CQ * 2];
+    const int lane = tid & 63, wave = tid >> 6;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (tvalid) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) { s1 += y[p]; s2 += y[p] * y[p]; }
+    }
+#pragma unroll
+    for (int o = CQ; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+    constexpr int NW = ITEMS / 64;
+    if (lane < CQ) { red[(wave * CQ + lane) * 2 + 0] = s1; red[(wave * CQ + lane) * 2 + 1] = s2; }
+    __syncthreads();
+    if (tid < CQ) {
+      f32x4 t1 = red[tid * 2], t2 = red[tid * 2 + 1];
+#pragma unroll
+      for (int wv = 1; wv < NW; ++wv) { t1 += red[(wv * CQ + tid) * 2]; t2 += red[(wv * CQ + tid) * 2 + 1]; }
+      float* o = a.stats + ((size_t)tb * a.Cout + cb * BN + 4 * tid) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[2 * e] = t1[e]; o[2 * e + 1] = t2[e]; }
+    }
+    if (!tvalid) return;
   }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -421,7 +447,7 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 struct WinoPlan { int bn, zsplit; float cost; int tsplit; };  // tsplit > 1: the tiles of the last round are cut that many ways (zsplit = 1)
 
 // rounds of the chip x (chunks per workgroup x time per chunk + fixed cost), plus the fix-up pass of a split
-WinoPlan wino_plan(int T, int Cin, int Cout, bool no_split = false) {
+WinoPlan wino_plan(int T, int Cin, int Cout, bool no_split = false, bool no_tail = false) {
   const int P = srx_plan_cus();
   const int nch = Cin / WKC, tblocks = (int)srx_cdiv(T, WT);
   WinoPlan best{64, 1, 1e30f};
@@ -439,7 +465,7 @@ WinoPlan wino_plan(int T, int Cin, int Cout, bool no_split = false) {
       if (cost < best.cost) best = WinoPlan{bn, zs, cost, 1};
       // whole tiles for the full rounds, the tiles of the last round cut along the input channels so that it is a short one
       const int tail = (int)(wgs % P);
-      if (zs == 1 && !no_split && !srx_dev().wino_no_tail && wgs > P && tail > 0) {
+      if (zs == 1 && !no_tail && !srx_dev().wino_no_tail && wgs > P && tail > 0) {
         for (int ts = 2; ts <= nch && ts <= 8; ++ts) {
           if ((int64_t)tail * ts > P) break;
           const float c = (float)(wgs / P) * (nch * t_chunk + fixed) + (float)srx_cdiv(nch, ts) * t_chunk + fixed + 4.0f;  // (+ the fix-up launch)
@@ -449,6 +475,7 @@ WinoPlan wino_plan(int T, int Cin, int Cout, bool no_split = false) {
     }
   }
   if (const int v = srx_dev().wino_zsplit; v > 0 && v <= nch && !no_split) { best.zsplit = v; best.tsplit = 1; }
+  (void)no_tail;
   if (const int v = srx_dev().wino_bn; (v == 32 || v == 64) && Cout % v == 0) best.bn = v;
   return best;
 }
@@ -490,10 +517,11 @@ extern "C" int srx_wino_pack(const srx_conv2d_t* d, const float* w, float* upk, 
 
 // workspace (floats) of a forward (which = 0) or data-gradient (which = 1) call: the partial outputs of a channel split
 extern "C" size_t srx_wino_ws_floats(const srx_conv2d_t* d, int which) {
-  if (!d || !wino_shape_ok(d, which == 0)) return 0;
-  const int cin = which ? d->Cout : d->Cin, cout = which ? d->Cin : d->Cout;
+  if (!d || !wino_shape_ok(d, which != 1)) return 0;
+  const int cin = which == 1 ? d->Cout : d->Cin, cout = which == 1 ? d->Cin : d->Cout;
   const int T = d->N * (d->H / 2) * (d->W / 2);
-  const WinoPlan p = wino_plan(T, cin, cout, d->shuffle != 0);
+  // (which = 2: the forward with BatchNorm statistics -- whole outputs per tile, so no split of every tile; the last round's may be cut)
+  const WinoPlan p = wino_plan(T, cin, cout, d->shuffle != 0 || which == 2, d->shuffle != 0);
   if (p.tsplit > 1) {
     const int64_t wgs = srx_cdiv(T, WT) * (cout / p.bn);
     return (size_t)(wgs % srx_plan_cus()) * p.tsplit * WT * 4 * p.bn;
@@ -536,7 +564,8 @@ static int wino_run(const srx_conv2d_t* d, int which, const float* x, const floa
   a.add = add; a.lrelu = lrelu; a.slope = slope;
   // (statistics come from whole outputs, and the fix-up pass knows neither an addend nor a LeakyReLU: no channel split then)
   a.shuffle = d->shuffle ? d->Cout / 4 : 0;
-  const WinoPlan p = wino_plan(a.T, a.Cin, a.Cout, stats != nullptr || add != nullptr || lrelu != 0 || d->shuffle != 0);
+  const bool plain = add == nullptr && lrelu == 0 && d->shuffle == 0;  // (the fix-up passes know bias, ReLU, mask and statistics)
+  const WinoPlan p = wino_plan(a.T, a.Cin, a.Cout, stats != nullptr || !plain, !plain);
   a.zsplit = p.zsplit;
   a.ncb = a.Cout / p.bn;
   a.stats = stats;
@@ -611,9 +640,9 @@ extern "C" int srx_wino_stat_rows(const srx_conv2d_t* d) {
   return (d && wino_shape_ok(d)) ? (int)srx_cdiv((int64_t)d->N * (d->H / 2) * (d->W / 2), WT) : 0;
 }
 extern "C" int srx_wino_fwd_stats(const srx_conv2d_t* d, const float* x, const float* upk, const float* bias, float* y, float* stats,
-                                  void* stream) {
+                                  float* ws, size_t ws_floats, void* stream) {
   SRX_REQUIRE(d && d->act == SRX_ACT_NONE && stats, "wino_fwd_stats: a linear layer and a statistics table");
-  return wino_run(d, 0, x, upk, bias, nullptr, 0, y, nullptr, 0, stream, stats);
+  return wino_run(d, 0, x, upk, bias, nullptr, 0, y, ws, ws_floats, stream, stats);
 }
 
 extern "C" int srx_wino_bwd_data(const srx_conv2d_t* d, const float* dy, const float* upk_t, const float* relu_out, float* dx,

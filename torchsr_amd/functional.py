@@ -522,7 +522,9 @@ class _Conv2d(Function):
             st.pack_wino(master, d, need_bwd=ctx.needs_input_grad[0])
             if want_stats:
                 part = torch.empty((L.srx_wino_stat_rows(dref), st.cout, 2), dtype=torch.float32, device=x.device)
-                call('srx_wino_fwd_stats', dref, _p(x), _p(st.wino_fwd), _p(b), _p(y), _p(part), _stream())
+                nws = L.srx_wino_ws_floats(dref, 2)
+                call('srx_wino_fwd_stats', dref, _p(x), _p(st.wino_fwd), _p(b), _p(y), _p(part), _p(_ws(nws, x)) if nws else None, nws,
+                     _stream())
             else:
                 nws = L.srx_wino_ws_floats(dref, 0)
                 call('srx_wino_fwd', dref, _p(x), _p(st.wino_fwd), _p(b), _p(y), _p(_ws(nws, x)) if nws else None, nws, _stream())
