@@ -2170,8 +2170,8 @@ __global__ void pack_table_kernel(const PackRec* __restrict__ table) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= r.n_elems) return;
   float v = 0.f;
-  if (r.kind >= 4) {  // Winograd-domain weights (wino.hip): 4 the layer, 5 its data gradient
-    srx_wino_pack_one(r.w, r.dst, r.Cout, r.Cin, r.kind == 5, idx);
+  if (r.kind >= 4) {  // Winograd-domain weights (wino.hip): 4 the layer, 5 its data gradient, 6 the layer with a PixelShuffle store
+    srx_wino_pack_one(r.w, r.dst, r.Cout, r.Cin, r.kind == 5 ? 1 : (r.kind == 6 ? 2 : 0), idx);
     return;
   }
   if (r.kind >= 2) {  // thin.hip layout: p[c][tap][ch]
@@ -2283,7 +2283,8 @@ extern "C" int srx_pack_table_add_wino(void* host_table, int* nrec, long long* m
   SRX_REQUIRE(host_table && nrec && max_elems && d && w && upk && *nrec >= 0, "pack_table_add_wino: bad argument");
   SRX_REQUIRE(srx_wino_applicable(d) || srx_wino_packed_floats(d) > 0, "pack_table_add_wino: not a Winograd layer");
   PackRec r{};
-  r.dst = upk; r.w = w; r.kind = transpose ? 5 : 4;
+  SRX_REQUIRE(!(transpose && d->shuffle), "pack_table_add_wino: a PixelShuffle layer has no Winograd data gradient");
+  r.dst = upk; r.w = w; r.kind = transpose ? 5 : (d->shuffle ? 6 : 4);
   r.Cout = d->Cout; r.Cin = d->Cin; r.KH = 3; r.KW = 3; r.stride = 1; r.pad = 1;
   r.n_elems = (long long)d->Cout * d->Cin;
   static_cast<PackRec*>(host_table)[(*nrec)++] = r;

@@ -387,6 +387,13 @@ class ConvState:
         self._bf16s_key = key
 
 
+def wino_forward_only_ok(st: ConvState, d: Conv2dDesc) -> bool:
+    """A sub-pixel conv (3x3 + nn.PixelShuffle(2), srgan/residual.py:27-28) in exact fp32: its FORWARD runs on Winograd with the
+    shuffle in the store (csrc/wino.hip); its data gradient (a gather from the shuffled gradient) keeps the direct kernel."""
+    return (not _dev.NO_WINO and st.shuffle == 2 and st.act == ACT_NONE and st.precision == 0
+            and _lib.lib().srx_wino_infer_applicable(C.byref(d)) == 1)
+
+
 def wino_layer_ok(st: ConvState, d: Conv2dDesc) -> bool:
     """Does this layer's forward (and data gradient) run on Winograd F(2x2, 3x3) (csrc/wino.hip) at this size?  Wide 3x3 /
     stride 1 / pad 1 fp32 layers without a fused LeakyReLU; small 64 -> 64 layers keep the row-tile kernel."""
@@ -515,11 +522,12 @@ class _Conv2d(Function):
         b = None if bias is None else _chk(bias.detach(), 'conv2d.bias')
         # wide 3x3 layers: Winograd F(2x2, 3x3), 2.25x fewer fp32 multiplications (csrc/wino.hip) -- the VGG19 features called
         # layer by layer, the discriminators' stride-1 layers (with the BatchNorm partial statistics in the epilogue)
-        ctx.wino = wino_layer_ok(st, d) and (not want_stats or st.act == ACT_NONE)
+        fwd_only = not want_stats and wino_forward_only_ok(st, d)
+        ctx.wino = fwd_only or (wino_layer_ok(st, d) and (not want_stats or st.act == ACT_NONE))
         part = None
         if ctx.wino:
             # (trainable layers: PackTable refreshes the Winograd-domain weights inside the captured step)
-            st.pack_wino(master, d, need_bwd=ctx.needs_input_grad[0])
+            st.pack_wino(master, d, need_bwd=ctx.needs_input_grad[0] and not fwd_only)
             if want_stats:
                 part = torch.empty((L.srx_wino_stat_rows(dref), st.cout, 2), dtype=torch.float32, device=x.device)
                 nws = L.srx_wino_ws_floats(dref, 2)
