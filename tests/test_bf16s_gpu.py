@@ -270,3 +270,44 @@ def test_bf16_storage_backward_chain_against_the_recipe_in_fp64(dev):
     d = got - x.grad
     assert float(d.norm() / x.grad.norm()) < 2e-3, float(d.norm() / x.grad.norm())
     assert rel(got, x.grad) < 2e-2
+
+
+@pytest.mark.parametrize('cfg', [(32, 64, 64, 128, 128), (32, 16, 16, 512, 512), (16, 128, 128, 64, 64)], ids=lambda c: 'x'.join(map(str, c)))
+def test_bf16_storage_conv_equals_the_fp32_stored_form_at_the_step_sizes(dev, cfg):
+    """At the sizes of the ESRGAN step (VGG19 on 128 x 128 crops, batch 32 forward / 16 backward) the bf16-storage conv against
+    ``srx_conv2d_fwd`` / ``srx_conv2d_bwd_data_act`` with ``precision = 1`` on the same bf16-representable operands stored as
+    fp32: the same products, fp32 sums in a possibly different order -- 2e-5 of the output scale."""
+    from torchsr_amd import _lib
+    n, h, w, cin, cout = cfg
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(19)
+    x16 = bf(torch.randn(n, h, w, cin, generator=g).relu()).to(dev)
+    dy16 = bf(torch.randn(n, h, w, cout, generator=g)).to(dev)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    d = _lib.Conv2dDesc(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, _lib.ACT_RELU, 0.0, 0, 1)
+    dref = C.byref(d)
+    wf = torch.empty(L.srx_conv2d_packed_fwd_floats(dref), device=dev)
+    wb = torch.empty(L.srx_conv2d_packed_bwd_floats(dref), device=dev)
+    _lib.call('srx_conv2d_pack', dref, wt.data_ptr(), wf.data_ptr(), wb.data_ptr(), s)
+    nb = L.srx_conv3x3_bf16s_packed_bytes(dref) // 2
+    pf, pb = torch.empty(nb, dtype=torch.bfloat16, device=dev), torch.empty(nb, dtype=torch.bfloat16, device=dev)
+    _lib.call('srx_conv3x3_bf16s_pack', dref, wt.data_ptr(), pf.data_ptr(), pb.data_ptr(), s)
+
+    def ws_for(nfl):
+        return torch.empty(max(int(nfl), 4), device=dev)
+    x32, dy32 = x16.float(), dy16.float()
+    ya, yb = torch.empty(n, h, w, cout, device=dev), torch.empty(n, h, w, cout, device=dev)
+    nws = L.srx_conv2d_fwd_ws_floats(dref)
+    _lib.call('srx_conv2d_fwd', dref, x32.data_ptr(), wf.data_ptr(), bias.data_ptr(), ya.data_ptr(), None, ws_for(nws).data_ptr(), nws, s)
+    nw2 = L.srx_conv3x3_bf16s_ws_floats(dref, 0)
+    _lib.call('srx_conv3x3_bf16s_fwd', dref, x16.data_ptr(), pf.data_ptr(), bias.data_ptr(), 1, yb.data_ptr(), 0, ws_for(nw2).data_ptr(), nw2, s)
+    assert rel(yb, ya) < 2e-5
+    da, db = torch.empty(n, h, w, cin, device=dev), torch.empty(n, h, w, cin, device=dev)
+    nws = L.srx_conv2d_bwd_data_ws_floats(dref)
+    _lib.call('srx_conv2d_bwd_data_act', dref, dy32.data_ptr(), wb.data_ptr(), x32.data_ptr(), 0.0, 0, cin, 0, da.data_ptr(),
+              ws_for(nws).data_ptr(), nws, s)
+    nw2 = L.srx_conv3x3_bf16s_ws_floats(dref, 1)
+    _lib.call('srx_conv3x3_bf16s_bwd_data', dref, dy16.data_ptr(), pb.data_ptr(), x16.data_ptr(), db.data_ptr(), 0, ws_for(nw2).data_ptr(), nw2, s)
+    assert rel(db, da) < 2e-5

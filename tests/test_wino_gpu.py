@@ -214,3 +214,54 @@ def test_winograd_forward_with_pixel_shuffle(dev):
     xg = x.permute(0, 2, 3, 1).contiguous().to(dev)
     _lib.call('srx_wino_fwd_act', dref, xg.data_ptr(), uf.data_ptr(), bias.to(dev).data_ptr(), None, y.data_ptr(), None, 0, s)
     assert rel(y.permute(0, 3, 1, 2), want) < 2e-5
+
+
+@pytest.mark.parametrize('cfg', [(32, 24, 24, 256, 256), (32, 12, 12, 512, 512), (32, 96, 96, 64, 64), (16, 48, 48, 128, 128),
+                                 (32, 6, 6, 512, 512)], ids=lambda c: 'x'.join(map(str, c)))
+def test_winograd_equals_the_direct_kernel_at_the_step_sizes(dev, cfg):
+    """At the sizes the BASELINE step runs (batch 32 / 16 of 96 x 96 crops through VGG19: too large for a CPU reference in the
+    suite's time) the Winograd forward and data gradient against the exact-fp32 direct gather-GEMM on the same operands
+    (``srx_conv2d_fwd`` / ``srx_conv2d_bwd_data_act``, themselves pinned against fp64 at small sizes): 2e-5 of the output scale,
+    and linearity of the Winograd path in its input (conv(2 x + x') = 2 conv(x) + conv(x') without bias)."""
+    from torchsr_amd import _lib
+    n, h, w, cin, cout = cfg
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, h, w, cin, generator=g).relu().to(dev)
+    x2 = torch.randn(n, h, w, cin, generator=g).to(dev)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    dy = torch.randn(n, h, w, cout, generator=g).to(dev)
+    d = _lib.Conv2dDesc(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, _lib.ACT_RELU, 0.0, 0, 0)
+    d0 = _lib.Conv2dDesc(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, _lib.ACT_NONE, 0.0, 0, 0)
+    dref = C.byref(d)
+    wf = torch.empty(L.srx_conv2d_packed_fwd_floats(dref), device=dev)
+    wb = torch.empty(L.srx_conv2d_packed_bwd_floats(dref), device=dev)
+    _lib.call('srx_conv2d_pack', dref, wt.data_ptr(), wf.data_ptr(), wb.data_ptr(), s)
+    uf, ub = torch.empty(L.srx_wino_packed_floats(dref), device=dev), torch.empty(L.srx_wino_packed_floats(dref), device=dev)
+    _lib.call('srx_wino_pack', dref, wt.data_ptr(), uf.data_ptr(), 0, s)
+    _lib.call('srx_wino_pack', dref, wt.data_ptr(), ub.data_ptr(), 1, s)
+
+    def ws_for(nfl):
+        return torch.empty(max(int(nfl), 4), device=dev)
+    ya, yb = torch.empty(n, h, w, cout, device=dev), torch.empty(n, h, w, cout, device=dev)
+    nws = L.srx_conv2d_fwd_ws_floats(dref)
+    _lib.call('srx_conv2d_fwd', dref, x.data_ptr(), wf.data_ptr(), bias.data_ptr(), ya.data_ptr(), None, ws_for(nws).data_ptr(), nws, s)
+    nww = L.srx_wino_ws_floats(dref, 0)
+    _lib.call('srx_wino_fwd', dref, x.data_ptr(), uf.data_ptr(), bias.data_ptr(), yb.data_ptr(), ws_for(nww).data_ptr(), nww, s)
+    assert rel(yb, ya) < 2e-5
+    da, db = torch.empty_like(x), torch.empty_like(x)
+    nws = L.srx_conv2d_bwd_data_ws_floats(dref)
+    _lib.call('srx_conv2d_bwd_data_act', dref, dy.data_ptr(), wb.data_ptr(), x.data_ptr(), 0.0, 0, cin, 0, da.data_ptr(),
+              ws_for(nws).data_ptr(), nws, s)
+    nww = L.srx_wino_ws_floats(dref, 1)
+    _lib.call('srx_wino_bwd_data', dref, dy.data_ptr(), ub.data_ptr(), x.data_ptr(), db.data_ptr(), ws_for(nww).data_ptr(), nww, s)
+    assert rel(db, da) < 2e-5
+    # linearity (no bias, no activation)
+    nww = L.srx_wino_ws_floats(C.byref(d0), 0)
+    y1, y2, y3 = (torch.empty(n, h, w, cout, device=dev) for _ in range(3))
+    mix = 2.0 * x + x2
+    for src, dst in ((x, y1), (x2, y2), (mix, y3)):
+        _lib.call('srx_wino_fwd', C.byref(d0), src.data_ptr(), uf.data_ptr(), None, dst.data_ptr(), ws_for(nww).data_ptr(), nww, s)
+    assert rel(y3, 2.0 * y1 + y2) < 2e-5
