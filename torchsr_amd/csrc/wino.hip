@@ -577,8 +577,8 @@ static int wino_run(const srx_conv2d_t* d, int which, const float* x, const floa
   int64_t items = (int64_t)a.tblocks * a.ncb * a.zsplit;
   a.full = (int)items; a.tsplit = 1;
   int tail = 0;
-  if (p.tsplit > 1) {
-    tail = (int)(items % srx_plan_cus());
+  if (p.tsplit > 1) tail = (int)(items % srx_plan_cus());
+  if (tail > 0) {  // (0: a developer override of BN left no partly filled round)
     const size_t need = (size_t)tail * p.tsplit * WT * 4 * p.bn;
     if (!ws || ws_floats < need) SRX_FAIL(SRX_E_WORKSPACE, "wino: workspace %zu < %zu floats", ws_floats, need);
     a.full = (int)items - tail; a.tsplit = p.tsplit; a.tpart = ws;
