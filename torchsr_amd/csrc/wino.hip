@@ -24,8 +24,10 @@
 //     M[xi][tile][channel], every thread takes one (tile, channel quad), applies A^T M A, adds the bias, applies ReLU or the
 //     ReLU mask of the layer below (data gradients: the fold of srx_conv2d_bwd_data_act) and stores four pixels x 16 bytes.
 // The data gradient of such a layer IS such a layer (channels swapped, taps flipped): srx_wino_pack(..., transpose = 1).
-// Small layers split the input channels over several workgroups (partial outputs + a streaming fix-up), the planner picks the
-// split and BN (64 or 32) that fill whole rounds of the chip.
+// Small layers split the input channels over several workgroups (partial outputs + a streaming fix-up); layers that cut into a
+// non-integer number of rounds of the chip's CUs run whole tiles for the full rounds and cut only the tiles of the last round along
+// the input channels (tile-local partial outputs + wino_tail_fixup_kernel); the planner (wino_plan) picks BN (64 or 32) and the split
+// from a cost model.  Inference adds LeakyReLU / PReLU, a skip addend and nn.PixelShuffle(2) in the store (srx_wino_fwd_act).
 #include "srx_common.h"
 #include <algorithm>
 #include <mutex>
