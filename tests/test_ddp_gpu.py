@@ -88,13 +88,20 @@ def _worker(rank, world, port, out):
 
         # ---- oracle for step 0: both shards in this process, gradients averaged, BatchNorm per rank
         vgg_sd = {k: v.detach().cpu().clone() for k, v in te.vgg_loss.features.state_dict().items()}
-        orc = O.SRGANDataParallelOracle(closed_form_state(te.generator.state_dict()),
-                                        closed_form_state(te.discriminator.state_dict()), vgg_sd, world)
-        shards = [_shard(r) for r in range(world)]
-        want_losses = orc.gan_step([s[0] for s in shards], [s[1] for s in shards])[rank]
+        # (computed once, on rank 0 with every host core to itself, and handed to the others: the oracle needs both shards anyway)
+        box = [None]
+        if rank == 0:
+            orc = O.SRGANDataParallelOracle(closed_form_state(te.generator.state_dict()),
+                                            closed_form_state(te.discriminator.state_dict()), vgg_sd, world)
+            shards = [_shard(r) for r in range(world)]
+            losses = orc.gan_step([s[0] for s in shards], [s[1] for s in shards])
+            box[0] = {r: (losses[r], {k: v.detach() for k, v in orc.g_ranks[r].items()},
+                          {k: v.detach() for k, v in orc.d_ranks[r].items()}) for r in range(world)}
+        dist.broadcast_object_list(box, src=0)
+        want_losses, ref_g, ref_d = box[0][rank]
         report['loss_err'] = max(abs(g - w) / max(abs(w), 1e-3) for g, w in zip(first['losses'], want_losses))
         bad, worst = [], 0.0
-        for name, got, ref in (('G', first['G'], orc.g_ranks[rank]), ('D', first['D'], orc.d_ranks[rank])):
+        for name, got, ref in (('G', first['G'], ref_g), ('D', first['D'], ref_d)):
             for k, v in got.items():
                 r = ref[k].detach()
                 if not v.is_floating_point():
@@ -212,13 +219,19 @@ def _esr_worker(rank, world, port, out):
         report['param_gap'] = gap
 
         vgg_sd = {k: v.detach().cpu().clone() for k, v in te.vgg_loss.features.state_dict().items()}
-        orc = OE.ESRGANDataParallelOracle(step_state(te.generator.state_dict(), 'esrgan.G'),
-                                          step_state(te.discriminator.state_dict(), 'esrgan.D'), vgg_sd, world)
-        shards = [_esr_shard(r) for r in range(world)]
-        want = orc.gan_step([s[0] for s in shards], [s[1] for s in shards])[rank]
+        box = [None]   # (the oracle once, on rank 0, handed to the others: as in _worker)
+        if rank == 0:
+            orc = OE.ESRGANDataParallelOracle(step_state(te.generator.state_dict(), 'esrgan.G'),
+                                              step_state(te.discriminator.state_dict(), 'esrgan.D'), vgg_sd, world)
+            shards = [_esr_shard(r) for r in range(world)]
+            losses = orc.gan_step([s[0] for s in shards], [s[1] for s in shards])
+            g_sd = {k: v.detach() for k, v in orc.g.items()}
+            box[0] = {r: (losses[r], g_sd, {k: v.detach() for k, v in orc.d_ranks[r].items()}) for r in range(world)}
+        dist.broadcast_object_list(box, src=0)
+        want, ref_g, ref_d = box[0][rank]
         report['loss_err'] = max(abs(g - w) / max(abs(w), 1e-3) for g, w in zip(first['losses'], want))
         bad = []
-        for name, got, ref in (('G', first['G'], orc.g), ('D', first['D'], orc.d_ranks[rank])):
+        for name, got, ref in (('G', first['G'], ref_g), ('D', first['D'], ref_d)):
             for k, v in got.items():
                 r = ref[k].detach()
                 if not v.is_floating_point():
