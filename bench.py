@@ -17,8 +17,10 @@ Rank 0 prints ONE JSON line.  At N = 1 it also carries
   "parity":       the four losses of the FIRST step (seeded default-init weights) on the HIP path and on the
                   CPU oracle from the same weights and batch; ``rel`` is the generator-loss difference;
   "roofline":     the dominant kernel by device time, measured live with HIP events on the launch stream in an
-                  instrumented eager pass of the same step: algorithmic FLOPs of its launches / their
-                  event-measured duration, against the 157.3 TFLOP/s fp32 MFMA peak of MI355X; ``by_shape``
+                  instrumented eager pass of the same step: the MFMA FLOPs its launches EXECUTE / their
+                  event-measured duration, against the 157.3 TFLOP/s fp32 MFMA peak of MI355X (``frac`` <= 1: a Winograd
+                  kernel executes 16/36 of the direct convolution's multiplications; the direct-form rate it delivers is
+                  ``algorithmic_tflops``, never a fraction); ``by_shape``
                   lists the layer shapes it serves, ``traffic`` = HBM bytes per launch of the heaviest one from
                   the committed rocprofv3 --pmc passes (profiles/r03_traffic.json; null if not profiled);
                   ``north_star`` = the 3x3 64->64 residual conv at 16x24x24 timed the way the step runs it,
@@ -55,6 +57,26 @@ CROP = 96
 GF_PER_CROP = 43.23  # necessary algorithmic GFLOP per crop of the GAN step
 PEAK_TFLOPS = 157.3  # fp32 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 NORTH_STAR_GF = 0.6795  # 3x3 64->64 conv at 16x24x24: 2 * 9216 * 64 * 576
+WINO_EXECUTED = 16.0 / 36.0  # Winograd F(2x2, 3x3): multiplications executed per multiplication of the direct form
+
+
+def executed_ratio(kernel):
+    """MFMA FLOPs a kernel EXECUTES per algorithmic (direct-convolution) FLOP the library's profiler books for it: the Winograd
+    kernels (csrc/wino.hip) multiply 16 times where the direct form multiplies 36 times, every other kernel runs the direct count.
+    Every ``frac`` of this file is executed FLOPs / time / peak (a share of the matrix pipe, <= 1); the direct-form rate is
+    carried beside it as ``algorithmic_tflops``."""
+    return WINO_EXECUTED if kernel.startswith('wino_') else 1.0
+
+
+def rates(kernel, flops, ms, peak):
+    """{'tflops' (executed), 'frac' (executed / peak), 'algorithmic_tflops'[, 'algorithmic_speedup']} of `flops` algorithmic
+    FLOPs in `ms` milliseconds on `kernel`."""
+    alg = flops / (ms * 1e-3) / 1e12
+    r = executed_ratio(kernel)
+    out = {'tflops': round(alg * r, 2), 'frac': round(alg * r / peak, 4), 'algorithmic_tflops': round(alg, 2)}
+    if r != 1.0:
+        out['algorithmic_speedup'] = round(1.0 / r, 3)
+    return out
 
 
 def synth_batch(device, rank, batch=BATCH):
@@ -142,7 +164,7 @@ def north_star_in_graph(device, reps=66, replays=20):
     tf = NORTH_STAR_GF / us * 1e3
     return {'kernel': 'rt36_conv3x3_c64_kernel<1>', 'shape': '3x3 64->64 @16x24x24 (M 9216, N 64, K 576)',
             'launches_per_replay': reps, 'us_per_launch_in_graph': round(us, 3), 'tflops': round(tf, 2),
-            'frac': round(tf / PEAK_TFLOPS, 4), 'gflop_per_launch': NORTH_STAR_GF,
+            'frac': round(tf / PEAK_TFLOPS, 4), 'algorithmic_tflops': round(tf, 2), 'gflop_per_launch': NORTH_STAR_GF,
             'note': 'includes the ~1.5 us kernel boundary between dependent launches'}
 
 
@@ -175,10 +197,13 @@ def dominant_shape_in_graph(device, reps=20, replays=10):
     times.sort()
     us = times[len(times) // 2]
     gf = 2.0 * 18432 * 256 * 2304 / 1e9
+    from torchsr_amd import functional as F
+    st = conv._st
+    kern = 'wino_kernel' if st._descs and F.wino_layer_ok(st, next(iter(st._descs.values()))) else 'gconv_kernel'
     return {'MxNxK': '18432x256x2304', 'what': 'VGG19 block 3 (3x3 256->256 + bias + ReLU, batch 32 at 24x24) on the kernel the step runs it on '
                                             '(Winograd F(2x2,3x3) since round 5; SRX_NO_WINO=1: the direct gather-GEMM)',
-            'launches_per_replay': reps, 'us_per_launch_in_graph': round(us, 2),
-            'gflop_per_launch': round(gf, 3), 'tflops': round(gf / us * 1e3, 2), 'frac': round(gf / us * 1e3 / PEAK_TFLOPS, 4)}
+            'kernel': kern, 'launches_per_replay': reps, 'us_per_launch_in_graph': round(us, 2),
+            'gflop_per_launch': round(gf, 3), **rates(kern, gf * 1e9, us * 1e-3, PEAK_TFLOPS)}
 
 
 def prof_tables(step_fn, reps=2, slots=4096):
@@ -216,12 +241,13 @@ def dominant_of(step_fn, peak_tflops, reps=2, slots=4096):
     if not kernels:
         return None
     kname, (ms, fl, cnt) = max(kernels.items(), key=lambda kv: kv[1][0])
-    tf = fl / (ms * 1e-3) / 1e12
     return {'kernel': kname, 'ms': round(ms / reps, 3), 'launches': cnt // reps, 'avg_launch_us': round(ms / cnt * 1e3, 2),
-            'tflops': round(tf, 2), 'frac': round(tf / peak_tflops, 4),
+            **rates(kname, fl, ms, peak_tflops),
             'timing': 'eager event pair per launch (dispatch gaps included: the sum can exceed the replayed wall time by ~10 %)',
             'conv_kernel_ms': round(sum(v[0] for v in kernels.values()) / reps, 3),
-            'conv_launches': sum(v[2] for v in kernels.values()) // reps}
+            'conv_launches': sum(v[2] for v in kernels.values()) // reps,
+            # algorithmic GFLOP per call that the Winograd kernels do NOT multiply (their launches' direct-form count x 20/36)
+            'gflop_not_executed': round(sum(v[1] * (1.0 - executed_ratio(k)) for k, v in kernels.items()) / reps / 1e9, 3)}
 
 
 def roofline_pass(trainer, lr, hr, reps=2):
@@ -241,10 +267,11 @@ def roofline_pass(trainer, lr, hr, reps=2):
     # the dominant kernel = the kernel (template instance) with the most device time per step, over all the layer
     # shapes it serves; its shapes are listed one by one, each with the HBM traffic of the committed --pmc passes
     kname, (ms, fl, cnt) = max(kernels.items(), key=lambda kv: kv[1][0])
-    achieved = fl / (ms * 1e-3) / 1e12
+    top_rates = rates(kname, fl, ms, PEAK_TFLOPS)
     table = {k: {'ms_per_step': round(v[0] / reps, 4), 'gflop_per_step': round(v[1] / reps / 1e9, 3),
-                 'launches_per_step': v[2] // reps, 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 2)}
+                 'launches_per_step': v[2] // reps, **rates(k, v[1], v[0], PEAK_TFLOPS)}
              for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][0])}
+    saved_gf = sum(v[1] * (1.0 - executed_ratio(k)) for k, v in kernels.items()) / reps / 1e9
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE: tools/pmc_run.sh) of
     # tools/pmc_workloads.py restricted to ONE layer shape; counters cannot be read from inside the process
     measured = {}
@@ -258,21 +285,25 @@ def roofline_pass(trainer, lr, hr, reps=2):
             continue
         ent = measured.get(full) or {}
         shapes.append({'MxNxK': full.split(' MxNxK=')[1], 'launches_per_step': v[2] // reps,
-                       'avg_launch_us': round(v[0] / v[2] * 1e3, 2), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 2),
+                       'avg_launch_us': round(v[0] / v[2] * 1e3, 2), **rates(kname, v[1], v[0], PEAK_TFLOPS),
                        'traffic': round(ent['hbm_bytes_per_launch']) if ent else None,
                        'algorithmic_bytes': ent.get('algorithmic_bytes_per_launch')})
     top = shapes[0] if shapes else {}
-    wino = kname.startswith('wino_kernel')
-    return {
-        'bound': 'mfma', 'kernel': kname, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / PEAK_TFLOPS, 4),
-        # Winograd F(2x2, 3x3) executes 16 multiplications where the direct convolution executes 36: `achieved` counts the
-        # ALGORITHMIC FLOPs of the convolution (2 x M x N x K, as for every other kernel), so it can exceed what the matrix
-        # cores could do on the direct form; `mfma_frac` is the share of the fp32 MFMA peak the kernel's own MFMAs reach
+    wino = executed_ratio(kname) != 1.0
+    out = {
+        # `achieved` / `frac`: the MFMA FLOPs the dominant kernel EXECUTES per second, against the fp32 MFMA peak -- the share of the
+        # matrix pipe it uses (<= 1).  A Winograd F(2x2, 3x3) kernel executes 16 multiplications where the direct convolution
+        # executes 36, so the rate of the convolution it delivers (`algorithmic_tflops` = 2 x M x N x K / time, what every
+        # direct kernel's `tflops` is too) is 2.25 x its executed rate and may exceed the peak; it is never called a fraction
+        'bound': 'mfma', 'kernel': kname, 'achieved': top_rates['tflops'], 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': top_rates['frac'],
         'algorithm': 'Winograd F(2x2,3x3), fp32' if wino else 'direct gather-GEMM, fp32',
-        'executed_over_algorithmic_flops': round(16.0 / 36.0, 4) if wino else 1.0,
-        'mfma_frac': round(achieved * (16.0 / 36.0 if wino else 1.0) / PEAK_TFLOPS, 4),
+        'algorithmic_tflops': top_rates['algorithmic_tflops'],
+        'algorithmic_speedup': round(1.0 / executed_ratio(kname), 3),
+        'executed_over_algorithmic_flops': round(executed_ratio(kname), 4),
         'timing': 'eager pass, one HIP event pair per launch on the launch stream (srx_prof_*): dispatch gaps included, a few per cent pessimistic against the replayed graph',
+        'step_gflop_algorithmic': round(GF_PER_CROP * BATCH, 2),
+        'step_gflop_executed': round(GF_PER_CROP * BATCH - saved_gf, 2),
 
         'traffic': top.get('traffic'), 'traffic_shape_MxNxK': top.get('MxNxK'),
         'algorithmic_bytes_per_launch': top.get('algorithmic_bytes'),
@@ -280,6 +311,7 @@ def roofline_pass(trainer, lr, hr, reps=2):
         'gflop_per_launch': round(fl / cnt / 1e9, 4),
         'conv_ms_per_step': round(total_ms / reps, 3), 'by_shape': shapes, 'by_kernel': table,
     }
+    return out
 
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
@@ -312,6 +344,17 @@ def _crops(device, n, crop, seed):
     return lr.to(device), hr.to(device)
 
 
+def leg_rates(alg_gf, dt, peak, dom):
+    """Rates of one configuration's step: `alg_gf` algorithmic GFLOP (2 x MACs of conv + linear, direct form) in `dt` seconds.
+    ``tflops`` / ``frac`` count the MFMA FLOPs the step EXECUTES (the algorithmic count less what its Winograd launches do not
+    multiply, from the same eager profiler pass that names the dominant kernel) -- a share of the matrix pipe, <= 1."""
+    saved = (dom or {}).get('gflop_not_executed', 0.0)
+    ex = alg_gf - saved
+    out = {'algorithmic_gflop': round(alg_gf, 2), 'executed_gflop': round(ex, 2), 'tflops': round(ex / dt / 1e3, 2),
+           'peak_tflops': peak, 'frac': round(ex / dt / 1e3 / peak, 4), 'algorithmic_tflops': round(alg_gf / dt / 1e3, 2)}
+    return out
+
+
 def other_configs(device):
     """BASELINE.json's other configurations, each timed on this GPU after the headline region (N = 1 only): wall time
     per step over hipGraph replays with a synchronize on both sides, inputs resident in HBM, the EXECUTED algorithmic
@@ -341,8 +384,7 @@ def other_configs(device):
         t.use_graphs = False
         dom = dominant_of(lambda: t.pretrain_step(lr, hr), PEAK_TFLOPS)
         return {'workload': f'SRGAN SRResNet pre-training step (BASELINE configs[0] shape), 96x96 crops, batch {b}, fp32',
-                'ms': round(dt * 1e3, 3), 'crops_per_s': round(b / dt, 1), 'executed_gflop': round(gf, 2),
-                'tflops': round(gf / dt / 1e3, 2), 'peak_tflops': PEAK_TFLOPS, 'frac': round(gf / dt / 1e3 / PEAK_TFLOPS, 4),
+                'ms': round(dt * 1e3, 3), 'crops_per_s': round(b / dt, 1), **leg_rates(gf, dt, PEAK_TFLOPS, dom),
                 'dtype': 'f32', 'dominant_kernel': dom}
 
     def esrgan():
@@ -355,9 +397,8 @@ def other_configs(device):
         dom = dominant_of(lambda: t.gan_step(lr, hr), PEAK_BF16_TFLOPS, reps=1, slots=8192)
         return {'workload': 'ESRGAN full GAN step (23-RRDB generator + relativistic discriminator + VGG19), 128x128 crops, '
                             'batch 16, bf16 products / fp32 accumulate (BASELINE configs[3])',
-                'ms': round(dt * 1e3, 3), 'crops_per_s': round(16 / dt, 1), 'executed_gflop': gf,
-                'reference_executes_gflop': 3622.0, 'tflops': round(gf / dt / 1e3, 2), 'peak_tflops': PEAK_BF16_TFLOPS,
-                'frac': round(gf / dt / 1e3 / PEAK_BF16_TFLOPS, 4), 'dtype': 'bf16 products, f32 accumulate',
+                'ms': round(dt * 1e3, 3), 'crops_per_s': round(16 / dt, 1), **leg_rates(gf, dt, PEAK_BF16_TFLOPS, dom),
+                'reference_executes_gflop': 3622.0, 'dtype': 'bf16 products, f32 accumulate',
                 'dominant_kernel': dom}
 
     def infer(precision):
@@ -370,8 +411,7 @@ def other_configs(device):
         dom = dominant_of(lambda: upscale(gen, lr, **kw), peak, reps=1, slots=8192)
         return {'workload': f'SRGAN generator 1920x1080 -> 7680x4320, batch 1, eval mode, tiled, {precision} '
                             '(BASELINE configs[4])',
-                'ms_per_image': round(dt * 1e3, 2), 'executed_gflop': INFER_GF, 'tflops': round(INFER_GF / dt / 1e3, 2),
-                'peak_tflops': peak, 'frac': round(INFER_GF / dt / 1e3 / peak, 4),
+                'ms_per_image': round(dt * 1e3, 2), **leg_rates(INFER_GF, dt, peak, dom),
                 'dtype': 'f32' if precision == 'fp32' else 'bf16 products, f32 accumulate', 'dominant_kernel': dom}
 
     leg('srgan_pretrain_b2', lambda: pretrain(2))
@@ -549,6 +589,19 @@ def cpu_baseline(states, lr, hr, warmup=3, steps=10, budget_s=60.0):
             'cpu_model': cpu_model(), 'os_cpu_count': os.cpu_count(), 'threads': torch.get_num_threads(),
             'config1_pretrain_b2': {'value': round(2 / med2, 3), 'unit': 'crops/s',
                                     'sample': f'{n2} timed pre-training steps of batch 2, median {med2 * 1e3:.1f} ms/step'}}
+
+
+def assert_fracs(obj, path='line'):
+    """Every ``frac`` of the line is a share of a hardware peak: none may exceed 1."""
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if 'frac' in k.split('_') and not isinstance(v, (dict, list, str)):
+                assert v is None or 0.0 <= v <= 1.0, f'{path}.{k} = {v}: not a fraction of a peak'
+            else:
+                assert_fracs(v, f'{path}.{k}')
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            assert_fracs(v, f'{path}[{i}]')
 
 
 def main():
@@ -731,8 +784,9 @@ def main():
                                         if distributed else None),
                        'plan_cus': _plan_cus(), 'comm': comm},
             'per_rank_ms_per_step': rank_ms,
-            'step_tflops': round(value * GF_PER_CROP / 1e3, 2),
-            'step_frac_of_fp32_mfma_peak': round(value * GF_PER_CROP / 1e3 / (PEAK_TFLOPS * world), 4),
+            # the convolution work the step DELIVERS per second (direct-form count); the share of the matrix
+            # pipe the step uses is roofline.step_frac_of_fp32_mfma_peak (executed FLOPs: Winograd layers multiply 16/36 of it)
+            'step_algorithmic_tflops': round(value * GF_PER_CROP / 1e3, 2),
             'step_ms_spread': spread,
             'final_gen_loss': round(gen_loss, 6),
         }
@@ -749,6 +803,9 @@ def main():
             if not args.no_roofline:
                 try:
                     out['roofline'] = roofline_pass(trainer, lr, hr)
+                    ex_tf = out['roofline']['step_gflop_executed'] / (elapsed / args.steps) / 1e3
+                    out['roofline']['step_executed_tflops'] = round(ex_tf, 2)
+                    out['roofline']['step_frac_of_fp32_mfma_peak'] = round(ex_tf / PEAK_TFLOPS, 4)
                     out['roofline']['north_star'] = north_star_in_graph(device)
                     out['roofline']['dominant_shape_in_graph'] = dominant_shape_in_graph(device)
                 except Exception as exc:  # noqa: BLE001
@@ -770,6 +827,7 @@ def main():
                 except Exception as exc:  # noqa: BLE001
                     print(f'bench.py: dp rehearsal failed: {type(exc).__name__}: {exc}', file=sys.stderr)
                     out['dp_rehearsal'] = {'error': f'{type(exc).__name__}: {str(exc)[-300:]}'}
+        assert_fracs(out)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

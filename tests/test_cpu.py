@@ -572,3 +572,21 @@ def test_comm_configuration_is_decided_before_the_process_group(monkeypatch):
     assert mine['nccl_max_nchannels'] == '4' and mine['nccl_min_nchannels'] == '2' and mine['reserved_cus_in_comm_window'] == 4
     monkeypatch.setenv('SRX_COMM_RESERVED_CUS', '12')
     assert ddp.configure_comm(8, 'nccl')['reserved_cus_in_comm_window'] == 12
+
+
+def test_bench_fractions_are_shares_of_a_peak():
+    """bench.py's ``frac`` fields are executed MFMA FLOPs over a hardware peak: a Winograd F(2x2, 3x3) kernel books 16/36 of
+    the direct convolution's multiplications, its direct-form rate travels as ``algorithmic_tflops``, and no line with a
+    fraction above 1 is printed."""
+    import bench
+    r = bench.rates('wino_kernel<64>', 380.5e9, 1.881, bench.PEAK_TFLOPS)  # round 5's dominant kernel, per replay
+    assert abs(r['algorithmic_tflops'] - 202.3) < 0.1 and abs(r['tflops'] - 89.9) < 0.1 and abs(r['frac'] - 0.5716) < 1e-3
+    assert r['algorithmic_speedup'] == 2.25
+    d = bench.rates('gconv_kernel<128, 64, 32, 32, 1, 16, 0>', 41.448e9, 0.4631, bench.PEAK_TFLOPS)
+    assert d['tflops'] == d['algorithmic_tflops'] and 'algorithmic_speedup' not in d
+    leg = bench.leg_rates(9199.0, 62.43e-3, bench.PEAK_TFLOPS, {'gflop_not_executed': 9199.0 * 0.9 * 20 / 36})
+    assert leg['frac'] < 1.0 and leg['algorithmic_tflops'] > leg['tflops']
+    bench.assert_fracs({'roofline': {'frac': 0.57, 'step_frac_of_fp32_mfma_peak': 0.41, 'by_shape': [{'frac': 0.6}]}})
+    for bad in ({'roofline': {'frac': 1.1218}}, {'x': [{'dominant_kernel': {'frac': 1.03}}]}, {'step_frac_of_fp32_mfma_peak': 1.2}):
+        with pytest.raises(AssertionError):
+            bench.assert_fracs(bad)
