@@ -1,4 +1,4 @@
-// 3x3 / stride 1 / pad 1 convolutions of wide layers as Winograd F(2x2, 3x3) on the fp32 matrix cores (round 5).
+// 3x3 / stride 1 / pad 1 convolutions of wide layers as Winograd F(2x2, 3x3) on the fp32 matrix cores (round 5; recut in round 6).
 //
 // The direct gather-GEMM (gconv.hip) runs the VGG19 layers of the perceptual loss (srgan/loss.py:30-54: 344 of the SRGAN
 // step's 692 GFLOP) at 0.95 of what v_mfma_f32_32x32x2_f32 gives at the clock the part holds under that load -- the only
@@ -13,16 +13,28 @@
 // direct fp32 convolution by rounding only (measured 2-3x its own rounding error against fp64, i.e. ~5e-7 of the tensor's
 // scale: tools/experiments/wino_error.py), far inside the 1e-3 the parity tests allow.
 //
-// One workgroup = 32 tiles (128 output pixels) x BN output channels x all 16 xi, 512 threads:
-//   * waves 0..3 gather the 4x4 input patches of the 32 tiles for a chunk of 32 input channels (16 pixels x 16 bytes per
-//     thread, padding pixels through an out-of-range descriptor offset), apply B^T d B in registers (32 float4 adds) and
-//     write the sixteen V_xi rows of the chunk to a two-stage LDS ring (64 KB per stage, XOR-swizzled 128-byte rows);
-//   * every wave owns two xi and multiplies them for all 32 tiles and BN channels: U fragments come STRAIGHT from global memory
-//     into MFMA operand registers (each xi belongs to exactly one wave, so nothing is shared through LDS; srx_wino_pack lays
-//     U out so that a wave's load is 1 KB contiguous), V fragments are one ds_read_b128 per eight MFMAs;
-//   * epilogue: the accumulators (U as the A operand, so a lane holds four consecutive channels of one tile) go to LDS as
-//     M[xi][tile][channel], every thread takes one (tile, channel quad), applies A^T M A, adds the bias, applies ReLU or the
-//     ReLU mask of the layer below (data gradients: the fold of srx_conv2d_bwd_data_act) and stores four pixels x 16 bytes.
+// What shapes the kernel (round 6, measured: tools/probe/mfma_valu.hip, tools/lab/): ON gfx950 THE f32 MFMA RUNS ON THE VECTOR
+// ALUs -- a v_mfma_f32_32x32x2_f32 and a VALU instruction of ANY wave of the SIMD never overlap; every VALU instruction costs
+// ~7 clocks of matrix time (v_pk_add_f32 the same 7 for two adds).  So the transforms are not "free under the MFMAs": the kernel
+// counts VALU instructions (packed adds, tile coordinates by one float multiply, offsets kept in LDS), spreads them evenly over the
+// four SIMDs, and uses co-residency only for what it can hide: memory latency, barrier waits, the prologue's first round trip.
+//
+// One workgroup = 32 tiles (128 output pixels) x BN output channels x all 16 xi, 256 threads = one wave per SIMD, 80 KB of LDS:
+// TWO workgroups share a CU, each with its own barriers (round 5: one 512-thread workgroup owned the CU and its 4.4 us of prologue
+// + epilogue per work item ran with the matrix pipe idle).
+//   * every wave owns FOUR xi (accumulators 4 xi x BN / 32 channel tiles x 16 registers) and multiplies them for all 32 tiles:
+//     U fragments come STRAIGHT from global memory into MFMA operand registers in 8-byte granules through a two-slot ring (each xi
+//     belongs to exactly one wave, so nothing is shared through LDS; srx_wino_pack lays U out so that a wave's load is contiguous),
+//     V fragments are one ds_read_b128 per eight MFMAs;
+//   * all four waves gather the 4x4 input patches of the 32 tiles for a chunk of 16 input channels -- one (tile, channel pair) per
+//     thread: 16 x 8-byte loads whose byte offsets (padding pixels: an out-of-range descriptor offset) sit in LDS, not in
+//     registers -- apply B^T d B with 32 packed adds and write the sixteen V_xi rows to a two-stage LDS ring (32 KB per stage,
+//     XOR-swizzled 64-byte rows); the loads of chunk c + 1 ride between the MFMAs of the first half of chunk c, its transform
+//     between those of the second half (sched_group_barrier), so a wave alone on its SIMD keeps issuing;
+//   * epilogue, one 32-channel tile at a time: the accumulators (U as the A operand, so a lane holds four consecutive channels
+//     of one tile) go to LDS as M[xi][tile][channel], every thread takes one (tile, channel quad), applies A^T M A, adds the bias,
+//     applies ReLU or the ReLU mask of the layer below (data gradients: the fold of srx_conv2d_bwd_data_act) and stores four
+//     pixels x 16 bytes.
 // The data gradient of such a layer IS such a layer (channels swapped, taps flipped): srx_wino_pack(..., transpose = 1).
 // Small layers split the input channels over several workgroups (partial outputs + a streaming fix-up); layers that cut into a
 // non-integer number of rounds of the chip's CUs run whole tiles for the full rounds and cut only the tiles of the last round along
@@ -34,16 +46,24 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int WT = 32;       // tiles per workgroup
-constexpr int WKC = 32;      // input channels per chunk
-constexpr int STAGE_BYTES = 16 * WT * WKC * 4;  // 65536: V of one chunk
-constexpr int WINO_LDS = 2 * STAGE_BYTES;       // the epilogue's M[16][32][BN <= 64] reuses both stages
+constexpr int WKC = 32;      // input channels per chunk of the packed U (the planner's unit of a channel split)
+constexpr int VKC = 16;      // input channels per LDS stage
+constexpr int STAGE_BYTES = 16 * WT * VKC * 4;  // 32768: V of one stage
+constexpr int RING_BYTES = 2 * STAGE_BYTES;     // the epilogue's M[16][32][32] (one 32-channel tile at a time) reuses both stages
+constexpr int POFF_BYTES = 256 * 16 * 4;        // the 16 patch-pixel byte offsets of every thread, [pixel row][thread] uint4s
+constexpr int WINO_LDS = RING_BYTES + POFF_BYTES;  // 81920: half a CU's LDS (the statistics epilogue reuses the offsets' area)
+constexpr int WINO_THREADS = 256;
 
 struct WinoArgs {
   const float* in; const float* upk; const float* bias; const float* mask; float* out; float* part;
   float* stats;  // training-mode BatchNorm partials of the pre-activation output: [tile block][Cout][2] = (sum, sum of squares), or null
   int N, H, W, Cin, Cout;
   int TH, TW, T, tblocks, ncb, nch, zsplit;
+  float inv_TW, inv_TH;  // tile coordinates by one float multiply each while T < 2^24 (srx_divmod); exact integer division above
   int relu;
   // inference forms (FoldedConv, round 5): `lrelu` != 0: LeakyReLU / single-parameter PReLU with slope `slope` instead of ReLU;
   // `add`: a tensor laid out like `out`, added after the activation (the skip of a residual block, srgan/residual.py:86-91)
@@ -58,8 +78,35 @@ struct WinoArgs {
   size_t out_elems;  // N * H * W * Cout (stride between the partial outputs of two splits)
 };
 
+__device__ __forceinline__ f32x2 srx_bload2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+// two adds for one instruction (see the header: beside f32 MFMAs the instruction count is what costs)
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+__device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {
+  const f32x2 lo = pk_add(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = pk_add(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b) {
+  const f32x2 lo = pk_sub(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = pk_sub(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+// tile t -> (image, tile row, tile column)
+__device__ __forceinline__ void wino_tile_coords(const WinoArgs& a, int t, int& n, int& th, int& tw) {
+  if (a.T < (1 << 24)) {  // (uniform)
+    int r;
+    srx_divmod(t, a.TW, a.inv_TW, r, tw);
+    srx_divmod(r, a.TH, a.inv_TH, n, th);
+  } else {
+    tw = t % a.TW; const int r = t / a.TW; th = r % a.TH; n = r / a.TH;
+  }
+}
+
 template <int BN>
-__global__ __launch_bounds__(512) void wino_kernel(const WinoArgs a) {
+__global__ __launch_bounds__(WINO_THREADS, 2) void wino_kernel(const WinoArgs a) {
   constexpr int NJ = BN / 32;  // channel tiles per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
@@ -82,249 +129,278 @@ __global__ __launch_bounds__(512) void wino_kernel(const WinoArgs a) {
     z = t % a.tsplit; zs = a.tsplit;
     tb = tile % a.tblocks; cb = tile / a.tblocks;
   }
-  // this split's chunks of input channels: [kc0, kc1)
-  const int kc0 = srx_uniform((int)((long long)z * a.nch / zs)), kc1 = srx_uniform((int)((long long)(z + 1) * a.nch / zs));
+  // this split's stages of 16 input channels: [kc0, kc1) -- whole 32-channel chunks of the packed U
+  const int kc0 = 2 * srx_uniform((int)((long long)z * a.nch / zs)), kc1 = 2 * srx_uniform((int)((long long)(z + 1) * a.nch / zs));
   const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes);
   const __amdgpu_buffer_rsrc_t ru = srx_rsrc(a.upk, a.upk_bytes);
 
-  // ---- loader state (waves 0..3): tile tl of the block, channel quad q of the chunk; byte offsets of the 16 patch pixels
-  const bool loader = wave < 4;
-  const int tl = tid >> 3, q = tid & 7;  // (tid < 256 for loaders)
-  unsigned poff[16];
+  // ---- this thread's tile (the one it gathers patches for AND the one it finishes in the epilogue) and channel pair / quad
+  const int tl = tid >> 3, pr = tid & 7;
+  const int t = tb * WT + tl;
+  const bool tvalid = t < a.T;
+  int tn, th, tw;
+  wino_tile_coords(a, t, tn, th, tw);
+  u32x4* spoff = reinterpret_cast<u32x4*>(smem + RING_BYTES);  // [4][256]
   {
-    const int t = tb * WT + (tl & 31);
-    const bool tok = loader && t < a.T;
-    const int tw = t % a.TW, r = t / a.TW, th = r % a.TH, n = r / a.TH;
     const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
-    const int base = ((n * a.H + ih0) * a.W + iw0) * a.Cin + 4 * q;  // element offset of patch pixel (0, 0) (may be "negative": never used then)
+    const int base = ((tn * a.H + ih0) * a.W + iw0) * a.Cin + 2 * pr;  // element offset of patch pixel (0, 0) (may be "negative": never used then)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool rok = tok && (unsigned)(ih0 + i) < (unsigned)a.H;
+      const bool rok = tvalid && (unsigned)(ih0 + i) < (unsigned)a.H;
+      u32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool ok = rok && (unsigned)(iw0 + j) < (unsigned)a.W;
-        poff[4 * i + j] = ok ? 4u * (unsigned)(base + (i * a.W + j) * a.Cin) : 0xffffffffu;  // out of range reads 0
+        o[j] = ok ? 4u * (unsigned)(base + (i * a.W + j) * a.Cin) : 0xffffffffu;  // out of range reads 0
       }
+      spoff[i * WINO_THREADS + tid] = o;  // (read back by this thread only: no barrier)
     }
   }
-  // ---- multiplier state: this wave's two xi; U fragments of a sub-step s: [xi][j] one float4 per lane
-  //      packed U: (((xi * (Cout / 32) + jg) * nch + kc) * 4 + s) * 64 + lane, in float4 units
-  const int xi0 = 2 * wave;
+  // ---- multiplier state: this wave's four xi; packed U, float4 index (((xi * (Cout / 32) + jg) * nch + kc32) * 4 + s4) * 64 + lane:
+  //      a lane part in a VGPR, the (xi, channel tile) part in SGPRs
+  const int xi0 = 4 * wave;
   const int cot = a.Cout >> 5;
-  unsigned uoff[2][NJ];
+  const unsigned ulane = 16u * (unsigned)lane;
+  unsigned ubase[4][NJ];
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-      uoff[x][j] = 16u * (unsigned)((((xi0 + x) * cot + cb * NJ + j) * a.nch) * 256 + lane);
+    for (int j = 0; j < NJ; ++j) ubase[x][j] = (unsigned)srx_uniform((((xi0 + x) * cot + cb * NJ + j) * a.nch) * 4096);
 
-  f32x16 acc[2][NJ];
+  f32x16 acc[4][NJ];
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][j][r] = 0.f;
 
-  f32x4 pd[16];        // the patch of the chunk being staged
-  f32x4 uf[4][2][NJ];  // U fragments, one slot per sub-step
-  // (measured: loads that are simply skipped past the last chunk beat gconv.hip's always-issued, out-of-range-pointed ones
-  // here -- 1360 vs 1404 us over VGG19's forward -- the chunk loop is short and the last chunk's dummy stage costs more)
+  f32x2 pd[16];        // the patch of the stage being gathered
+  f32x2 uf[2][4][NJ];  // U fragments, two slots: (phase & 1); a phase = two of the four k-pairs of a sub-step = 8 NJ MFMAs
+  f32x4 vf[4];
   auto load_patch = [&](int kc) {
-#pragma unroll
-    for (int p = 0; p < 16; ++p) pd[p] = srx_bload(rin, poff[p], (unsigned)srx_uniform(kc * (WKC * 4)));
-  };
-  auto load_u = [&](int kc, int s) {
-    const unsigned so = (unsigned)srx_uniform((kc * 4 + s) * 1024);
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) uf[s][x][j] = srx_bload(ru, uoff[x][j], so);
-  };
-  // B^T d B of this thread's patch, the sixteen results to row (xi, tl) of stage `st` at quad q (XOR swizzle as in gconv.hip)
-  auto stage_patch = [&](int st) {
-    // in place, so that no second copy of the patch is ever live: rows first (d B: every input row on its own), then the
-    // columns (B^T .), each column's four results written as soon as they exist
+    const unsigned so = (unsigned)srx_uniform(kc * (VKC * 4));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const f32x4 r0 = pd[4 * i + 0] - pd[4 * i + 2], r1 = pd[4 * i + 1] + pd[4 * i + 2], r2 = pd[4 * i + 2] - pd[4 * i + 1],
-                  r3 = pd[4 * i + 1] - pd[4 * i + 3];
+      const u32x4 o = spoff[i * WINO_THREADS + tid];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pd[4 * i + j] = srx_bload2(rin, o[j], so);
+    }
+  };
+  // phase ph (0..3) of stage kc: sub-step s = ph >> 1 of the stage (sub-step 2 (kc & 1) + s of the packed 32-channel chunk),
+  // k-pairs 2 (ph & 1), 2 (ph & 1) + 1 of it: the second 8 bytes of the packed float4
+  auto load_u = [&](int kc, int ph) {
+    const unsigned so = (unsigned)srx_uniform(((kc >> 1) * 4 + (kc & 1) * 2 + (ph >> 1)) * 1024 + (ph & 1) * 8);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) uf[ph & 1][x][j] = srx_bload2(ru, ulane, ubase[x][j] + so);
+  };
+  // B^T d B of this thread's patch (rows first, in place; then the columns), the sixteen results to row (xi, tl) of stage `st`:
+  // 16 floats per row, 16-byte quad q of the row at quad q ^ ((tl >> 2) & 3) (conflict-free ds_read_b128 of the MFMA operands)
+  auto stage_patch = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 r0 = pk_sub(pd[4 * i + 0], pd[4 * i + 2]), r1 = pk_add(pd[4 * i + 1], pd[4 * i + 2]), r2 = pk_sub(pd[4 * i + 2], pd[4 * i + 1]),
+                  r3 = pk_sub(pd[4 * i + 1], pd[4 * i + 3]);
       pd[4 * i + 0] = r0; pd[4 * i + 1] = r1; pd[4 * i + 2] = r2; pd[4 * i + 3] = r3;
     }
-    float* base = reinterpret_cast<float*>(smem + st * STAGE_BYTES) + tl * WKC + ((q ^ ((tl >> 1) & 7)) << 2);
+    float* base = reinterpret_cast<float*>(smem + st * STAGE_BYTES) + tl * VKC + (((pr >> 1) ^ ((tl >> 2) & 3)) << 2) + ((pr & 1) << 1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f32x4 v0 = pd[0 + j] - pd[8 + j], v1 = pd[4 + j] + pd[8 + j], v2 = pd[8 + j] - pd[4 + j], v3 = pd[4 + j] - pd[12 + j];
-      *reinterpret_cast<f32x4*>(base + (0 + j) * (WT * WKC)) = v0;   // xi = 4 i + j
-      *reinterpret_cast<f32x4*>(base + (4 + j) * (WT * WKC)) = v1;
-      *reinterpret_cast<f32x4*>(base + (8 + j) * (WT * WKC)) = v2;
-      *reinterpret_cast<f32x4*>(base + (12 + j) * (WT * WKC)) = v3;
+      const f32x2 v0 = pk_sub(pd[0 + j], pd[8 + j]), v1 = pk_add(pd[4 + j], pd[8 + j]), v2 = pk_sub(pd[8 + j], pd[4 + j]), v3 = pk_sub(pd[4 + j], pd[12 + j]);
+      *reinterpret_cast<f32x2*>(base + (0 + j) * (WT * VKC)) = v0;   // xi = 4 i + j
+      *reinterpret_cast<f32x2*>(base + (4 + j) * (WT * VKC)) = v1;
+      *reinterpret_cast<f32x2*>(base + (8 + j) * (WT * VKC)) = v2;
+      *reinterpret_cast<f32x2*>(base + (12 + j) * (WT * VKC)) = v3;
     }
   };
-  // sub-step s of the chunk in stage st: quads 2s (lanes 0..31) and 2s + 1 (lanes 32..63) of this wave's two xi
-  const int vrow = l31 * WKC, vsw = (l31 >> 1) & 7;
-  auto mma = [&](int st, int s) {
+  // sub-step s of the stage st: quads 2s (lanes 0..31) and 2s + 1 (lanes 32..63) of this wave's four xi
+  const int vrow = l31 * VKC, vsw = (l31 >> 2) & 3;
+  auto read_v = [&](int st, int s) {
     const float* sv = reinterpret_cast<const float*>(smem + st * STAGE_BYTES) + vrow + (((2 * s + h) ^ vsw) << 2);
-    f32x4 vf[2];
 #pragma unroll
-    for (int x = 0; x < 2; ++x) vf[x] = *reinterpret_cast<const f32x4*>(sv + (xi0 + x) * (WT * WKC));
-    __builtin_amdgcn_s_setprio(1);
+    for (int x = 0; x < 4; ++x) vf[x] = *reinterpret_cast<const f32x4*>(sv + (xi0 + x) * (WT * VKC));
+  };
+  auto mma = [&](int ph) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int x = 0; x < 2; ++x)
+      for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[x][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[s][x][j][e], vf[x][e], acc[x][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+          acc[x][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[ph & 1][x][j][e], vf[x][2 * (ph & 1) + e], acc[x][j], 0, 0, 0);
   };
 
-  // ---- prologue: first chunk staged, its U fragments requested
-  if (loader) load_patch(kc0);
-#pragma unroll
-  for (int s = 0; s < 4; ++s) load_u(kc0, s);
-  if (loader) stage_patch(0);
+  // ---- prologue: first stage gathered, its first U fragments requested
+  load_patch(kc0);
+  load_u(kc0, 0);
+  load_u(kc0, 1);
+  stage_patch(0);
   __syncthreads();
-  // ---- chunk loop: the patch of chunk c + 1 is requested at the top, transformed and written between the second and third
-  // sub-step (the partner wave on the SIMD keeps the matrix pipe busy meanwhile); a sub-step's U slot is refilled for
-  // chunk c + 1 as soon as its MFMAs are issued
+  // ---- stage loop (the last stage peeled: it requests nothing beyond itself, so every vmcnt of the steady state is exact)
   int st = 0;
-  for (int kc = kc0; kc < kc1; ++kc) {
-    const bool more = kc + 1 < kc1;  // (workgroup-uniform)
-    if (loader && more) load_patch(kc + 1);
-    mma(st, 0);
-    if (more) load_u(kc + 1, 0);
-    mma(st, 1);
-    if (more) load_u(kc + 1, 1);
-    if (loader && more) stage_patch(st ^ 1);
-    mma(st, 2);
-    if (more) load_u(kc + 1, 2);
-    mma(st, 3);
-    if (more) load_u(kc + 1, 3);
+  for (int kc = kc0; kc + 1 < kc1; ++kc) {
+    // first half: the next stage's patch requests and this stage's later U fragments ride between the MFMAs of phases 0, 1
+    load_patch(kc + 1);
+    read_v(st, 0);
+    mma(0);
+    load_u(kc, 2);
+    mma(1);
+    load_u(kc, 3);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int i = 0; i < 16 * NJ; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, NJ == 2 ? 1 : 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // second half: the patch transform and the next stage's first U fragments between the MFMAs of phases 2, 3
+    read_v(st, 1);  // (before the transform's LDS stores in program order: the compiler cannot tell the two stages apart)
+    stage_patch(st ^ 1);
+    mma(2);
+    load_u(kc + 1, 0);
+    mma(3);
+    load_u(kc + 1, 1);
     __syncthreads();
     st ^= 1;
   }
+  {
+    const int kc = kc1 - 1;
+    read_v(st, 0);
+    mma(0);
+    load_u(kc, 2);
+    mma(1);
+    load_u(kc, 3);
+    read_v(st, 1);
+    mma(2);
+    mma(3);
+    __syncthreads();
+  }
 
-  // ---- epilogue: M[xi][tile][channel] through LDS (16-byte chunk c of row (xi, t) at chunk c ^ (t & 15): the 32 lanes of
-  // a store hit 16 different chunk columns), then A^T M A per (tile, channel quad)
-  constexpr int MROW = BN;  // floats per (xi, tile) row
+  // ---- epilogue, one 32-channel tile j at a time: M[xi][tile][32 channels] through LDS (16-byte chunk c of row (xi, t) at chunk
+  // c ^ (t & 7)), then A^T M A per (tile, channel quad)
   float* sM = reinterpret_cast<float*>(smem);
+  const int cq = pr;
+  const bool store_ok = tvalid;
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int j = 0; j < NJ; ++j) {
+    if (j > 0) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int x = 0; x < 4; ++x)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         // accumulator rows (channels) 8 g + 4 h + 0..3 of channel tile j, column (tile) l31
-        const int c = (j * 32 + 8 * g + 4 * h) >> 2;  // 16-byte chunk of the row
+        const int c = 2 * g + h;
         const f32x4 v = {acc[x][j][4 * g + 0], acc[x][j][4 * g + 1], acc[x][j][4 * g + 2], acc[x][j][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(sM + ((xi0 + x) * WT + l31) * MROW + ((c ^ (l31 & (BN / 4 - 1))) << 2)) = v;
+        *reinterpret_cast<f32x4*>(sM + ((xi0 + x) * WT + l31) * 32 + ((c ^ (l31 & 7)) << 2)) = v;
       }
-  __syncthreads();
-  constexpr int CQ = BN / 4;            // channel quads per row
-  constexpr int ITEMS = WT * CQ;        // 512 (BN = 64) or 256 (BN = 32)
-  if (tid >= ITEMS) return;             // (BN = 32: waves 4..7 are done; a terminated wave does not hold up the barrier below)
-  const int et = tid / CQ, cq = tid % CQ;
-  const int t = tb * WT + et;
-  const bool tvalid = t < a.T;
-  if (!tvalid && !a.stats) return;
-  f32x4 m[16];
+    __syncthreads();
+    f32x4 m[16];
 #pragma unroll
-  for (int x = 0; x < 16; ++x) m[x] = *reinterpret_cast<const f32x4*>(sM + (x * WT + et) * MROW + ((cq ^ (et & (CQ - 1))) << 2));
-  f32x4 s0[4], s1[4];
+    for (int x = 0; x < 16; ++x) m[x] = *reinterpret_cast<const f32x4*>(sM + (x * WT + tl) * 32 + ((cq ^ (tl & 7)) << 2));
+    f32x4 s0[4], s1[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    s0[j] = m[0 + j] + m[4 + j] + m[8 + j];
-    s1[j] = m[4 + j] - m[8 + j] - m[12 + j];
-  }
-  f32x4 y[4];
-  y[0] = s0[0] + s0[1] + s0[2];
-  y[1] = s0[1] - s0[2] - s0[3];
-  y[2] = s1[0] + s1[1] + s1[2];
-  y[3] = s1[1] - s1[2] - s1[3];
-  const int tw = t % a.TW, r = t / a.TW, th = r % a.TH, n = r / a.TH;
-  const int co = cb * BN + 4 * cq;
-  const size_t p00 = (((size_t)n * a.H + 2 * th) * a.W + 2 * tw) * a.Cout + co;
-  size_t offs[4] = {p00, p00 + a.Cout, p00 + (size_t)a.W * a.Cout, p00 + (size_t)a.W * a.Cout + a.Cout};
-  if (a.shuffle) {  // GEMM column co = (sub-pixel ij, channel cc): pixel (y, x) of the conv lands at (2y + ij / 2, 2x + ij % 2), channel cc
-    const int ij = co / a.shuffle, cc = co - ij * a.shuffle;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const size_t oy = 2 * (size_t)(2 * th + (p >> 1)) + (ij >> 1), ox = 2 * (size_t)(2 * tw + (p & 1)) + (ij & 1);
-      offs[p] = (((size_t)n * 2 * a.H + oy) * (2 * (size_t)a.W) + ox) * a.shuffle + cc;
+    for (int q = 0; q < 4; ++q) {
+      s0[q] = pk_add4(pk_add4(m[0 + q], m[4 + q]), m[8 + q]);
+      s1[q] = pk_sub4(pk_sub4(m[4 + q], m[8 + q]), m[12 + q]);
     }
-  }
-  if (tailw) {  // a part of a tail tile: raw partial output, tile-local layout; finished by wino_tail_fixup_kernel
-    float* o = a.tpart + (size_t)((int)blockIdx.x - a.full) * (WT * 4 * BN) + (size_t)(et * 4) * BN + 4 * cq;
+    f32x4 y[4];
+    y[0] = pk_add4(pk_add4(s0[0], s0[1]), s0[2]);
+    y[1] = pk_sub4(pk_sub4(s0[1], s0[2]), s0[3]);
+    y[2] = pk_add4(pk_add4(s1[0], s1[1]), s1[2]);
+    y[3] = pk_sub4(pk_sub4(s1[1], s1[2]), s1[3]);
+    const int co = cb * BN + 32 * j + 4 * cq;
+    if (tailw) {  // a part of a tail tile: raw partial output, tile-local layout; finished by wino_tail_fixup_kernel
+      if (store_ok) {
+        float* o = a.tpart + (size_t)((int)blockIdx.x - a.full) * (WT * 4 * BN) + (size_t)(tl * 4) * BN + 32 * j + 4 * cq;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(o + p * BN) = y[p];
-    return;
-  }
-  if (a.part) {  // one of several splits of the input channels: the raw partial output; bias / activation in the fix-up pass
-    float* o = a.part + (size_t)z * a.out_elems;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(o + offs[p]) = y[p];
-    return;
-  }
-  f32x4 mk[4], ad[4];
-  if (a.mask && tvalid) {  // (all loads before the first store)
-#pragma unroll
-    for (int p = 0; p < 4; ++p) mk[p] = *reinterpret_cast<const f32x4*>(a.mask + offs[p]);
-  }
-  if (a.add && tvalid) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) ad[p] = *reinterpret_cast<const f32x4*>(a.add + offs[p]);
-  }
-  if (a.bias) {
-    f32x4 bv;
-    if (a.shuffle) {  // (the bias is in the conv's own channel order)
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(o + p * BN) = y[p];
+      }
+      continue;
+    }
+    const size_t p00 = (((size_t)tn * a.H + 2 * th) * a.W + 2 * tw) * a.Cout + co;
+    size_t offs[4] = {p00, p00 + a.Cout, p00 + (size_t)a.W * a.Cout, p00 + (size_t)a.W * a.Cout + a.Cout};
+    if (a.shuffle) {  // GEMM column co = (sub-pixel ij, channel cc): pixel (y, x) of the conv lands at (2y + ij / 2, 2x + ij % 2), channel cc
       const int ij = co / a.shuffle, cc = co - ij * a.shuffle;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bv[e] = a.bias[(cc + e) * 4 + ij];
-    } else {
-      bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+      for (int p = 0; p < 4; ++p) {
+        const size_t oy = 2 * (size_t)(2 * th + (p >> 1)) + (ij >> 1), ox = 2 * (size_t)(2 * tw + (p & 1)) + (ij & 1);
+        offs[p] = (((size_t)tn * 2 * a.H + oy) * (2 * (size_t)a.W) + ox) * a.shuffle + cc;
+      }
     }
+    if (a.part) {  // one of several splits of the input channels: the raw partial output; bias / activation in the fix-up pass
+      if (store_ok) {
+        float* o = a.part + (size_t)z * a.out_elems;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) y[p] += bv;
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(o + offs[p]) = y[p];
+      }
+      continue;
+    }
+    f32x4 mk[4], ad[4];
+    if (a.mask && store_ok) {  // (all loads before the first store)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) mk[p] = *reinterpret_cast<const f32x4*>(a.mask + offs[p]);
+    }
+    if (a.add && store_ok) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) ad[p] = *reinterpret_cast<const f32x4*>(a.add + offs[p]);
+    }
+    if (a.bias) {
+      f32x4 bv;
+      if (a.shuffle) {  // (the bias is in the conv's own channel order)
+        const int ij = co / a.shuffle, cc = co - ij * a.shuffle;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = a.bias[(cc + e) * 4 + ij];
+      } else {
+        bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) y[p] = pk_add4(y[p], bv);
+    }
+    if (a.stats) {
+      // per-channel sum / sum of squares of this tile block's 128 pixels (what gconv's epilogue writes per row tile): the lanes
+      // of a wave that share a channel quad first (fixed butterfly over the 8 tiles of the wave), then the four waves in order
+      f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+      if (store_ok) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { s1 += y[p]; s2 += y[p] * y[p]; }
+      }
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+      f32x4* red = reinterpret_cast<f32x4*>(smem + RING_BYTES) + j * 64;  // [4 waves][8 quads][2] per channel tile
+      if (lane < 8) { red[(wave * 8 + lane) * 2 + 0] = s1; red[(wave * 8 + lane) * 2 + 1] = s2; }
+    }
+    if (store_ok) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = y[p][e];
+          if (a.relu) v = fmaxf(v, 0.f);
+          if (a.lrelu) v = v > 0.f ? v : v * a.slope;
+          if (a.mask) v = mk[p][e] > 0.f ? v : 0.f;
+          if (a.add) v += ad[p][e];
+          y[p][e] = v;
+        }
+        *reinterpret_cast<f32x4*>(a.out + offs[p]) = y[p];
+      }
+    }
   }
-  if (a.stats) {
-    // per-channel sum / sum of squares of this tile block's 128 pixels (what gconv's epilogue writes per row tile): the
-    // lanes of a wave that share a channel quad first (fixed butterfly), then the waves in order through LDS
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-    if (tvalid) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) { s1 += y[p]; s2 += y[p] * y[p]; }
-    }
-#pragma unroll
-    for (int o = CQ; o < 64; o <<= 1)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
-    constexpr int NW = ITEMS / 64;  // waves that hold items
-    f32x4* red = reinterpret_cast<f32x4*>(smem + WINO_LDS);  // [NW][CQ][2]
-    if (lane < CQ) { red[(wave * CQ + lane) * 2 + 0] = s1; red[(wave * CQ + lane) * 2 + 1] = s2; }
+  if (a.stats && !tailw && !a.part) {  // (workgroup-uniform) the waves' partial sums, in order
     __syncthreads();
-    if (tid < CQ) {
-      f32x4 t1 = red[tid * 2], t2 = red[tid * 2 + 1];
+    if (tid < 8 * NJ) {
+      const int j = tid >> 3, q = tid & 7;
+      const f32x4* red = reinterpret_cast<const f32x4*>(smem + RING_BYTES) + j * 64;
+      f32x4 t1 = red[q * 2], t2 = red[q * 2 + 1];
 #pragma unroll
-      for (int wv = 1; wv < NW; ++wv) { t1 += red[(wv * CQ + tid) * 2]; t2 += red[(wv * CQ + tid) * 2 + 1]; }
-      float* o = a.stats + ((size_t)tb * a.Cout + cb * BN + 4 * tid) * 2;
+      for (int wv = 1; wv < 4; ++wv) { t1 += red[(wv * 8 + q) * 2]; t2 += red[(wv * 8 + q) * 2 + 1]; }
+      float* o = a.stats + ((size_t)tb * a.Cout + cb * BN + 32 * j + 4 * q) * 2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o[2 * e] = t1[e]; o[2 * e + 1] = t2[e]; }
     }
-    if (!tvalid) return;
-  }
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = y[p][e];
-      if (a.relu) v = fmaxf(v, 0.f);
-      if (a.lrelu) v = v > 0.f ? v : v * a.slope;
-      if (a.mask) v = mk[p][e] > 0.f ? v : 0.f;
-      if (a.add) v += ad[p][e];
-      y[p][e] = v;
-    }
-    *reinterpret_cast<f32x4*>(a.out + offs[p]) = y[p];
   }
 }
 
@@ -559,6 +635,7 @@ static int wino_run(const srx_conv2d_t* d, int which, const float* x, const floa
   a.tblocks = (int)srx_cdiv(a.T, WT);
   a.nch = a.Cin / WKC;
   a.relu = relu;
+  a.inv_TW = 1.0f / (float)a.TW; a.inv_TH = 1.0f / (float)a.TH;
   a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * a.Cin * sizeof(float));
   a.upk_bytes = (unsigned)((size_t)16 * a.Cin * a.Cout * sizeof(float));
   a.out_elems = (size_t)d->N * d->H * d->W * a.Cout;
@@ -589,15 +666,14 @@ static int wino_run(const srx_conv2d_t* d, int which, const float* x, const floa
   const dim3 grid((unsigned)items);
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
   });
   char nm[112];
   if (srx_prof_on()) snprintf(nm, sizeof(nm), "wino_kernel<%d> MxNxK=%dx%dx%d", p.bn, a.N * a.H * a.W, a.Cout, 9 * a.Cin);
   const double fl = 2.0 * a.N * a.H * a.W * (double)a.Cout * 9.0 * a.Cin;  // algorithmic FLOPs of the convolution (the direct form's)
-  const size_t lds = WINO_LDS + (stats ? 4096 : 0);
-  if (p.bn == 64) SRX_LAUNCH_PROF(nm, fl, wino_kernel<64>, grid, dim3(512), lds, st, a);
-  else SRX_LAUNCH_PROF(nm, fl, wino_kernel<32>, grid, dim3(512), lds, st, a);
+  if (p.bn == 64) SRX_LAUNCH_PROF(nm, fl, wino_kernel<64>, grid, dim3(WINO_THREADS), WINO_LDS, st, a);
+  else SRX_LAUNCH_PROF(nm, fl, wino_kernel<32>, grid, dim3(WINO_THREADS), WINO_LDS, st, a);
   SRX_CHECK_LAUNCH("wino_kernel");
   if (p.zsplit > 1) {
     const size_t n4 = a.out_elems / 4;
