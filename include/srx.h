@@ -478,6 +478,12 @@ int srx_wino_fwd_stats(const srx_conv2d_t* d, const float* x, const float* upk, 
 int srx_wino_infer_applicable(const srx_conv2d_t* d);
 int srx_wino_fwd_act(const srx_conv2d_t* d, const float* x, const float* upk, const float* bias, const float* residual, float* y,
                      float* ws, size_t ws_floats, void* stream);
+/* Measurement aid (tools/lab/wino_sweep.cpp: the sweep the planner's cost constants are fitted from; no reference counterpart): until
+ * called again with (0, 0, 0), every Winograd plan of this process is (BN 32 / 64, channel splits of every tile, parts per tile of the
+ * last round) instead of the planner's choice -- srx_wino_ws_floats / srx_wino_plan / the launches all follow it; combinations a
+ * layer cannot run (BN not dividing Cout, more splits than 32-channel chunks, splits of a statistics / inference launch) fall back
+ * to the planner. */
+int srx_wino_force_plan(int bn, int zsplit, int tsplit);
 
 /* ------------------------------------------------- bf16 storage of activations on the training path (round 5) */
 /* Under autocast (esrgan/trainer.py:446,461) the reference's convs read and write half tensors.  These entry points keep the

@@ -28,7 +28,7 @@ sys.path.insert(0, REF)
 
 from oracle import esrgan as OE  # noqa: E402
 from oracle import srgan as O  # noqa: E402
-from oracle.weights import closed_form_state, seeded_input, step_state, tensor_digest  # noqa: E402
+from oracle.weights import closed_form_state, sample_table, seeded_input, step_state, tensor_digest  # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
 os.makedirs(OUT, exist_ok=True)
@@ -317,7 +317,7 @@ def gen_steps():
     logged = []
     t._log_wandb = lambda contents, step=None: logged.append(float(contents['gan/train-loss']))
     orc = _oracle_for(t)
-    gan_losses, gdig, ddig, ref_gen_losses = [], [], [], []
+    gan_losses, gdig, ddig, ref_gen_losses, gsam, dsam = [], [], [], [], [], []
     for step in range(3):
         t._gan_loop(lr_img, hr_img, step)
         dl, cl, al, gl = orc.gan_step(lr_img, hr_img)
@@ -333,8 +333,12 @@ def gen_steps():
         gan_losses.append([dl, cl, al, gl])
         gdig.append(np.stack([tensor_digest(v) for k, v in sorted(t.generator.state_dict().items())]))
         ddig.append(np.stack([tensor_digest(v) for k, v in sorted(t.discriminator.state_dict().items())]))
+        # (round 6) the large tensors element by element: a strided sample of the REFERENCE's post-step values
+        gsam.append(sample_table(t.generator.state_dict()))
+        dsam.append(sample_table(t.discriminator.state_dict()))
         print(f'  gan step {step}: disc {dl:.6f} content {cl:.6f} adv {al:.6f} gen {gl:.6f}')
     out.update(gan_ref_gen_losses=np.array(ref_gen_losses), gan_losses=np.array(gan_losses), gan_g_digest=np.stack(gdig), gan_d_digest=np.stack(ddig),
+               gan_g_sample=np.stack(gsam), gan_d_sample=np.stack(dsam),
                g_keys=np.array(sorted(t.generator.state_dict().keys())),
                d_keys=np.array(sorted(t.discriminator.state_dict().keys())))
     with torch.no_grad():
@@ -346,7 +350,7 @@ def gen_steps():
     # ---- pretrain body (srgan/trainer.py:376-388)
     t = _reference_srgan_trainer(2)
     orc = _oracle_for(t, with_vgg=False)
-    pre_losses, pdig = [], []
+    pre_losses, pdig, psam = [], [], []
     for step in range(3):
         loss = _reference_pretrain_body(t, lr_img, hr_img)
         lo = orc.pretrain_step(lr_img, hr_img)
@@ -354,8 +358,9 @@ def gen_steps():
         check(f'pretrain step{step} conv3.weight', orc.g['conv3.weight'].detach(), t.generator.state_dict()['conv3.weight'], tol=1e-6 if step == 0 else 1e-4)
         pre_losses.append(loss)
         pdig.append(np.stack([tensor_digest(v) for k, v in sorted(t.generator.state_dict().items())]))
+        psam.append(sample_table(t.generator.state_dict()))
         print(f'  pretrain step {step}: mse {loss:.6f}')
-    out.update(pre_losses=np.array(pre_losses), pre_g_digest=np.stack(pdig))
+    out.update(pre_losses=np.array(pre_losses), pre_g_digest=np.stack(pdig), pre_g_sample=np.stack(psam))
 
     # ---- BASELINE config 2 size: batch 16 (inputs are seeded: only losses and digests are stored)
     lr16, hr16 = seeded_input((16, 3, 24, 24), 141), seeded_input((16, 3, 96, 96), 142)
@@ -371,12 +376,14 @@ def gen_steps():
     print(f'  batch-16 gan step: disc {res[0]:.6f} content {res[1]:.6f} adv {res[2]:.6f} gen {res[3]:.6f}')
     out.update(b16_seeds=np.array([141, 142]), b16_gan_losses=np.array(res), b16_gan_ref_gen_loss=np.float64(logged[-1]),
                b16_gan_g_digest=np.stack([tensor_digest(v) for k, v in sorted(t.generator.state_dict().items())]),
-               b16_gan_d_digest=np.stack([tensor_digest(v) for k, v in sorted(t.discriminator.state_dict().items())]))
+               b16_gan_d_digest=np.stack([tensor_digest(v) for k, v in sorted(t.discriminator.state_dict().items())]),
+               b16_gan_g_sample=sample_table(t.generator.state_dict()), b16_gan_d_sample=sample_table(t.discriminator.state_dict()))
     t = _reference_srgan_trainer(16)
     loss = _reference_pretrain_body(t, lr16, hr16)
     print(f'  batch-16 pretrain step: mse {loss:.6f}')
     out.update(b16_pre_loss=np.float64(loss),
-               b16_pre_g_digest=np.stack([tensor_digest(v) for k, v in sorted(t.generator.state_dict().items())]))
+               b16_pre_g_digest=np.stack([tensor_digest(v) for k, v in sorted(t.generator.state_dict().items())]),
+               b16_pre_g_sample=sample_table(t.generator.state_dict()))
     np.savez_compressed(os.path.join(OUT, 'srgan_steps.npz'), **out)
     os.chdir(ROOT)
 
@@ -536,6 +543,9 @@ if __name__ == '__main__':
     install_torchvision_stub()
     if sys.argv[1:] == ['checkpoint']:
         gen_checkpoint()
+        sys.exit(0)
+    if sys.argv[1:] == ['steps']:
+        gen_steps()
         sys.exit(0)
     print('generator'); gen_generator()
     print('discriminator'); gen_discriminator()

@@ -99,3 +99,29 @@ def tensor_digest(t: torch.Tensor):
     idx = torch.arange(1, f.numel() + 1, dtype=torch.float64)
     return np.array([f.sum().item(), f.abs().sum().item(), (f * torch.cos(idx * 0.001)).sum().item(),
                      f[0].item(), f[-1].item()], dtype=np.float64)
+
+
+SAMPLE_MIN_NUMEL = 4096  # tensors at least this large are pinned by a strided SAMPLE of their elements (a digest is a sum: its
+SAMPLE_COUNT = 512       # tolerance would have to grow with the element count and ends up pinning nothing on a 19 M-element tensor)
+
+
+def sample_indices(numel: int) -> torch.Tensor:
+    """The same ``SAMPLE_COUNT`` (or fewer) element indices for the fixture generator and the tests: an even stride over the
+    flattened tensor, offset so that neither the first nor the last element is special."""
+    stride = max(1, numel // SAMPLE_COUNT)
+    return torch.arange(stride // 2, numel, stride)[:SAMPLE_COUNT]
+
+
+def sample_keys(sd) -> list:
+    """Sorted keys of the floating-point entries of a state dict that are pinned by samples."""
+    return [k for k, v in sorted(sd.items()) if v.is_floating_point() and v.numel() >= SAMPLE_MIN_NUMEL]
+
+
+def sample_table(sd) -> np.ndarray:
+    """[len(sample_keys(sd))][SAMPLE_COUNT] float32: the sampled elements of every large tensor of a state dict."""
+    rows = []
+    for k in sample_keys(sd):
+        f = sd[k].detach().float().cpu().flatten()
+        row = f[sample_indices(f.numel())]
+        rows.append(torch.nn.functional.pad(row, (0, SAMPLE_COUNT - row.numel())).numpy())
+    return np.stack(rows).astype(np.float32)

@@ -270,6 +270,10 @@ def _bf16_within_yardstick(got_sd, fp32sum_sd, exact_sd, name, skip=()):
         # (which elements sit at the noise floor is a draw: the count of flipped ones scatters like a Poisson variable, three
         # standard deviations of the yardstick's own count are allowed on top -- it matters for the 32..512-entry vectors only)
         assert bad_p <= 1.5 * bad_a + 3.0 * max(bad_a, 1) ** 0.5 + 2, (name, k, bad_p, bad_a, dp.numel())
+        # ... and an ABSOLUTE ceiling on top of the relative yardstick (round-5 advice): should the oracle's own fp32-sum evaluation
+        # ever drift or get noisy, the product's allowance must not grow with it -- round 4's hand-set value, 8 % of a tensor
+        # (+ the same small-vector slack), stays as the cap
+        assert bad_p <= 0.08 * dp.numel() + 3.0 * max(0.08 * dp.numel(), 1.0) ** 0.5 + 2, (name, k, bad_p, dp.numel())
         assert dp.max().item() <= 2.1e-4, (name, k, dp.max().item())
 
 
@@ -294,10 +298,21 @@ def test_esrgan_config4_bf16_launch_geometry(dev):
     got16 = [l16[k].item() for k in LOSS_KEYS]
     for got in (got4, got16):
         for g, w, wa in zip(got, want_e, want_a):
-            # 2e-3 of the exact-sum loss, or 1.5 x the oracle's own fp32-sum distance where that is larger
-            assert abs(g - w) <= max(2e-3 * max(abs(w), 1e-3), 1.5 * abs(wa - w)), (got, want_e, want_a)
+            # 2e-3 of the exact-sum loss, or 1.5 x the oracle's own fp32-sum distance where that is larger -- but never more than
+            # 5e-3 (round 4's ceiling: the relative yardstick may not grow without bound with the oracle's own noise)
+            tol = min(max(2e-3 * max(abs(w), 1e-3), 1.5 * abs(wa - w)), 5e-3 * max(abs(w), 1e-3))
+            assert abs(g - w) <= tol, (got, want_e, want_a)
     for a, b in zip(got16, got4):  # the same recipe on two launch shapes
         assert abs(a - b) <= 1e-3 * max(abs(b), 1e-3), (got16, got4)
+    # ... and element by element: the batch-16 step of the four crops x 4 and the batch-4 step are the same arithmetic on two
+    # launch shapes, so their parameters after the step may differ by one Adam step (an element at the noise floor going the
+    # other way) and nowhere by more -- a bug that depends on the launch shape cannot hide inside the oracle's noise
+    for net4, net16 in ((t4.generator, t16.generator), (t4.discriminator, t16.discriminator)):
+        sd4 = net4.state_dict()
+        for k, v in net16.state_dict().items():
+            if v.is_floating_point() and 'running_' not in k:
+                dev_ = (v - sd4[k]).abs().max().item()
+                assert dev_ <= 2.1e-4, (k, dev_)
     _bf16_within_yardstick(t4.generator.state_dict(), orc_a.g, orc_e.g, 'G bf16 b4')
     _bf16_within_yardstick(t4.discriminator.state_dict(), orc_a.d, orc_e.d, 'D bf16 b4', skip=('classifier.2.bias',))
     _bf16_within_yardstick(t16.generator.state_dict(), orc_a.g, orc_e.g, 'G bf16 b16')

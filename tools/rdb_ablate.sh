@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 for a in 0 1 2 3; do
   echo "== SRX_RDB_ABLATE=$a"
-  SRX_RDB_ABLATE=$a python3 $R/tools/bench_rdb.py 2>&1 | grep -v amdgpu.ids
+  SRX_ALLOW_GARBAGE_RESULTS=1 SRX_RDB_ABLATE=$a python3 $R/tools/bench_rdb.py 2>&1 | grep -v amdgpu.ids
 done
 i=0
 for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_LDS" \

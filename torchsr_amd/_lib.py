@@ -257,6 +257,7 @@ _SIGS = {
     'srx_act_bwd_from_out_to_bf16': (_I, [_P, _P, _P, C.c_int64, _I, C.c_float, _P]),
     'srx_wino_infer_applicable': (_I, [_D]),
     'srx_wino_fwd_act': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    'srx_wino_force_plan': (_I, [_I, _I, _I]),
     'srx_wino_stat_rows': (_I, [_D]),
     'srx_wino_fwd_stats': (_I, [_D, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'srx_gan_head_fwd': (_I, [C.POINTER(GanHead), _P, _P, _P, _P, _P, _P, _P, _P, _P]),

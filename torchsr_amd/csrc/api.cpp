@@ -56,6 +56,19 @@ static SrxDevSwitches read_switches() {
   s.wino_no_tail = flag("SRX_WINO_NO_TAIL");
   s.wino_zsplit = num("SRX_WINO_ZSPLIT");
   s.wino_bn = num("SRX_WINO_BN");
+  // Result-CHANGING switches (the ablation instantiations compute garbage by design: they exist to time a kernel without one of
+  // its parts) need a second, explicit opt-in and say so once on stderr -- a stray variable must not silently corrupt a run
+  if (s.rdb_ablate != 0 || s.c64_ablate != 0) {
+    const char* ok = getenv("SRX_ALLOW_GARBAGE_RESULTS");
+    if (ok && ok[0] == '1') {
+      fprintf(stderr, "libsrx_hip: SRX_RDB_ABLATE=%d SRX_C64_ABLATE=%d with SRX_ALLOW_GARBAGE_RESULTS=1: the fused dense-block / bf16 trunk "
+                      "kernels of this process compute GARBAGE (timing ablations)\n", s.rdb_ablate, s.c64_ablate);
+    } else {
+      fprintf(stderr, "libsrx_hip: SRX_RDB_ABLATE / SRX_C64_ABLATE ignored: ablation kernels compute garbage and need "
+                      "SRX_ALLOW_GARBAGE_RESULTS=1 as well\n");
+      s.rdb_ablate = 0; s.c64_ablate = 0;
+    }
+  }
   if (const char* f = getenv("SRX_FORCE_PLAN")) {
     int v[4] = {0, 0, 1, 1};
     if (sscanf(f, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) { s.force_plan = true; for (int i = 0; i < 4; ++i) s.plan[i] = v[i]; }

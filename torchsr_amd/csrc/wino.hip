@@ -42,7 +42,9 @@
 // from a cost model.  Inference adds LeakyReLU / PReLU, a skip addend and nn.PixelShuffle(2) in the store (srx_wino_fwd_act).
 #include "srx_common.h"
 #include <algorithm>
+#include <atomic>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_kernel(const WinoArgs a)
     tb = tile % a.tblocks; cb = tile / a.tblocks;
   }
   // this split's stages of 16 input channels: [kc0, kc1) -- whole 32-channel chunks of the packed U
-  const int kc0 = 2 * srx_uniform((int)((long long)z * a.nch / zs)), kc1 = 2 * srx_uniform((int)((long long)(z + 1) * a.nch / zs));
+  const int kc0 = 2 * srx_uniform(z * a.nch / zs), kc1 = 2 * srx_uniform((z + 1) * a.nch / zs);  // (nch <= 2^15 / 32, zs <= 16)
   const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, a.in_bytes);
   const __amdgpu_buffer_rsrc_t ru = srx_rsrc(a.upk, a.upk_bytes);
 
@@ -142,18 +144,24 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_kernel(const WinoArgs a)
   wino_tile_coords(a, t, tn, th, tw);
   u32x4* spoff = reinterpret_cast<u32x4*>(smem + RING_BYTES);  // [4][256]
   {
+    // byte offset of patch pixel (i, j) = base + i * (W Cin 4) + j * (Cin 4): per-lane adds of uniform steps, no per-lane multiplies;
+    // a padding pixel (or a tile past the end) gets an out-of-range offset, which reads 0
     const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
-    const int base = ((tn * a.H + ih0) * a.W + iw0) * a.Cin + 2 * pr;  // element offset of patch pixel (0, 0) (may be "negative": never used then)
+    const unsigned base = 4u * (unsigned)(((tn * a.H + ih0) * a.W + iw0) * a.Cin + 2 * pr);  // (may wrap for padding pixels: never used then)
+    const unsigned cstep = 4u * (unsigned)a.Cin, rstep = cstep * (unsigned)a.W;
+    bool cok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cok[j] = (unsigned)(iw0 + j) < (unsigned)a.W;
+    unsigned rowb = base;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool rok = tvalid && (unsigned)(ih0 + i) < (unsigned)a.H;
       u32x4 o;
+      unsigned v = rowb;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool ok = rok && (unsigned)(iw0 + j) < (unsigned)a.W;
-        o[j] = ok ? 4u * (unsigned)(base + (i * a.W + j) * a.Cin) : 0xffffffffu;  // out of range reads 0
-      }
+      for (int j = 0; j < 4; ++j) { o[j] = (rok && cok[j]) ? v : 0xffffffffu; v += cstep; }
       spoff[i * WINO_THREADS + tid] = o;  // (read back by this thread only: no barrier)
+      rowb += rstep;
     }
   }
   // ---- multiplier state: this wave's four xi; packed U, float4 index (((xi * (Cout / 32) + jg) * nch + kc32) * 4 + s4) * 64 + lane:
@@ -167,13 +175,7 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_kernel(const WinoArgs a)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) ubase[x][j] = (unsigned)srx_uniform((((xi0 + x) * cot + cb * NJ + j) * a.nch) * 4096);
 
-  f32x16 acc[4][NJ];
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[x][j][r] = 0.f;
+  f32x16 acc[4][NJ];  // (never zero-filled -- 128 moves that the matrix pipe would wait for: the first MFMAs take C = 0)
 
   f32x2 pd[16];        // the patch of the stage being gathered
   f32x2 uf[2][4][NJ];  // U fragments, two slots: (phase & 1); a phase = two of the four k-pairs of a sub-step = 8 NJ MFMAs
@@ -222,15 +224,22 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_kernel(const WinoArgs a)
 #pragma unroll
     for (int x = 0; x < 4; ++x) vf[x] = *reinterpret_cast<const f32x4*>(sv + (xi0 + x) * (WT * VKC));
   };
-  auto mma = [&](int ph) {
+  auto mma = [&](int ph, auto first) {
+    constexpr f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[x][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[ph & 1][x][j][e], vf[x][2 * (ph & 1) + e], acc[x][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) {
+          if (decltype(first)::value && e == 0)
+            acc[x][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[ph & 1][x][j][e], vf[x][2 * (ph & 1) + e], zero, 0, 0, 0);
+          else
+            acc[x][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[ph & 1][x][j][e], vf[x][2 * (ph & 1) + e], acc[x][j], 0, 0, 0);
+        }
   };
+  constexpr std::false_type later{};
+  constexpr std::true_type very_first{};
 
   // ---- prologue: first stage gathered, its first U fragments requested
   load_patch(kc0);
@@ -238,15 +247,17 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_kernel(const WinoArgs a)
   load_u(kc0, 1);
   stage_patch(0);
   __syncthreads();
-  // ---- stage loop (the last stage peeled: it requests nothing beyond itself, so every vmcnt of the steady state is exact)
+  // ---- stage loop.  The first stage is peeled (its first MFMAs start the accumulators) and so is the last (it requests nothing
+  // beyond itself, so every vmcnt of the steady state is exact); a split covers whole 32-channel chunks: at least two stages
   int st = 0;
-  for (int kc = kc0; kc + 1 < kc1; ++kc) {
-    // first half: the next stage's patch requests and this stage's later U fragments ride between the MFMAs of phases 0, 1
+  // first half of a stage: the next stage's patch requests and this stage's later U fragments ride between the MFMAs of phases 0, 1;
+  // second half: the patch transform and the next stage's first U fragments between the MFMAs of phases 2, 3
+  auto stage = [&](int kc, auto first) {
     load_patch(kc + 1);
     read_v(st, 0);
-    mma(0);
+    mma(0, first);
     load_u(kc, 2);
-    mma(1);
+    mma(1, later);
     load_u(kc, 3);
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
@@ -255,34 +266,43 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_kernel(const WinoArgs a)
       __builtin_amdgcn_sched_group_barrier(0x020, NJ == 2 ? 1 : 2, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // second half: the patch transform and the next stage's first U fragments between the MFMAs of phases 2, 3
     read_v(st, 1);  // (before the transform's LDS stores in program order: the compiler cannot tell the two stages apart)
     stage_patch(st ^ 1);
-    mma(2);
+    mma(2, later);
     load_u(kc + 1, 0);
-    mma(3);
+    mma(3, later);
     load_u(kc + 1, 1);
     __syncthreads();
     st ^= 1;
-  }
+  };
+  stage(kc0, very_first);
+  for (int kc = kc0 + 1; kc + 1 < kc1; ++kc) stage(kc, later);
   {
     const int kc = kc1 - 1;
     read_v(st, 0);
-    mma(0);
+    mma(0, later);
     load_u(kc, 2);
-    mma(1);
+    mma(1, later);
     load_u(kc, 3);
     read_v(st, 1);
-    mma(2);
-    mma(3);
+    mma(2, later);
+    mma(3, later);
     __syncthreads();
   }
 
   // ---- epilogue, one 32-channel tile j at a time: M[xi][tile][32 channels] through LDS (16-byte chunk c of row (xi, t) at chunk
-  // c ^ (t & 7)), then A^T M A per (tile, channel quad)
+  // c ^ (t & 7)), then A^T M A per (tile, channel quad).  Addresses: ONE per-lane byte offset, relative to the first pixel row the
+  // tile block touches; everything else (channel tile, the four pixels of the 2x2 tile, the sub-pixel of a PixelShuffle store) is
+  // uniform and travels in the buffer descriptor's base or the scalar offset of the access
   float* sM = reinterpret_cast<float*>(smem);
   const int cq = pr;
-  const bool store_ok = tvalid;
+  int n0, th0, tw0;
+  wino_tile_coords(a, srx_uniform(tb * WT), n0, th0, tw0);
+  const int row0 = srx_uniform(n0 * a.H + 2 * th0);              // first pixel row of the block (tiles are ordered by (image, row, column))
+  const int rowrel = (tn * a.H + 2 * th) - row0;                 // >= 0 for every tile of the block
+  const int oW = a.shuffle ? 2 * a.W : a.W, oC = a.shuffle ? a.shuffle : a.Cout, ps = a.shuffle ? 2 : 1;  // output row length, channels, pixel step
+  const unsigned voff = 4u * (unsigned)(((ps * rowrel) * oW + 2 * ps * tw) * oC + 4 * cq);
+  const unsigned pstep[4] = {0u, 4u * (unsigned)(ps * oC), 4u * (unsigned)(ps * oW * oC), 4u * (unsigned)(ps * oW * oC + ps * oC)};
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     if (j > 0) __syncthreads();
@@ -310,50 +330,50 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_kernel(const WinoArgs a)
     y[1] = pk_sub4(pk_sub4(s0[1], s0[2]), s0[3]);
     y[2] = pk_add4(pk_add4(s1[0], s1[1]), s1[2]);
     y[3] = pk_sub4(pk_sub4(s1[1], s1[2]), s1[3]);
-    const int co = cb * BN + 32 * j + 4 * cq;
+    const int cu = srx_uniform(cb * BN + 32 * j);  // first channel (GEMM column) of this pass
     if (tailw) {  // a part of a tail tile: raw partial output, tile-local layout; finished by wino_tail_fixup_kernel
-      if (store_ok) {
+      if (tvalid) {
         float* o = a.tpart + (size_t)((int)blockIdx.x - a.full) * (WT * 4 * BN) + (size_t)(tl * 4) * BN + 32 * j + 4 * cq;
 #pragma unroll
         for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(o + p * BN) = y[p];
       }
       continue;
     }
-    const size_t p00 = (((size_t)tn * a.H + 2 * th) * a.W + 2 * tw) * a.Cout + co;
-    size_t offs[4] = {p00, p00 + a.Cout, p00 + (size_t)a.W * a.Cout, p00 + (size_t)a.W * a.Cout + a.Cout};
-    if (a.shuffle) {  // GEMM column co = (sub-pixel ij, channel cc): pixel (y, x) of the conv lands at (2y + ij / 2, 2x + ij % 2), channel cc
-      const int ij = co / a.shuffle, cc = co - ij * a.shuffle;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const size_t oy = 2 * (size_t)(2 * th + (p >> 1)) + (ij >> 1), ox = 2 * (size_t)(2 * tw + (p & 1)) + (ij & 1);
-        offs[p] = (((size_t)tn * 2 * a.H + oy) * (2 * (size_t)a.W) + ox) * a.shuffle + cc;
-      }
-    }
+    // element offset of (first pixel row of the block, pixel column 0, this pass's first channel) in an output-shaped tensor; with a
+    // PixelShuffle store GEMM column c = (sub-pixel ij, channel cc) and a 32-column pass lies inside one sub-pixel (Cout / 4 is a
+    // multiple of 32): conv pixel (y, x) lands at (2y + ij / 2, 2x + ij % 2), channel cc
+    const int ij = a.shuffle ? cu / a.shuffle : 0;
+    const size_t ebase = a.shuffle ? ((size_t)(2 * row0 + (ij >> 1)) * oW + (ij & 1)) * oC + (cu - ij * a.shuffle)
+                                   : (size_t)row0 * oW * oC + cu;
+    const unsigned span = (unsigned)std::min<size_t>((a.out_elems - ebase) * sizeof(float), 0xffffffffu);
     if (a.part) {  // one of several splits of the input channels: the raw partial output; bias / activation in the fix-up pass
-      if (store_ok) {
-        float* o = a.part + (size_t)z * a.out_elems;
+      const __amdgpu_buffer_rsrc_t ro = srx_rsrc(a.part + (size_t)z * a.out_elems + ebase, span);
+      if (tvalid) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(o + offs[p]) = y[p];
+        for (int p = 0; p < 4; ++p) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[p]), ro, (int)voff, (int)pstep[p], 0);
       }
       continue;
     }
+    const __amdgpu_buffer_rsrc_t ro = srx_rsrc(a.out + ebase, span);
     f32x4 mk[4], ad[4];
-    if (a.mask && store_ok) {  // (all loads before the first store)
+    if (a.mask) {  // (all loads before the first store; an invalid tile's loads are harmless: its offset is in range or reads 0)
+      const __amdgpu_buffer_rsrc_t rm = srx_rsrc(a.mask + ebase, span);
 #pragma unroll
-      for (int p = 0; p < 4; ++p) mk[p] = *reinterpret_cast<const f32x4*>(a.mask + offs[p]);
+      for (int p = 0; p < 4; ++p) mk[p] = srx_bload(rm, voff, pstep[p]);
     }
-    if (a.add && store_ok) {
+    if (a.add) {
+      const __amdgpu_buffer_rsrc_t ra = srx_rsrc(a.add + ebase, span);
 #pragma unroll
-      for (int p = 0; p < 4; ++p) ad[p] = *reinterpret_cast<const f32x4*>(a.add + offs[p]);
+      for (int p = 0; p < 4; ++p) ad[p] = srx_bload(ra, voff, pstep[p]);
     }
     if (a.bias) {
       f32x4 bv;
-      if (a.shuffle) {  // (the bias is in the conv's own channel order)
-        const int ij = co / a.shuffle, cc = co - ij * a.shuffle;
+      if (a.shuffle) {  // (the bias is in the conv's own channel order: channel cc * 4 + ij)
+        const int cc = cu - ij * a.shuffle + 4 * cq;
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[e] = a.bias[(cc + e) * 4 + ij];
       } else {
-        bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+        bv = *reinterpret_cast<const f32x4*>(a.bias + cu + 4 * cq);
       }
 #pragma unroll
       for (int p = 0; p < 4; ++p) y[p] = pk_add4(y[p], bv);
@@ -362,7 +382,7 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_kernel(const WinoArgs a)
       // per-channel sum / sum of squares of this tile block's 128 pixels (what gconv's epilogue writes per row tile): the lanes
       // of a wave that share a channel quad first (fixed butterfly over the 8 tiles of the wave), then the four waves in order
       f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-      if (store_ok) {
+      if (tvalid) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) { s1 += y[p]; s2 += y[p] * y[p]; }
       }
@@ -373,20 +393,31 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_kernel(const WinoArgs a)
       f32x4* red = reinterpret_cast<f32x4*>(smem + RING_BYTES) + j * 64;  // [4 waves][8 quads][2] per channel tile
       if (lane < 8) { red[(wave * 8 + lane) * 2 + 0] = s1; red[(wave * 8 + lane) * 2 + 1] = s2; }
     }
-    if (store_ok) {
+    // the activation forms are uniform branches (not per-element selects: every VALU instruction here is matrix time lost)
+    if (a.relu) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = y[p][e];
-          if (a.relu) v = fmaxf(v, 0.f);
-          if (a.lrelu) v = v > 0.f ? v : v * a.slope;
-          if (a.mask) v = mk[p][e] > 0.f ? v : 0.f;
-          if (a.add) v += ad[p][e];
-          y[p][e] = v;
-        }
-        *reinterpret_cast<f32x4*>(a.out + offs[p]) = y[p];
-      }
+        for (int e = 0; e < 4; ++e) y[p][e] = fmaxf(y[p][e], 0.f);
+    } else if (a.lrelu) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[p][e] = y[p][e] > 0.f ? y[p][e] : y[p][e] * a.slope;
+    }
+    if (a.mask) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[p][e] = mk[p][e] > 0.f ? y[p][e] : 0.f;
+    }
+    if (a.add) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) y[p] = pk_add4(y[p], ad[p]);
+    }
+    if (tvalid) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[p]), ro, (int)voff, (int)pstep[p], 0);
     }
   }
   if (a.stats && !tailw && !a.part) {  // (workgroup-uniform) the waves' partial sums, in order
@@ -522,7 +553,8 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
   srx_wino_pack_one(w, upk, Cout, Cin, transpose, idx);
 }
 
-struct WinoPlan { int bn, zsplit; float cost; int tsplit; };  // tsplit > 1: the tiles of the last round are cut that many ways (zsplit = 1)
+struct WinoPlan { int bn, zsplit; float cost; int tsplit; };
+std::atomic<int> g_force[3] = {{0}, {0}, {0}};  // srx_wino_force_plan  // tsplit > 1: the tiles of the last round are cut that many ways (zsplit = 1)
 
 // rounds of the chip x (chunks per workgroup x time per chunk + fixed cost), plus the fix-up pass of a split
 WinoPlan wino_plan(int T, int Cin, int Cout, bool no_split = false, bool no_tail = false) {
@@ -553,8 +585,15 @@ WinoPlan wino_plan(int T, int Cin, int Cout, bool no_split = false, bool no_tail
     }
   }
   if (const int v = srx_dev().wino_zsplit; v > 0 && v <= nch && !no_split) { best.zsplit = v; best.tsplit = 1; }
-  (void)no_tail;
   if (const int v = srx_dev().wino_bn; (v == 32 || v == 64) && Cout % v == 0) best.bn = v;
+  // srx_wino_force_plan (measurement aid): the forced plan where this launch can run it
+  if (const int fb = g_force[0].load(std::memory_order_relaxed); fb != 0) {
+    const int fz = g_force[1].load(std::memory_order_relaxed), ft = g_force[2].load(std::memory_order_relaxed);
+    const int64_t wgs = (int64_t)tblocks * (Cout / (Cout % fb ? 32 : fb));
+    if (Cout % fb == 0 && fz >= 1 && fz <= nch && (fz == 1 || !no_split) &&
+        (ft == 1 || (fz == 1 && !no_tail && ft <= nch && wgs > P && wgs % P != 0 && (wgs % P) * ft <= 2 * P)))
+      best = WinoPlan{fb, fz, 0.f, ft};
+  }
   return best;
 }
 
@@ -577,6 +616,13 @@ extern "C" int srx_wino_applicable(const srx_conv2d_t* d) {
   // BatchNorm-statistics epilogue needs): the direct kernel's K-split plans serve those better
   const double direct_us = 2.0 * d->N * d->H * d->W * (double)d->Cout * 9.0 * d->Cin / 110.0e6 + 5.0;
   return wino_plan(d->N * (d->H / 2) * (d->W / 2), d->Cin, d->Cout, true).cost < direct_us ? 1 : 0;
+}
+
+extern "C" int srx_wino_force_plan(int bn, int zsplit, int tsplit) {
+  SRX_REQUIRE((bn == 0 && zsplit == 0 && tsplit == 0) || ((bn == 32 || bn == 64) && zsplit >= 1 && zsplit <= 16 && tsplit >= 1 && tsplit <= 8),
+              "wino_force_plan: (0, 0, 0) or BN 32 / 64, 1..16 splits, 1..8 tail parts");
+  g_force[1].store(zsplit); g_force[2].store(tsplit); g_force[0].store(bn);
+  return SRX_OK;
 }
 
 extern "C" size_t srx_wino_packed_floats(const srx_conv2d_t* d) {

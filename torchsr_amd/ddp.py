@@ -108,6 +108,12 @@ class GradBuckets:
         self.slices = [flat.grad[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
         self._work = []
         self.issued = 0  # collectives handed to the process group so far
+        # measurement aid (bench.py --gpus N): with `timing` on, every bucket gets three HIP events on the compute stream -- at its
+        # launch(), in front of its wait() and behind it -- so that a first real N > 1 run says by itself how long each bucket had
+        # to hide (launch -> wait) and how long the compute stream stood still for it (the exposed part)
+        self.timing = False
+        self._marks = []
+        self._launched = []
 
     def __len__(self) -> int:
         return len(self.slices)
@@ -129,18 +135,54 @@ class GradBuckets:
                 set_reserved_cus(max(self.reserve_cus, self._base_reserved))
                 if self.window_hook is not None:
                     self.window_hook.begin()
+            ev = None
+            if self.timing:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+            self._launched.append((int(s.numel()) * 4, ev))
             self._work.append(dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.issued += 1
 
     def wait(self) -> None:
-        for w in self._work:
-            w.wait()  # stream-orders the compute stream after the collective (no host block on RCCL)
-        self._work = []
+        for w, (nbytes, ev0) in zip(self._work, self._launched):
+            if ev0 is not None:
+                ev1, ev2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev1.record()
+                w.wait()  # stream-orders the compute stream after the collective (no host block on RCCL)
+                ev2.record()
+                self._marks.append((nbytes, ev0, ev1, ev2))
+            else:
+                w.wait()
+        self._work, self._launched = [], []
+        self._close_window()
+
+    def _close_window(self) -> None:
         if self._window:
             self._window = False
             if self.window_hook is not None:
                 self.window_hook.end()
             set_reserved_cus(self._base_reserved)
+
+    def abort(self) -> None:
+        """A step raised between ``launch()`` and ``wait()``: drop the pending work handles and give the reserved compute units
+        (and the rehearsal hook's holder) back, so that no later plan or captured graph is cut for a chip with fewer CUs."""
+        for w in self._work:
+            try:
+                w.wait()
+            except Exception:  # noqa: BLE001  (the collective itself may be what failed)
+                pass
+        self._work, self._launched = [], []
+        self._close_window()
+
+    def timings(self, reset: bool = True) -> list:
+        """Per bucket launch since the last call (``timing`` on): bytes, device ms from its launch() to the front of its wait()
+        (the compute it had to hide under) and device ms the compute stream stood in that wait() (the exposed part)."""
+        torch.cuda.synchronize()
+        out = [{'bytes': nb, 'launch_to_wait_ms': round(e0.elapsed_time(e1), 4), 'exposed_wait_ms': round(e1.elapsed_time(e2), 4)}
+               for nb, e0, e1, e2 in self._marks]
+        if reset:
+            self._marks = []
+        return out
 
 
 def reserved_cus() -> int:

@@ -400,6 +400,13 @@ def wino_layer_ok(st: ConvState, d: Conv2dDesc) -> bool:
     return (not _dev.NO_WINO and st.act in (ACT_NONE, ACT_RELU) and _lib.lib().srx_wino_applicable(C.byref(d)) == 1)
 
 
+def wino_forward_runs(st: ConvState, d: Conv2dDesc, want_stats: bool) -> bool:
+    """THE decision whether this forward call runs on the Winograd kernel -- shared by ``_Conv2d.forward`` and
+    ``conv_stat_tile_rows`` so that the row granularity of a partial-statistics table is always the one of the kernel that
+    writes it: the statistics epilogue exists for linear layers only (``srx_wino_fwd_stats``)."""
+    return wino_layer_ok(st, d) and (not want_stats or st.act == ACT_NONE)
+
+
 class PackTable:
     """Every conv of a model repacked by ONE launch after an optimiser step (``srx_pack_table_*``).
 
@@ -523,7 +530,7 @@ class _Conv2d(Function):
         # wide 3x3 layers: Winograd F(2x2, 3x3), 2.25x fewer fp32 multiplications (csrc/wino.hip) -- the VGG19 features called
         # layer by layer, the discriminators' stride-1 layers (with the BatchNorm partial statistics in the epilogue)
         fwd_only = not want_stats and wino_forward_only_ok(st, d)
-        ctx.wino = fwd_only or (wino_layer_ok(st, d) and (not want_stats or st.act == ACT_NONE))
+        ctx.wino = fwd_only or wino_forward_runs(st, d, want_stats)
         part = None
         if ctx.wino:
             # (trainable layers: PackTable refreshes the Winograd-domain weights inside the captured step)
@@ -724,7 +731,7 @@ def bn_groups_ok(m: int, tile_rows: Optional[int], groups: int) -> bool:
 def conv_stat_tile_rows(st: ConvState, n: int, h: int, w: int) -> int:
     """Output rows (pixels) summarised by one row of the partial-statistics table ``conv2d(..., want_stats=True)``
     returns for this layer at this input size: the tile height of the launch plan."""
-    if wino_layer_ok(st, st.desc(n, h, w)):
+    if wino_forward_runs(st, st.desc(n, h, w), True):
         return 128  # a Winograd tile block: 32 consecutive 2x2 tiles (image-major)
     out = (C.c_int * 6)()
     call('srx_conv2d_plan', C.byref(st.desc(n, h, w)), 0, out)

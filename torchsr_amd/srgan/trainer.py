@@ -447,6 +447,9 @@ class SRGANTrainer:
                 self.gen_sync.launch(0)
                 self.gen_sync.wait()
                 self._exec('psnr.opt', lambda: (self.psnr_optimizer.step(), self._push_loss('psnr/train-loss')))
+            except BaseException:
+                self.gen_sync.abort()  # a bucket may be on the wire with compute units reserved for it: give them back
+                raise
             finally:
                 F.cut_hook[0] = None
                 self._cuts.clear()
@@ -565,6 +568,12 @@ class SRGANTrainer:
                 self.gen_sync.launch(0)
                 self.gen_sync.wait()
                 self._exec('gan.gopt', lambda: (self.gen_optimizer.step(), self._push_loss('gan/train-loss')))
+            except BaseException:
+                # (OOM, an error in user code inside a segment) buckets may be on the wire and compute units reserved for
+                # RCCL's channels: without this every later plan and captured graph would be cut for a smaller chip
+                self.disc_sync.abort()
+                self.gen_sync.abort()
+                raise
             finally:
                 F.cut_hook[0] = None
                 self._cuts.clear()  # a segment that raised between a cut and its resume must not leak into the next step
