@@ -724,9 +724,11 @@ def main():
     # spread of the step time (outside the timed region): per-step HIP events on the step's stream
     spread = None
     dp = None
-    if forced:
-        # the same step as ONE hipGraph without cuts, buckets or collectives, same process, same GPU: what the
-        # segmentation itself costs on one GPU (the ceiling on multi-GPU efficiency before any wire time)
+    if distributed:
+        # the same step as ONE hipGraph without cuts, buckets or collectives, same process, same GPU: at world size 1 what the
+        # segmentation itself costs (the ceiling on multi-GPU efficiency before any wire time); at N > 1 the difference to the
+        # timed data-parallel step is everything the exchange costs this rank -- segmentation, CUs lent to RCCL's channels and
+        # the time the compute stream stands in a bucket's wait() -- so a first real N > 1 run diagnoses itself
         torch.manual_seed(0)
         fargs = Namespace(**{**vars(targs), 'rank': -1, 'force_collectives': False})
         fused = SRGANTrainer(device, fargs, [], [], BATCH, BATCH, distributed=False)
@@ -741,7 +743,29 @@ def main():
         torch.cuda.synchronize()
         fused_ms = (time.perf_counter() - t1) / args.steps * 1e3
         seg_ms = elapsed / args.steps * 1e3
+        del fused
+        torch.cuda.empty_cache()
+        # per bucket, a few extra steps with HIP events at launch() / in front of wait() / behind it (outside the timed region)
+        for sync in (trainer.gen_sync, trainer.disc_sync):
+            sync.timing = True
+        for _ in range(8):
+            trainer.gan_step(lr, hr)
+        buckets = {}
+        for name, sync in (('generator', trainer.gen_sync), ('discriminator', trainer.disc_sync)):
+            sync.timing = False
+            marks = sync.timings()
+            by_size = {}
+            for m in marks:
+                by_size.setdefault(m['bytes'], []).append(m)
+            med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+            buckets[name] = [{'bytes': nb, 'launches_timed': len(ms), 'launch_to_wait_ms': round(med([m['launch_to_wait_ms'] for m in ms]), 4),
+                              'exposed_wait_ms': round(med([m['exposed_wait_ms'] for m in ms]), 4)} for nb, ms in sorted(by_size.items())]
+        exposed = sum(b['exposed_wait_ms'] for bs in buckets.values() for b in bs)
         dp = {'process_group': describe_group(), 'collectives_issued_per_step': 4,
+              'exposed_comm_ms': round(seg_ms - fused_ms, 3),
+              'exposed_comm_what': 'data-parallel step minus the single-graph step without collectives, same process and GPU (max over ranks '
+                                   'for the former at N > 1): segmentation + CUs lent to the channels + waits',
+              'bucket_timings': buckets, 'sum_of_exposed_waits_ms': round(exposed, 4),
               'collectives_issued_total': trainer.gen_sync.issued + trainer.disc_sync.issued,
               'grad_buckets': {'generator': len(trainer.gen_sync), 'discriminator': len(trainer.disc_sync)},
               'bucket_bytes': {'generator': [int(x.numel()) * 4 for x in trainer.gen_sync.slices],
@@ -752,8 +776,10 @@ def main():
               'comm_windows_opened': getattr(targs.comm_window_hook, 'windows', None),
               'segmented_ms_per_step': round(seg_ms, 3), 'fused_ms_per_step': round(fused_ms, 3),
               'segmentation_overhead': round(seg_ms / fused_ms - 1.0, 4), 'steps': args.steps,
-              'what': 'SRGAN GAN step, batch 16, world size 1 on RCCL: 7 hipGraph segments + 4 async all-reduces '
-                      '(no-op sums) vs the single-graph step; unmeasured at N > 1'}
+              'what': ('SRGAN GAN step, batch 16, world size 1 on RCCL: 7 hipGraph segments + 4 async all-reduces '
+                       '(no-op sums) vs the single-graph step; unmeasured at N > 1') if world == 1 else
+                      f'SRGAN GAN step, batch 16 per GPU, world size {world}: the timed data-parallel step vs the single-graph step '
+                      'without collectives on this rank'}
     if rank == 0 and single:
         evs = []
         for _ in range(min(args.steps, 50)):
