@@ -1072,6 +1072,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WMulti mp) {
 // and the only wait in the loop is a counted vmcnt that leaves the newest chunk's four requests in flight.
 // Same work decomposition, slab layout and bias rows as wgrad_kernel<0>: the reduction kernel is shared.
 // ---------------------------------------------------------------------------
+// WIDE (round 6): on gfx950 the f32 MFMA runs on the vector ALUs -- every VALU instruction of the gather's bookkeeping is matrix time
+// lost (tools/probe/mfma_valu.hip) -- and the row state (pixel coordinates, two element offsets, three wrap tests: ~25 instructions)
+// was advanced for TWO rows per thread and chunk.  When a tap's channels come in multiples of 64 (every layer of the SRGAN step that
+// runs here) a thread owns ONE row of the chunk and both 32-float halves of it (same tap, same validity: the second request is the
+// first + 32 elements), and the chunk image in LDS is [half][32 rows][32 floats] -- still lane-linear for the DMA, and a wave's MFMA
+// operand is exactly one half.  Half the bookkeeping per MFMA.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WMulti mp) {
   const WArgs& a = mp.a;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -1089,7 +1096,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WMulti mp) {
   const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
   const int ntile = srx_uniform(tile_id / a.ktiles), kt = srx_uniform(tile_id - ntile * a.ktiles);
   const int k0 = kt * 64, n0 = ntile * 64;
-  const int q = tid & 15, r0 = tid >> 4;
+  constexpr int NP = WIDE ? 1 : 2;                  // row states per thread
+  const int q = WIDE ? (tid & 7) : (tid & 15), r0 = WIDE ? (tid >> 3) : (tid >> 4);
   auto make_rsrc = [](const void* p, unsigned bytes) {
     const unsigned long long v = (unsigned long long)p;
     u32x4 r;
@@ -1101,9 +1109,9 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WMulti mp) {
   };
   const u32x4 rx_ = make_rsrc(mp.x[prob], a.in_bytes), rd_ = make_rsrc(mp.dy[prob], a.dy_bytes);
 
-  // this thread's fixed k (A gather) and fixed dy column
+  // this thread's fixed k (A gather) and fixed dy column (WIDE: of the first half; the second half is 32 further, same tap)
   const int k = k0 + 4 * q;
-  const bool kvalid = k < a.K;
+  const bool kvalid = k < a.K, kvalid1 = WIDE && k + 32 < a.K;
   int dh = 0, dw = 0, kc = 0;
   if (kvalid) {
     const int tap = k / a.Ck;
@@ -1113,9 +1121,9 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WMulti mp) {
     dw = a.dw0 + tw;
   }
   const int col = n0 + 4 * q;
-  const bool cvalid = col < a.Cdv;
+  const bool cvalid = col < a.Cdv, cvalid1 = WIDE && col + 32 < a.Cdv;
   int sh_i = 0, sh_j = 0, sh_c = col;
-  if (a.dy_shuffle) {
+  if (a.dy_shuffle) {  // (WIDE: a sub-pixel's channels come in multiples of 64 too, checked on the host: both halves in one sub-pixel)
     const int ij = col / a.dy_shuffle;
     sh_c = col - ij * a.dy_shuffle;
     sh_i = ij >> 1;
@@ -1124,11 +1132,11 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WMulti mp) {
   const int mbeg = zsplit * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
-  // row state of this thread's two rows (r0 + 16 p of the current chunk), advanced by one chunk per request
-  int rm[2], rmh[2], rmw[2];
-  unsigned rox[2], rod[2];
+  // row state of this thread's rows (r0 [+ 16 p] of the current chunk), advanced by one chunk per request
+  int rm[NP], rmh[NP], rmw[NP];
+  unsigned rox[NP], rod[NP];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int m = mbeg + r0 + 16 * p;
     int n, rem, mh, mw;
     srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
@@ -1144,17 +1152,22 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WMulti mp) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs) : "memory");
   };
-  // four requests per wave and chunk, always (so that the waits can be counted): the thread's 16 bytes of row r0 + 16 p land at
-  // byte 16 tid + 4096 p of the slot
+  // four requests per wave and chunk, always (so that the waits can be counted).  Two rows per thread: the thread's 16 bytes of row
+  // r0 + 16 p land at byte 16 tid + 4096 p of the slot ([32 rows][64 floats]).  WIDE: the thread's 16 bytes of half hf of row r0 land
+  // at byte 16 tid + 4096 hf ([half][32 rows][32 floats])
   auto request = [&](int slot) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const bool valid = rm[p] < mend;
       const int ih = rmh[p] * a.in_stride + dh, iw = rmw[p] * a.in_stride + dw;
       const bool okx = valid && kvalid && ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
       const unsigned dst = (unsigned)srx_uniform((int)((unsigned)(slot * CHUNK * 4) + (unsigned)(p * 4096 + wave * 1024)));
       dma(rx_, okx ? 4u * rox[p] : 0xffffffffu, ldsX + dst);
       dma(rd_, (valid && cvalid) ? 4u * rod[p] : 0xffffffffu, ldsD + dst);
+      if constexpr (WIDE) {
+        dma(rx_, (okx && kvalid1) ? 4u * rox[p] + 128u : 0xffffffffu, ldsX + dst + 4096u);
+        dma(rd_, (valid && cvalid1) ? 4u * rod[p] + 128u : 0xffffffffu, ldsD + dst + 4096u);
+      }
       rm[p] += 32; rmw[p] += a.s_c; rmh[p] += a.s_rm; rox[p] += (unsigned)a.dX0; rod[p] += (unsigned)a.dD0;
       const bool wc = rmw[p] >= a.Wm;
       rmw[p] -= wc ? a.Wm : 0; rmh[p] += wc ? 1 : 0;
@@ -1165,22 +1178,30 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WMulti mp) {
     }
   };
   const bool want_bias = a.bslab != nullptr && kt == 0;  // workgroup-uniform
-  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f}, bsum1 = {0.f, 0.f, 0.f, 0.f};
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int h = lane >> 5, l31 = lane & 31;
   const int wn = wave >> 1, wk = wave & 1;
+  // MFMA step s multiplies rows 2 s + h of the chunk: floats between two steps / between the two lane halves / to this wave's columns
+  constexpr int SSTEP = WIDE ? 64 : 128, HSTEP = WIDE ? 32 : 64, WSTEP = WIDE ? 1024 : 32;
   auto compute = [&](int slot) {
-    const float* cD = &sD[0][0] + slot * CHUNK + h * 64 + wn * 32 + l31;
-    const float* cX = &sX[0][0] + slot * CHUNK + h * 64 + wk * 32 + l31;
+    const float* cD = &sD[0][0] + slot * CHUNK + h * HSTEP + wn * WSTEP + l31;
+    const float* cX = &sX[0][0] + slot * CHUNK + h * HSTEP + wk * WSTEP + l31;
     if (want_bias) {  // (fp32 values of this thread's two dy quads, as wgrad_kernel<0> adds them)
-      const float* bd = &sD[0][0] + slot * CHUNK + r0 * 64 + q * 4;
-      bsum += *reinterpret_cast<const f32x4*>(bd) + *reinterpret_cast<const f32x4*>(bd + 16 * 64);
+      if constexpr (WIDE) {
+        const float* bd = &sD[0][0] + slot * CHUNK + r0 * 32 + q * 4;
+        bsum += *reinterpret_cast<const f32x4*>(bd);
+        bsum1 += *reinterpret_cast<const f32x4*>(bd + 1024);
+      } else {
+        const float* bd = &sD[0][0] + slot * CHUNK + r0 * 64 + q * 4;
+        bsum += *reinterpret_cast<const f32x4*>(bd) + *reinterpret_cast<const f32x4*>(bd + 16 * 64);
+      }
     }
     float dv[16], xv[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) { dv[s] = cD[s * 128]; xv[s] = cX[s * 128]; }
+    for (int s = 0; s < 16; ++s) { dv[s] = cD[s * SSTEP]; xv[s] = cX[s * SSTEP]; }
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[s], xv[s], acc, 0, 0, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -1212,15 +1233,17 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WMulti mp) {
     const int row = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
     slab[(size_t)row * a.Kw + k0 + wk * 32 + l31] = acc[r];
   }
-  if (want_bias) {  // 16 row lanes x 16 column quads -> 64 column sums of this row split
+  if (want_bias) {  // row lanes x 16 column quads -> 64 column sums of this row split
     __syncthreads();
     f32x4* red = reinterpret_cast<f32x4*>(&sD[0][0]);
-    red[r0 * 16 + q] = bsum;
+    constexpr int NR = WIDE ? 32 : 16;  // row lanes
+    if constexpr (WIDE) { red[r0 * 16 + q] = bsum; red[r0 * 16 + 8 + q] = bsum1; }
+    else red[r0 * 16 + q] = bsum;
     __syncthreads();
     if (tid < 16) {
       f32x4 t = red[tid];
 #pragma unroll
-      for (int r = 1; r < 16; ++r) t += red[r * 16 + tid];
+      for (int r = 1; r < NR; ++r) t += red[r * 16 + tid];
       *reinterpret_cast<f32x4*>(a.bslab + slab_id * a.Cnw + n0 + 4 * tid) = t;
     }
   }
@@ -2731,7 +2754,9 @@ static int wgrad_multi_impl(const srx_conv2d_t* d, int nprob, int per_out, const
     snprintf(nm, sizeof(nm), "wgrad_kernel<%d> MxNxK=%dx%dx%d x%d", d->precision ? 1 : 0, a.M, d->Cout, a.K, nprob);
   if (d->precision) SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<1>, grid, dim3(256), 0, st, mp);
   else if (srx_dev().no_wgrad_dma) SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<0>, grid, dim3(256), 0, st, mp);
-  else SRX_LAUNCH_PROF(nm, wfl, wgrad_dma_kernel, grid, dim3(256), 0, st, mp);
+  else if (g.Ck % 64 == 0 && a.Cdv % 64 == 0 && (!a.dy_shuffle || a.dy_shuffle % 64 == 0))
+    SRX_LAUNCH_PROF(nm, wfl, wgrad_dma_kernel<true>, grid, dim3(256), 0, st, mp);
+  else SRX_LAUNCH_PROF(nm, wfl, wgrad_dma_kernel<false>, grid, dim3(256), 0, st, mp);
   SRX_CHECK_LAUNCH("wgrad_kernel");
   }
   if (srx_dev().old_wgrad_reduce || (size_t)g.K * sizeof(float) > 48 * 1024) {
