@@ -392,7 +392,9 @@ int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const
   const double fl = 2.0 * a.M * 64 * KTOT;
   const dim3 grid((unsigned)(a.M / RT));
   char nm[112];
-  if (srx_prof_on()) snprintf(nm, sizeof(nm), "rt36_conv3x3_c64_kernel<%d> MxNxK=%dx64x%d", nb, a.M, KTOT);
+  // (the BatchNorm folds are part of the name: the bench line reports the forms the step really runs, not only the plain conv)
+  if (srx_prof_on())
+    snprintf(nm, sizeof(nm), "rt36_conv3x3_c64_kernel<%d%s%s%s> MxNxK=%dx64x%d", nb, bn ? ", BNR" : "", bnl ? ", BNL" : "", bnb ? ", BNB" : "", a.M, KTOT);
   // one instance per (patch batches, BatchNorm modes, tile pixels); each raises its LDS limit once
 #define RT_LAUNCH(NB_, R_, L_, B_, T_)                                                                                    \
   do {                                                                                                                    \
