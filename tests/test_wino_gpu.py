@@ -265,3 +265,55 @@ def test_winograd_equals_the_direct_kernel_at_the_step_sizes(dev, cfg):
     for src, dst in ((x, y1), (x2, y2), (mix, y3)):
         _lib.call('srx_wino_fwd', C.byref(d0), src.data_ptr(), uf.data_ptr(), None, dst.data_ptr(), ws_for(nww).data_ptr(), nww, s)
     assert rel(y3, 2.0 * y1 + y2) < 2e-5
+
+
+def test_every_forced_plan_computes_the_same_convolution(dev):
+    """srx_wino_force_plan (the measurement aid behind tools/lab/wino_sweep.cpp): every plan the sweep times -- 64- and 32-column
+    workgroups, channel splits of every tile, the last round's tiles cut in parts -- computes the layer the planner's own plan
+    computes (forward with bias + ReLU and masked data gradient, against fp64), and (0, 0, 0) hands the choice back."""
+    from torchsr_amd import _lib
+    L = _lib.lib()
+    n, h, w, cin, cout = 16, 24, 24, 256, 128   # 2304 tiles: 72 tile blocks x 2 / 4 channel blocks; data gradient 256 <- 128
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, h, w, generator=g).relu()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    dy = torch.randn(n, cout, h, w, generator=g)
+    xr = x.double().requires_grad_(True)
+    yr = TF.relu(TF.conv2d(xr, wt.double(), bias.double(), padding=1))
+    dxr = torch.autograd.grad(TF.conv2d(xr, wt.double(), None, padding=1), xr, dy.double())[0] * (x.double() > 0)
+    d = _lib.Conv2dDesc(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, _lib.ACT_RELU, 0.0, 0, 0)
+    dref = C.byref(d)
+    s = torch.cuda.current_stream().cuda_stream
+    nf = L.srx_wino_packed_floats(dref)
+    wg = wt.to(dev)
+    uf, ub = torch.empty(nf, device=dev), torch.empty(nf, device=dev)
+    _lib.call('srx_wino_pack', dref, wg.data_ptr(), uf.data_ptr(), 0, s)
+    _lib.call('srx_wino_pack', dref, wg.data_ptr(), ub.data_ptr(), 1, s)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    dyg = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    bg = bias.to(dev)
+    plan = (C.c_int * 6)()
+    seen = set()
+    try:
+        for forced in ((0, 0, 0), (64, 1, 1), (32, 1, 1), (64, 2, 1), (32, 3, 1), (64, 8, 1), (64, 1, 2), (32, 1, 4)):
+            _lib.call('srx_wino_force_plan', *forced)
+            for which in (0, 1):
+                _lib.call('srx_wino_plan', dref, which, plan)
+                seen.add((which, plan[0], plan[1], plan[5]))
+                nws = L.srx_wino_ws_floats(dref, which)
+                ws = torch.empty(max(nws, 4), device=dev)
+                if which == 0:
+                    y = torch.full((n, h, w, cout), float('nan'), device=dev)
+                    _lib.call('srx_wino_fwd', dref, xg.data_ptr(), uf.data_ptr(), bg.data_ptr(), y.data_ptr(), ws.data_ptr(), nws, s)
+                    assert rel(y.permute(0, 3, 1, 2), yr) < 2e-5, (forced, tuple(plan))
+                else:
+                    dx = torch.full((n, h, w, cin), float('nan'), device=dev)
+                    _lib.call('srx_wino_bwd_data', dref, dyg.data_ptr(), ub.data_ptr(), xg.data_ptr(), dx.data_ptr(), ws.data_ptr(), nws, s)
+                    assert rel(dx.permute(0, 3, 1, 2), dxr) < 2e-5, (forced, tuple(plan))
+    finally:
+        _lib.call('srx_wino_force_plan', 0, 0, 0)
+    # the forced plans were really taken where the layer can run them (not silently replaced by the planner's)
+    assert {(0, 64, 2, 1), (0, 32, 3, 1), (0, 64, 8, 1), (1, 64, 2, 1), (0, 32, 1, 1)} <= seen, seen  # (the gradient contracts 128 channels: 4 chunks, no 8 splits)
+    with pytest.raises(RuntimeError):
+        _lib.call('srx_wino_force_plan', 48, 1, 1)
