@@ -450,7 +450,10 @@ def test_rrdb_modules_alone_equal_the_trunk_node(dev, bf16):
     for i, ((name, _), a, b) in enumerate(zip(blocks.named_parameters(), ga, gb)):
         if bf16:
             far_a, far_b = rel2(a, ge[i]), rel2(b, ge[i])
-            assert rel2(a, b) < max(far_a, far_b) and far_b < max(2 * far_a, 1e-2), (name, rel2(a, b), far_a, far_b)
+            # (1e-6: a bias gradient is an fp32 sum of the output gradient -- no bf16 product in it -- so all three evaluations agree to
+            # fp32 summation-order rounding and "closer to each other than to exact fp32" compares 1.8e-7 with 1.8e-7 there: the first
+            # failure of this line, round 6, after the weight-gradient kernel's bias rows changed their summation order)
+            assert rel2(a, b) < max(far_a, far_b, 1e-6) and far_b < max(2 * far_a, 1e-2), (name, rel2(a, b), far_a, far_b)
         else:
             assert rel(a, b) < 2e-5, (name, rel(a, b))
 
