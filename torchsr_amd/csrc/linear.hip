@@ -213,6 +213,199 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* __r
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same three passes with NOTHING but loads and MFMAs in their loops.  On gfx950 the f32 MFMA runs on the vector ALUs
+// (tools/probe/mfma_valu.hip): the kernels above select zeros for out-of-range rows / split ends with ~70 v_cndmask per 32 MFMAs and
+// wait for each trip's loads before the next trip requests its own -- at batch 32 the 75.5 MB weight stream needs 60 % of the fp32
+// matrix peak to keep up with HBM, and those kernels ran at 2 TB/s.  Here every operand comes through a raw buffer descriptor (rows
+// past the tensor read 0: no selects; the k / j position is the instruction's scalar offset: no address arithmetic), the loads of
+// trip i + 1 are requested before the MFMAs of trip i, and the work decomposition -- splits, wave interleave, order of the sums --
+// is the one above, so the results are bit-identical.  Preconditions (checked on the host, otherwise the kernels above run): K a
+// multiple of 64 (no partial 64-wide slice), J a multiple of 16 for the two backward passes, every tensor below 4 GiB.
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float srx_bload1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void linear_fwd_fast_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              float* __restrict__ part, int B, int K, int J, int b0, int kper) {
+  __shared__ f32x4 red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
+  const int r = lane & 15, h = lane >> 4;
+  const int j0 = blockIdx.x * 16;
+  const int kbeg = blockIdx.y * kper, kend = min(K, kbeg + kper);
+  const __amdgpu_buffer_rsrc_t rw = srx_rsrc(w, (unsigned)((size_t)J * K * 4)), rx = srx_rsrc(x, (unsigned)((size_t)B * K * 4));
+  const unsigned wv = 4u * ((unsigned)(j0 + r) * (unsigned)K + 4u * h);  // (a row past J lies past the tensor: reads 0)
+  unsigned xv[NB];
+  f32x4 acc[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    xv[n] = 4u * ((unsigned)(b0 + 16 * n + r) * (unsigned)K + 4u * h);
+    acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 wa[2][4], xa[2][NB][4];
+  auto load = [&](int set, int kb) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const unsigned so = (unsigned)srx_uniform((kb + 16 * t) * 4);
+      wa[set][t] = srx_bload(rw, wv, so);
+#pragma unroll
+      for (int n = 0; n < NB; ++n) xa[set][n][t] = srx_bload(rx, xv[n], so);
+    }
+  };
+  auto mma = [&](int set) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[set][n][t][e], wa[set][t][e], acc[n], 0, 0, 0);
+  };
+  int kb = kbeg + wave * 64;  // (the waves interleave 64-wide slices, as above)
+  if (kb < kend) {
+    load(0, kb);
+    while (true) {
+      if (kb + 256 < kend) load(1, kb + 256);
+      mma(0);
+      kb += 256;
+      if (kb >= kend) break;
+      if (kb + 256 < kend) load(0, kb + 256);
+      mma(1);
+      kb += 256;
+      if (kb >= kend) break;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    if (n) __syncthreads();
+    red[wave][lane] = acc[n];
+    __syncthreads();
+    if (wave == 0) {
+      f32x4 s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+      const int jj = j0 + r;
+      if (jj < J) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int bb = b0 + 16 * n + 4 * h + e;
+          if (bb < B) part[((size_t)blockIdx.y * B + bb) * J + jj] = s[e];
+        }
+      }
+    }
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void linear_bwd_data_fast_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                   float* __restrict__ part, int B, int K, int J, int b0, int jper) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
+  const int r = lane & 15, h = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * 64;
+  if (n0 >= K) return;  // (K is a multiple of 64: a wave's columns are all in range or none is)
+  const int jbeg = blockIdx.y * jper, jend = min(J, jbeg + jper);
+  const int kcol = n0 + 4 * r;
+  const __amdgpu_buffer_rsrc_t rw = srx_rsrc(w, (unsigned)((size_t)J * K * 4)), rd = srx_rsrc(dy, (unsigned)((size_t)B * J * 4));
+  const unsigned wv = 4u * ((unsigned)h * (unsigned)K + (unsigned)kcol);
+  unsigned dv[NB];
+  f32x4 acc[NB][4];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    dv[n] = 4u * ((unsigned)(b0 + 16 * n + r) * (unsigned)J + (unsigned)h);  // (a row past B lies past the tensor: reads 0)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[n][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 wf[2][4];
+  float av[2][NB][4];
+  auto load = [&](int set, int jb) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      wf[set][t] = srx_bload(rw, wv, (unsigned)srx_uniform((jb + 4 * t) * K * 4));
+#pragma unroll
+      for (int n = 0; n < NB; ++n) av[set][n][t] = srx_bload1(rd, dv[n], (unsigned)srx_uniform((jb + 4 * t) * 4));
+    }
+  };
+  auto mma = [&](int set) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[n][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][n][t], wf[set][t][e], acc[n][e], 0, 0, 0);
+  };
+  int jb = jbeg;
+  if (jb < jend) {
+    load(0, jb);
+    while (true) {
+      if (jb + 16 < jend) load(1, jb + 16);
+      mma(0);
+      jb += 16;
+      if (jb >= jend) break;
+      if (jb + 16 < jend) load(0, jb + 16);
+      mma(1);
+      jb += 16;
+      if (jb >= jend) break;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int bb = b0 + 16 * n + 4 * h + g;
+      if (bb < B) {
+        f32x4 o = {acc[n][0][g], acc[n][1][g], acc[n][2][g], acc[n][3][g]};
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.y * B + bb) * K + kcol) = o;
+      }
+    }
+}
+
+// dw[j][k] = sum_b dy[b][j] x[b][k]: the batch is the contraction, four rows per MFMA; all loads of up to 32 rows are requested
+// before the first MFMA (the loop above waits per four rows)
+__global__ __launch_bounds__(256) void linear_bwd_weight_fast_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     float* __restrict__ dw, int B, int K, int J, int accumulate) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
+  const int r = lane & 15, h = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * 64;
+  if (n0 >= K) return;
+  const int j0 = blockIdx.y * 16;
+  const int kcol = n0 + 4 * r;
+  const __amdgpu_buffer_rsrc_t rx = srx_rsrc(x, (unsigned)((size_t)B * K * 4)), rd = srx_rsrc(dy, (unsigned)((size_t)B * J * 4));
+  const unsigned xv = 4u * ((unsigned)h * (unsigned)K + (unsigned)kcol), dv = 4u * ((unsigned)h * (unsigned)J + (unsigned)(j0 + r));
+  f32x4 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 prev[4];
+  if (accumulate) {  // (requested with the operands: the read-modify-write does not wait behind the MFMAs)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) prev[g] = *reinterpret_cast<const f32x4*>(dw + (size_t)(j0 + 4 * h + g) * K + kcol);
+  }
+  for (int bb0 = 0; bb0 < B; bb0 += 32) {
+    float av[8];
+    f32x4 xf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // rows bb0 + 4 i + h (past B: past the tensors, zeros)
+      av[i] = srx_bload1(rd, dv, (unsigned)srx_uniform((bb0 + 4 * i) * J * 4));
+      xf[i] = srx_bload(rx, xv, (unsigned)srx_uniform((bb0 + 4 * i) * K * 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], xf[i][e], acc[e], 0, 0, 0);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 o = {acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
+    if (accumulate) o += prev[g];
+    *reinterpret_cast<f32x4*>(dw + (size_t)(j0 + 4 * h + g) * K + kcol) = o;
+  }
+}
+
+// may the fast forms run?  (32-bit offsets with a row of slack for the out-of-range rows of the last tile)
+bool linear_fast_ok(int B, int K, int J, bool need_j16) {
+  const size_t lim = 0xfffffff0ull;
+  return K % 64 == 0 && (!need_j16 || J % 16 == 0) && ((size_t)J + 16) * K * 4 < lim && ((size_t)B + 64) * K * 4 < lim && ((size_t)B + 64) * J * 4 < lim;
+}
+
 int fwd_splits(int K, int J, int B) {
   const int64_t tiles = srx_cdiv(J, 16) * srx_cdiv(B, 64);  // (a launch covers 64 rows)
   int64_t s = srx_cdiv(1024, tiles);
@@ -250,7 +443,11 @@ extern "C" int srx_linear_fwd(const float* x, const float* w, const float* bias,
   for (int b0 = 0; b0 < B; b0 += 64) {  // up to four 16-row blocks per launch share one pass over the weight
     const dim3 grid((unsigned)srx_cdiv(J, 16), nsplit);
     const int nb = (int)srx_cdiv(std::min(B - b0, 64), 16);
-    if (nb == 1) hipLaunchKernelGGL(linear_fwd_kernel<1>, grid, dim3(256), 0, st, x, w, ws, B, K, J, b0, kper);
+    if (linear_fast_ok(B, K, J, false) && nb <= 2) {
+      if (nb == 1) hipLaunchKernelGGL(linear_fwd_fast_kernel<1>, grid, dim3(256), 0, st, x, w, ws, B, K, J, b0, kper);
+      else hipLaunchKernelGGL(linear_fwd_fast_kernel<2>, grid, dim3(256), 0, st, x, w, ws, B, K, J, b0, kper);
+    }
+    else if (nb == 1) hipLaunchKernelGGL(linear_fwd_kernel<1>, grid, dim3(256), 0, st, x, w, ws, B, K, J, b0, kper);
     else if (nb == 2) hipLaunchKernelGGL(linear_fwd_kernel<2>, grid, dim3(256), 0, st, x, w, ws, B, K, J, b0, kper);
     else if (nb == 3) hipLaunchKernelGGL(linear_fwd_kernel<3>, grid, dim3(256), 0, st, x, w, ws, B, K, J, b0, kper);
     else hipLaunchKernelGGL(linear_fwd_kernel<4>, grid, dim3(256), 0, st, x, w, ws, B, K, J, b0, kper);
@@ -274,7 +471,11 @@ extern "C" int srx_linear_bwd_data(const float* dy, const float* w, float* dx, i
   for (int b0 = 0; b0 < B; b0 += 64) {  // up to four 16-row blocks per launch share one pass over the weight
     const dim3 grid((unsigned)srx_cdiv(K, 256), nsplit);
     const int nb = (int)srx_cdiv(std::min(B - b0, 64), 16);
-    if (nb == 1) hipLaunchKernelGGL(linear_bwd_data_kernel<1>, grid, dim3(256), 0, st, dy, w, ws, B, K, J, b0, jper);
+    if (linear_fast_ok(B, K, J, true) && nb <= 2) {
+      if (nb == 1) hipLaunchKernelGGL(linear_bwd_data_fast_kernel<1>, grid, dim3(256), 0, st, dy, w, ws, B, K, J, b0, jper);
+      else hipLaunchKernelGGL(linear_bwd_data_fast_kernel<2>, grid, dim3(256), 0, st, dy, w, ws, B, K, J, b0, jper);
+    }
+    else if (nb == 1) hipLaunchKernelGGL(linear_bwd_data_kernel<1>, grid, dim3(256), 0, st, dy, w, ws, B, K, J, b0, jper);
     else if (nb == 2) hipLaunchKernelGGL(linear_bwd_data_kernel<2>, grid, dim3(256), 0, st, dy, w, ws, B, K, J, b0, jper);
     else if (nb == 3) hipLaunchKernelGGL(linear_bwd_data_kernel<3>, grid, dim3(256), 0, st, dy, w, ws, B, K, J, b0, jper);
     else hipLaunchKernelGGL(linear_bwd_data_kernel<4>, grid, dim3(256), 0, st, dy, w, ws, B, K, J, b0, jper);
@@ -290,8 +491,12 @@ extern "C" int srx_linear_bwd_weight(const float* x, const float* dy, float* dw,
                                      void* stream) {
   SRX_REQUIRE(x && dy && dw && B > 0 && K > 0 && J > 0, "linear_bwd_weight: bad argument");
   SRX_REQUIRE(K % 4 == 0, "linear_bwd_weight: in_features must be a multiple of 4");
-  hipLaunchKernelGGL(linear_bwd_weight_kernel, dim3((unsigned)srx_cdiv(K, 256), (unsigned)srx_cdiv(J, 16)), dim3(256),
-                     0, srx_stream(stream), x, dy, dw, B, K, J, accumulate);
+  if (linear_fast_ok(B, K, J, true))
+    hipLaunchKernelGGL(linear_bwd_weight_fast_kernel, dim3((unsigned)srx_cdiv(K, 256), (unsigned)srx_cdiv(J, 16)), dim3(256),
+                       0, srx_stream(stream), x, dy, dw, B, K, J, accumulate);
+  else
+    hipLaunchKernelGGL(linear_bwd_weight_kernel, dim3((unsigned)srx_cdiv(K, 256), (unsigned)srx_cdiv(J, 16)), dim3(256),
+                       0, srx_stream(stream), x, dy, dw, B, K, J, accumulate);
   SRX_CHECK_LAUNCH("linear_bwd_weight_kernel");
   return SRX_OK;
 }
