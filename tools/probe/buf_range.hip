@@ -1,4 +1,6 @@
-// Probe: does the raw-buffer range check on gfx950 include the scalar offset?
+// Probe: does the raw-buffer range check on gfx950 include the scalar offset?  It does (MI355X, round 6): with a 256-byte descriptor
+// and soffset 128 lanes 0..31 read floats 32..63 and lanes 32..63 read 0; with soffset 256 every lane reads 0.  Kernels may therefore
+// put wave-uniform row / tap / split offsets into the instruction's scalar offset and still rely on "past the tensor reads 0".
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(const float* in, float* out, unsigned bytes, unsigned soff) {

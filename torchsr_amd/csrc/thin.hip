@@ -50,27 +50,38 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinW a) {
 #pragma unroll
   for (int t = 0; t < RPG * KW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int s = sbeg; s < send; ++s) {
+  // Round 6: every address of this loop is WAVE-UNIFORM up to the lane's channel (wide: lane, thin: lane & 3) -- the segment, the
+  // kernel row and the column are the wave's, not the lane's -- so both operands come through raw buffer descriptors with the pixel
+  // offset (or, for a padding pixel / a column past the row, an offset past the tensor: reads 0; the range check includes the scalar
+  // offset, tools/probe/buf_range.hip) in the instruction's SCALAR offset: no per-lane compare, select or multiply is left.  The
+  // f32 MFMAs run on the vector ALUs (tools/probe/mfma_valu.hip): the ~340 VALU instructions per segment of the select form cost
+  // 0.7 of its 432 MFMAs' time (PMC, round 5: 35 % MFMA-busy at 24 M VALU instructions per launch).
+  const unsigned wide_bytes = (unsigned)((size_t)a.N * a.H * a.W * 256), thin_bytes = (unsigned)((size_t)a.N * a.H * a.W * 16);
+  const __amdgpu_buffer_rsrc_t rwd = srx_rsrc(a.wide, wide_bytes), rth = srx_rsrc(a.thin, thin_bytes);
+  const unsigned wlane = 4u * (unsigned)lane, tlane = 4u * (unsigned)tc;
+  const int s0 = srx_uniform(sbeg), s1 = srx_uniform(send);
+  for (int s = s0; s < s1; ++s) {
     const int cb = s % a.wsegs;
     const int row = (s / a.wsegs) % a.H;
     const int n = s / (a.wsegs * a.H);
     const int c0 = cb * 16;
     float wv[16];
-    const float* wp = a.wide + ((size_t)(n * a.H + row) * a.W + c0) * 64 + lane;
+    const unsigned wrow = (unsigned)(((n * a.H + row) * a.W + c0) * 256);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) wv[j] = (c0 + j < a.W) ? wp[j * 64] : 0.f;
+    for (int j = 0; j < 16; ++j)
+      wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwd, (int)wlane, (int)((c0 + j < a.W) ? wrow + 256u * j : wide_bytes), 0));
 #pragma unroll
     for (int dr = 0; dr < RPG; ++dr) {
       const int kh = group * RPG + dr;
       const int tr = row + SGN * (kh - PAD);
       const bool rok = (unsigned)tr < (unsigned)a.H;
       float tv[NT];
-      const float* tp = a.thin + ((size_t)(n * a.H + (rok ? tr : 0)) * a.W) * 4 + tc;
+      const unsigned trow = (unsigned)(((n * a.H + tr) * a.W) * 16);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = c0 - PAD + t;
         const bool ok = rok && (unsigned)col < (unsigned)a.W;
-        tv[t] = ok ? tp[(ok ? col : 0) * 4] : 0.f;
+        tv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rth, (int)tlane, (int)(ok ? trow + 16u * (unsigned)col : thin_bytes), 0));
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j)
@@ -504,6 +515,7 @@ int srx_thin_wgrad(const srx_conv2d_t* d, const float* x, const float* dy, float
   a.thin = thin_out ? dy : x;
   a.slab = ws;
   a.N = d->N; a.H = d->H; a.W = d->W;
+  SRX_REQUIRE((size_t)d->N * d->H * d->W * 256 < 0xfffffff0ull, "conv2d_bwd_weight(thin): activation tensor above 4 GiB (32-bit buffer offsets)");
   a.wsegs = (int)srx_cdiv(d->W, 16);
   a.nseg = d->N * d->H * a.wsegs;
   const int groups = d->KH == 9 ? 3 : 1;
