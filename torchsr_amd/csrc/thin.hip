@@ -209,22 +209,31 @@ __global__ __launch_bounds__(256) void thin_fwd2_kernel(const ThinF a) {
   constexpr int NPX = PH * PW * 2;                      // b128 units of the patch (pixel, channel quad)
   constexpr int LP = (NPX + 255) / 256;                 // loads per thread (all issued before any is written)
   constexpr int NWQ = 4 * TAPS * 2, LW = (NWQ + 255) / 256;
+  // the patch / weight offsets of this thread do not depend on the channel round: computed ONCE (round 6: ~20 VALU instructions per
+  // load and round were matrix time lost -- the f32 MFMA shares the vector ALUs), the round's channel offset is the load's scalar
+  // offset; a slot outside the image keeps an offset that stays out of range with any round's offset added (no 32-bit wrap)
+  constexpr unsigned OOR = 0x7ffffff0u;
+  unsigned poff[LP], woff[LW];
+#pragma unroll
+  for (int u = 0; u < LP; ++u) {
+    const int i = u * 256 + tid;
+    const int q = i & 1, pix = i >> 1;
+    const int pw = pix % PW, ph = pix / PW;
+    const int ih = h0 - PAD + ph, iw = w0 - PAD + pw;
+    const bool ok = i < NPX && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+    poff[u] = ok ? 4u * (unsigned)(((ih - hb) * a.W + iw) * 64 + q * 4) : OOR;
+  }
+#pragma unroll
+  for (int u = 0; u < LW; ++u) {
+    const int i = u * 256 + tid;  // (c*TAPS + tap) * 2 + q
+    woff[u] = i < NWQ ? 4u * (unsigned)((i >> 1) * 64 + (i & 1) * 4) : OOR;
+  }
   for (int cc = 0; cc < 64; cc += CS) {
     f32x4 vp[LP], vw[LW];
 #pragma unroll
-    for (int u = 0; u < LP; ++u) {
-      const int i = u * 256 + tid;
-      const int q = i & 1, pix = i >> 1;
-      const int pw = pix % PW, ph = pix / PW;
-      const int ih = h0 - PAD + ph, iw = w0 - PAD + pw;
-      const bool ok = i < NPX && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-      vp[u] = srx_bload(rin, ok ? 4u * (unsigned)(((ih - hb) * a.W + iw) * 64 + cc + q * 4) : 0xffffffffu, 0);
-    }
+    for (int u = 0; u < LP; ++u) vp[u] = srx_bload(rin, poff[u], (unsigned)(cc * 4));
 #pragma unroll
-    for (int u = 0; u < LW; ++u) {
-      const int i = u * 256 + tid;  // (c*TAPS + tap) * 2 + q
-      vw[u] = srx_bload(rw, i < NWQ ? 4u * (unsigned)((i >> 1) * 64 + cc + (i & 1) * 4) : 0xffffffffu, 0);
-    }
+    for (int u = 0; u < LW; ++u) vw[u] = srx_bload(rw, woff[u], (unsigned)(cc * 4));
     __syncthreads();  // the previous round's reads are done
 #pragma unroll
     for (int u = 0; u < LP; ++u) {
