@@ -488,6 +488,20 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
   const __amdgpu_buffer_rsrc_t rmask = srx_rsrc(reinterpret_cast<const char*>(a.mask ? a.mask : a.out) +
                                                     ((((size_t)tb_hi << 32) | tb_lo) << (mask16 ? 1 : 2)), 0xfffffff0u);
 
+  // Row offsets of a pixel-mapped output (strided data gradients, PixelShuffle): ONE thread per tile row works out the row's byte
+  // offset (two divisions by a float multiply, the output pixel, ~25 VALU instructions) and parks it in LDS; the epilogue below reads
+  // its 16 rows back with four ds_read_b128.  Round 6: every lane used to recompute all 16 of its rows -- 400 VALU instructions per
+  // wave and 32-row block, i.e. matrix time (the f32 MFMA runs on the vector ALUs, tools/probe/mfma_valu.hip), 70 % of the launch on
+  // the short-K parity classes of the discriminator's first stride-2 data gradient (PMC).  The table sits at the end of the staging
+  // ring (free since the barrier behind the k loop; the fold and the statistics use its start).
+  unsigned* rowtab = reinterpret_cast<unsigned*>(reinterpret_cast<float*>(smem) + KS * RING * (BMT + BN) * BKL) - ((BMT + 3) & ~3);
+  if (!a.linear_out) {
+    for (int rr = (int)threadIdx.x; rr < BMT; rr += NT) {
+      const int m = m0 + rr;
+      rowtab[rr] = m < a.M ? 4u * (unsigned)(out_elem(m) - tile_base) : 4u * (unsigned)(out_elem(m0) - tile_base);
+    }
+    __syncthreads();
+  }
   float bv[TN];
   unsigned ocol[TN];  // byte offset of the column inside its output row
   bool cok[TN];       // this lane stores the column
@@ -532,8 +546,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool mok = m < a.M;
-        const unsigned rowoff = decltype(linear)::value ? 4u * (unsigned)((m - m0) * a.Co)
-                                                        : 4u * (unsigned)(out_elem(mok ? m : m0) - tile_base);
+        const unsigned rowoff = decltype(linear)::value ? 4u * (unsigned)((m - m0) * a.Co) : rowtab[m - m0];
         const unsigned arow = decltype(linear)::value ? 4u * (unsigned)((m - m0) * a.add_ld) : rowoff;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -613,8 +626,7 @@ __device__ __forceinline__ void gconv_body(const GArgs& a, const int bid) {
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + BM + 4 * xg + r;
       const bool mok = m < a.M;
-      const unsigned rowoff = a.linear_out ? 4u * (unsigned)((m - m0) * a.Co)
-                                           : 4u * (unsigned)(out_elem(mok ? m : m0) - tile_base);
+      const unsigned rowoff = a.linear_out ? 4u * (unsigned)((m - m0) * a.Co) : rowtab[m - m0];
       float v = accx[r] + xb;
       const float vs = mok ? v : 0.f;
       xs1 += vs;
