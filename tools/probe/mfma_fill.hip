@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void mixed(float* out, const float* in, int it
     if constexpr (FILL == 12) asm volatile("ds_write_b128 %0, %1" ::"v"((threadIdx.x & 63) * 16 + (k % 4) * 2048), "v"(q[k % 4]));
     if constexpr (FILL == 8) { asm volatile("ds_read_b128 %0, %1" : "=v"(q[k % 4]) : "v"((threadIdx.x & 63) * 16 + (k % 4) * 2048)); }
     if constexpr (FILL == 9) { asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(p[k % 4]) : "v"((threadIdx.x & 63) * 8 + (k % 4) * 1024), "s"(rs)); }
-    if constexpr (FILL == 10) asm volatile("s_add_u32 %0, %0, 1" : "+s"(si));
+    if constexpr (FILL == 10) asm volatile("s_add_u32 %0, %0, 1" : "+s"(si) : : "scc");  // (SCC is the loop branch's condition: without the clobber the probe never ends)
     if constexpr (FILL == 11) asm volatile("v_max_f32 %0, %1, %0" : "+v"(v[k % 8]) : "v"(x));
     if constexpr (FILL == 13) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v[k % 8]) : "v"(x), "v"(y));
   };
