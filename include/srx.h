@@ -127,7 +127,7 @@ int srx_conv2d_stat_rows(const srx_conv2d_t* d);
 
 /* launch plan the library will use (for profiling / the bench's roofline bookkeeping):
  * which = 0 forward, 1 data gradient; out[6] = {tile rows BM, tile cols BN, tail split-K factor, workgroups,
- * KS (wave groups splitting K inside a workgroup), multi (1: stride-parity classes in one launch)}.
+ * KS (wave groups splitting K inside a workgroup), multi (1: stride-parity classes in one launch; 2: in one workgroup per tile, gconv_s2f_kernel)}.
  * BM = 144 is the 128 + 16 row tile, BM = 36 the row-tile kernel of rowtile.hip. */
 int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out);
 

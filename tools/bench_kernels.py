@@ -35,6 +35,10 @@ SHAPES = [
     ('V.3_2 256->256 @24', 16, 24, 24, 256, 256, 3, 1, 1, 0),
     ('V.4_2 512->512 @12', 16, 12, 12, 512, 512, 3, 1, 1, 0),
     ('V.5_2 512->512 @6', 16, 6, 6, 512, 512, 3, 1, 1, 0),
+    ('D.c2 64->64 s2 @96 N=32', 32, 96, 96, 64, 64, 3, 2, 1, 0),
+    ('D.c4 128->128 s2 @48 N=32', 32, 48, 48, 128, 128, 3, 2, 1, 0),
+    ('D.c6 256->256 s2 @24 N=32', 32, 24, 24, 256, 256, 3, 2, 1, 0),
+    ('D.c8 512->512 s2 @12 N=32', 32, 12, 12, 512, 512, 3, 2, 1, 0),
     ('V.1_2 N=32', 32, 96, 96, 64, 64, 3, 1, 1, 0),
     ('V.5_2 N=32', 32, 6, 6, 512, 512, 3, 1, 1, 0),
 ]

@@ -56,6 +56,7 @@ static SrxDevSwitches read_switches() {
   s.wino_no_tail = flag("SRX_WINO_NO_TAIL");
   s.wino_zsplit = num("SRX_WINO_ZSPLIT");
   s.wino_bn = num("SRX_WINO_BN");
+  s.s2_mode = num("SRX_S2_MODE");
   // Result-CHANGING switches (the ablation instantiations compute garbage by design: they exist to time a kernel without one of
   // its parts) need a second, explicit opt-in and say so once on stderr -- a stray variable must not silently corrupt a run
   if (s.rdb_ablate != 0 || s.c64_ablate != 0) {

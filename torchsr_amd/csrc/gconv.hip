@@ -697,12 +697,341 @@ struct GMulti {
   int first[5];  // first[i] = first workgroup of problem i; first[n] = grid size
   GArgs g[4];
 };
-template <int BM, int BN, int WM, int WN, int XR, int PR = 0>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gconv_multi_kernel(const GMulti m) {
+// KS = 2 (round 6, the 64 x 64 tile only): two wave groups share a tile's k-chunks (gconv_body) -- the deep, small-M classes of
+// the discriminators' last strided layers (576..4608 rows, K up to 2048 per class) are bound by the serial chunk chain of their
+// heaviest class's workgroups, not by the chip: 64 x 64 tiles give four times the workgroups of 128 x 64 and the in-workgroup
+// split halves each chain.
+template <int BM, int BN, int WM, int WN, int XR, int PR = 0, int KS = 1>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KS) void gconv_multi_kernel(const GMulti m) {
   int ci = 0;
   while (ci + 1 < m.n && (int)blockIdx.x >= m.first[ci + 1]) ++ci;
   const GArgs a = m.g[ci];
-  gconv_body<BM, BN, WM, WN, 1, XR, PR>(a, blockIdx.x - m.first[ci]);
+  gconv_body<BM, BN, WM, WN, KS, XR, PR>(a, blockIdx.x - m.first[ci]);
+}
+
+// ---------------------------------------------------------------------------
+// Strided data gradient, all stride-parity classes of a tile in ONE workgroup and ONE pipelined K loop (round 6).
+//
+// gconv_multi_kernel runs the classes as separate workgroups: for the 3x3 / stride-2 layers of the discriminators that is four
+// gather-GEMMs with 1, 2, 2 and 4 taps -- K loops of 2..8 chunks at 64 channels, each with its own k table, row set-up, pipeline
+// fill and epilogue (34-44 % MFMA-busy under the counters).  The classes of a layer whose extents are multiples of the stride
+// share EVERYTHING but their taps, their weight matrix and a constant output offset: the same M grid (one row per gradient
+// pixel neighbourhood), hence the same A rows, bounds and row offsets.  Here a workgroup owns one (row tile, column tile) and
+// walks the classes back to back: one chunk sequence -- each class's chunks padded to whole trips of the three-slot ring, the
+// padding chunks loading nothing and multiplying nothing --, one table entry per chunk (tap coordinates, gather offset, the
+// chunk's place in its class's weight matrix: wave-uniform, so they live in SGPRs and the per-thread k table of gconv_body
+// disappears), the loads of class c+1 already in flight while class c's accumulators are stored.  A chunk lies inside one tap
+// (channels per tap a multiple of 32: checked on the host; other layers keep gconv_multi_kernel).
+// ---------------------------------------------------------------------------
+struct S2Class {
+  int nth, ntw, dh0, dw0;  // taps of the class and its most negative tap
+  int chunks, pstart;      // k-chunks (32 floats) of the class; its first chunk in the padded sequence
+  int oh_off, ow_off;      // output parity
+  unsigned wbase, kpb;     // byte offset of the class's weight matrix in the packed buffer; bytes per row of it (Kp * 4)
+};
+struct GFused {
+  GArgs g;                 // what the classes share (w / w_bytes: the WHOLE packed data-gradient buffer)
+  int nclass, cpt, ptotal; // classes; chunks per tap (Ck / 32); chunks of the padded sequence
+  S2Class c[4];
+};
+
+// (the 64-column tiles: at most 128 registers, so that two 8-wave workgroups share a CU -- one's epilogues and dead steps
+// under the other's MFMAs)
+template <int BM, int BN, int WM, int WN, int XR, int PR>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) == 8 && BN == 64 ? 4 : 1) void gconv_s2f_kernel(const GFused f) {
+  static_assert(PR == 0 || (PR == 1 && XR == 0), "fp32, or bf16 products without the 16-row extension");
+  const GArgs& a = f.g;
+  constexpr int BKL = PR == 1 ? BK / 2 : BK;
+  constexpr int NS = PR == 1 ? 2 : 4;
+  constexpr int BMT = BM + XR;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int RPP = NT / 8;
+  constexpr int RA = (BMT + RPP - 1) / RPP, RB = BN / RPP;
+  static_assert(RA >= 1 && RB >= 1, "tile too small for the thread count");
+  static_assert(XR == 0 || BN / 16 <= NT / 64, "one extra 16x16 block per wave at most");
+  constexpr int RING = 3;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
+  float* sA = reinterpret_cast<float*>(smem);
+  float* sB = sA + RING * BMT * BKL;
+  int4* ctab = reinterpret_cast<int4*>(sA + RING * (BMT + BN) * BKL);        // [ptotal + 3]
+  unsigned* rowtab = reinterpret_cast<unsigned*>(ctab + (f.ptotal + 3));      // [BMT]
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int tile = srx_uniform((int)blockIdx.x);
+  const int nt = srx_uniform(tile / a.mtiles), mt = tile - nt * a.mtiles;
+  const int m0 = mt * BMT, n0 = nt * BN;
+  const int q = tid & 7, r0 = tid >> 3;
+  auto split_row = [&](int m, int& n, int& mh, int& mw) {
+    int rem;
+    srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
+    srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
+  };
+  const __amdgpu_buffer_rsrc_t rin = srx_rsrc(a.in, (unsigned)a.in_bytes);
+  const __amdgpu_buffer_rsrc_t rw = srx_rsrc(a.w, a.w_bytes);
+
+  // ---- chunk table: one entry per chunk of the padded sequence (+ 3 dead ones the pipeline runs ahead into)
+  for (int e = tid; e < f.ptotal + 3; e += NT) {
+    int4 ent = {(int)(INVALID & 0xffff), 0, 0, 0};  // dead: taps out of every image, weight row pitch 0
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < f.nclass) {
+        const S2Class& k = f.c[c];
+        const int j = e - k.pstart;
+        if (j >= 0 && j < k.chunks) {
+          const int tap = j / f.cpt, cin = j - tap * f.cpt;
+          const int th = tap / k.ntw, tw = tap - th * k.ntw;
+          const int dh = k.dh0 + th, dw = k.dw0 + tw;
+          ent.x = (int)((unsigned)(dh & 0xffff) | ((unsigned)dw << 16));
+          ent.y = ((dh * a.Wi + dw) * a.Ci + cin * BK) * 4;
+          ent.z = (int)(k.wbase + (unsigned)j * (BK * 4));
+          ent.w = (int)k.kpb;
+        }
+      }
+    }
+    ctab[e] = ent;
+  }
+  // ---- per-thread rows of the A tile: the same for every class
+  int rih[RA], riw[RA];
+  unsigned rbase[RA];
+#pragma unroll
+  for (int p = 0; p < RA; ++p) {
+    const int m = m0 + r0 + RPP * p;
+    if (m < a.M && r0 + RPP * p < BMT) {
+      int n, mh, mw;
+      split_row(m, n, mh, mw);
+      rih[p] = mh; riw[p] = mw;
+      rbase[p] = 4u * (unsigned)(((n * a.Hi + mh) * a.Wi + mw) * a.Ci) + 16u * (unsigned)q;
+    } else {
+      rih[p] = INVALID; riw[p] = 0; rbase[p] = 0;
+    }
+  }
+  unsigned wrow[RB];
+#pragma unroll
+  for (int p = 0; p < RB; ++p) wrow[p] = (unsigned)(n0 + r0 + RPP * p);
+  // ---- byte offsets of the tile's output rows for parity (0, 0), relative to the tile's first row (a class adds a constant)
+  auto out_elem = [&](int m) -> size_t {
+    int n, mh, mw;
+    split_row(m, n, mh, mw);
+    return ((size_t)(n * a.Ho + mh * a.out_stride) * a.Wo + mw * a.out_stride) * a.Co;
+  };
+  const size_t tile_base = out_elem(m0);
+  for (int rr = tid; rr < BMT; rr += NT) {
+    const int m = m0 + rr;
+    rowtab[rr] = m < a.M ? 4u * (unsigned)(out_elem(m) - tile_base) : 0u;
+  }
+  __syncthreads();
+
+  f32x16 acc[TM][TN];
+  f32x4 accx = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB], ra2[RA], rb2[RB];
+  auto gload = [&](int kc, f32x4 (&ra)[RA], f32x4 (&rb)[RB]) {
+    const int4 ct = ctab[kc];  // (one address for the whole wave: a broadcast read)
+    const int cx = srx_uniform(ct.x), cy = srx_uniform(ct.y), cz = srx_uniform(ct.z), cw = srx_uniform(ct.w);
+    const int dh = (int)(short)(cx & 0xffff), dw = cx >> 16;
+#pragma unroll
+    for (int p = 0; p < RA; ++p) {
+      const int ih = rih[p] + dh, iw = riw[p] + dw;
+      const bool ok = ((unsigned)ih < (unsigned)a.Hi) && ((unsigned)iw < (unsigned)a.Wi);
+      ra[p] = srx_bload(rin, ok ? rbase[p] + (unsigned)cy : 0xffffffffu, 0);  // out of range (padding taps, dead chunks) reads 0
+    }
+#pragma unroll
+    for (int p = 0; p < RB; ++p)
+      rb[p] = srx_bload(rw, cw ? wrow[p] * (unsigned)cw + 16u * (unsigned)q : 0xffffffffu, (unsigned)cz);
+  };
+  const int wchunk = PR == 1 ? (((q >> 1) ^ ((r0 >> 2) & 3)) * 4 + (q & 1) * 2) : (q ^ ((r0 >> 1) & 7)) * 4;
+  auto put = [&](float* dst, const f32x4& v) {
+    if (PR == 1) {
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      const bf16x2 lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
+      *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  };
+  auto swrite = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) {
+    float* dA = sA + buf * BMT * BKL;
+    float* dB = sB + buf * BN * BKL;
+#pragma unroll
+    for (int p = 0; p < RA; ++p)
+      if (RPP * (p + 1) <= BMT || r0 + RPP * p < BMT) put(dA + (r0 + RPP * p) * BKL + wchunk, ra[p]);
+#pragma unroll
+    for (int p = 0; p < RB; ++p) put(dB + (r0 + RPP * p) * BKL + wchunk, rb[p]);
+  };
+  const int h = lane >> 5, l31 = lane & 31;
+  const int xr = PR == 1 ? (l31 >> 2) & 3 : (l31 >> 1) & 7;
+  const int arow = (wm * WM + l31) * BKL, brow = (wn * WN + l31) * BKL;
+  const bool has_x = XR > 0 && wave < BN / 16;
+  const int xi = lane & 15, xg = lane >> 4;
+  const int xra = BM + xi, xrb = 16 * wave + xi;
+  f32x4 af[2][TM], bf[2][TN];
+  auto frag = [&](int slot, int s, int set) {
+    const float* cA = sA + slot * BMT * BKL + arow;
+    const float* cB = sB + slot * BN * BKL + brow;
+    const int ch = ((2 * s + h) ^ xr) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[set][i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * BKL + ch);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * BKL + ch);
+  };
+  auto mma = [&](int set) {
+    __builtin_amdgcn_s_setprio(1);
+    if (PR) {
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[set][i]),
+                                                              __builtin_bit_cast(bf16x8, bf[set][j]), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][i][e], bf[set][j][e], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto extra = [&](int slot) {
+    const float* xA = sA + slot * BMT * BKL + xra * BKL;
+    const float* xB = sB + slot * BN * BKL + xrb * BKL;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(xA + (((xg + 4 * u) ^ ((xra >> 1) & 7)) * 4));
+      const f32x4 fb = *reinterpret_cast<const f32x4*>(xB + (((xg + 4 * u) ^ ((xrb >> 1) & 7)) * 4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) accx = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[e], accx, 0, 0, 0);
+    }
+  };
+  // one step of gconv_body's pipeline (see there); `live`: the chunk is a real one of the class
+  auto step = [&](int kc, int slot, f32x4 (&ra_next)[RA], f32x4 (&rb_next)[RB], f32x4 (&ra_free)[RA], f32x4 (&rb_free)[RB]) {
+    const int nslot = slot == 2 ? 0 : slot + 1;
+    swrite(nslot, ra_next, rb_next);
+    gload(kc + 3, ra_free, rb_free);
+    const bool live = srx_uniform(ctab[kc].w) != 0;
+    if (NS == 2) {
+      frag(slot, 1, 1);
+      if (live) mma(0);
+      __syncthreads();
+      frag(nslot, 0, 0);
+      if (live) mma(1);
+      return;
+    }
+    frag(slot, 1, 1);
+    if (live) mma(0);
+    frag(slot, 2, 0);
+    if (live) mma(1);
+    __syncthreads();
+    frag(slot, 3, 1);
+    if (live) mma(0);
+    frag(nslot, 0, 0);
+    if (XR > 0 && has_x && live) extra(slot);
+    if (live) mma(1);
+  };
+
+  // ---- epilogue constants (class-independent)
+  const unsigned tb_lo = (unsigned)srx_uniform((int)(unsigned)(tile_base & 0xffffffffu));
+  const unsigned tb_hi = (unsigned)srx_uniform((int)(unsigned)(tile_base >> 32));
+  unsigned ocol[TN];
+  bool cok[TN], cmk[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WN + j * 32 + l31;
+    cmk[j] = col >= a.mask_lo && col < a.mask_hi;
+    ocol[j] = 4u * (unsigned)col;
+    cok[j] = col < a.Cs;
+  }
+  auto store_class = [&](auto masked, const __amdgpu_buffer_rsrc_t rout, const __amdgpu_buffer_rsrc_t rmask) {
+    constexpr bool MASK = decltype(masked)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int hr = 0; hr < 16; hr += 8) {  // eight rows at a time: the offsets and mask values of a half block are what the
+        unsigned offs[8][TN];               // epilogue holds on top of the three load stages in flight (two workgroups per CU)
+        float mv[MASK ? 8 : 1][TN];
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {  // (every mask value of the half block is requested before its first store: see gconv_body)
+          const int r = hr + r8;
+          const int rl = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const bool mok = m0 + rl < a.M;
+          const unsigned rowoff = rowtab[rl];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const unsigned off = (mok && cok[j]) ? rowoff + ocol[j] : 0xffffffffu;
+            offs[r8][j] = off;
+            if (MASK) mv[r8][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)(cmk[j] ? off : 0xffffffffu), 0, 0));
+          }
+        }
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float v = acc[i][j][hr + r8];
+            if (MASK) v = (cmk[j] && !(mv[r8][j] > 0.f)) ? v * a.mask_slope : v;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, offs[r8][j], 0, 0);
+          }
+      }
+    if (XR > 0 && has_x) {  // the extra 16x16 block: rows BM + 4(l>>4) + reg, column 16 wave + (l&15)
+      const int col = n0 + 16 * wave + xi;
+      const bool xok = col < a.Cs;
+      const bool xmk = MASK && col >= a.mask_lo && col < a.mask_hi;
+      unsigned xoff[4];
+      float xm[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = BM + 4 * xg + r;
+        xoff[r] = (m0 + rl < a.M && xok) ? rowtab[rl] + 4u * (unsigned)col : 0xffffffffu;
+        xm[r] = MASK ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)(xmk ? xoff[r] : 0xffffffffu), 0, 0)) : 1.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = accx[r];
+        if (MASK) v = (xmk && !(xm[r] > 0.f)) ? v * a.mask_slope : v;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, xoff[r], 0, 0);
+      }
+    }
+  };
+
+  // ---- the pipelined loop over the padded chunk sequence, class by class
+  gload(0, ra0, rb0);
+  gload(1, ra1, rb1);
+  gload(2, ra2, rb2);
+  swrite(0, ra0, rb0);
+  __syncthreads();
+  frag(0, 0, 0);
+  int kc = 0;
+  for (int c = 0; c < f.nclass; ++c) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    accx = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kend = srx_uniform(c + 1 < f.nclass ? f.c[c + 1].pstart : f.ptotal);
+    for (; kc < kend; kc += 3) {  // whole trips of the ring (a class's chunks are padded to a multiple of three)
+      step(kc, 0, ra1, rb1, ra0, rb0);
+      step(kc + 1, 1, ra2, rb2, ra1, rb1);
+      step(kc + 2, 2, ra0, rb0, ra2, rb2);
+    }
+    // this class's outputs: parity (oh_off, ow_off) of the tile's 2x2 (stride x stride) output blocks
+    const S2Class& k = f.c[c];
+    const size_t delta = ((size_t)k.oh_off * a.Wo + k.ow_off) * a.Co;
+    const size_t cbase = ((((size_t)tb_hi << 32) | tb_lo) + delta) << 2;
+    const unsigned cb_lo = (unsigned)srx_uniform((int)(unsigned)(cbase & 0xffffffffu));
+    const unsigned cb_hi = (unsigned)srx_uniform((int)(unsigned)(cbase >> 32));
+    const size_t cb = ((size_t)cb_hi << 32) | cb_lo;
+    const __amdgpu_buffer_rsrc_t rout = srx_rsrc(reinterpret_cast<char*>(a.out) + cb, 0xfffffff0u);
+    const __amdgpu_buffer_rsrc_t rmask = srx_rsrc(reinterpret_cast<const char*>(a.mask ? a.mask : a.out) + cb, 0xfffffff0u);
+    if (a.mask) store_class(std::true_type{}, rout, rmask);
+    else store_class(std::false_type{}, rout, rmask);
+  }
 }
 
 // finishes the K-split tail tiles: out = act(sum_z partial[z] + bias) and, when asked, the tile's
@@ -1823,20 +2152,20 @@ int launch_gconv(const GArgs& a, const Plan& p, hipStream_t st) {
   return SRX_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int XR, int PR = 0>
+template <int BM, int BN, int WM, int WN, int XR, int PR = 0, int KS = 1>
 int launch_gconv_multi(const GMulti& m, size_t lds, hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_multi_kernel<BM, BN, WM, WN, XR, PR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_multi_kernel<BM, BN, WM, WN, XR, PR, KS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   char nm[64];
   double fl = 0.0;
   if (srx_prof_on()) {
-    snprintf(nm, sizeof(nm), "gconv_multi_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, XR, PR);
+    snprintf(nm, sizeof(nm), "gconv_multi_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, XR, PR, KS);
     for (int i = 0; i < m.n; ++i) fl += 2.0 * m.g[i].M * m.g[i].Cn * m.g[i].K;
   }
-  SRX_LAUNCH_PROF(nm, fl, (gconv_multi_kernel<BM, BN, WM, WN, XR, PR>), dim3(m.first[m.n]), dim3((BM / WM) * (BN / WN) * 64),
+  SRX_LAUNCH_PROF(nm, fl, (gconv_multi_kernel<BM, BN, WM, WN, XR, PR, KS>), dim3(m.first[m.n]), dim3((BM / WM) * (BN / WN) * 64 * KS),
                   lds, st, m);
   SRX_CHECK_LAUNCH("gconv_multi_kernel");
   return SRX_OK;
@@ -1846,17 +2175,23 @@ int launch_gconv_multi(const GMulti& m, size_t lds, hipStream_t st) {
 // 1x..4x different K, and their strided outputs cannot take the split-K fix-up path, so balance comes
 // from the tile size alone: every candidate's workgroups are list-scheduled heavy-first (the order
 // run_gconv_multi launches them in) over the CUs and the shortest makespan wins.
-void multi_tile(const GMulti& m, int Cnp, int& BM, int& BN, bool bf16 = false) {
+float multi_tile(const GMulti& m, int Cnp, int& BM, int& BN, int& KS, bool bf16 = false) {
   const int P = device_cus();
-  constexpr int NC = 6;
-  const int cand[NC][2] = {{144, 128}, {144, 64}, {128, 128}, {128, 64}, {64, 64}, {128, 32}};
-  const float eff[NC] = {0.91f, 0.82f, 0.95f, 0.85f, 0.60f, 0.50f};
+  constexpr int NC = 7;
+  // (the last candidate: 64 x 64 with the k-chunks of a tile dealt to two wave groups -- half the chain, one workgroup per CU)
+  const int cand[NC][2] = {{144, 128}, {144, 64}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 64}};
+  const float eff[NC] = {0.91f, 0.82f, 0.95f, 0.85f, 0.60f, 0.50f, 0.80f};
   float best = 1e30f;
-  BM = 128; BN = Cnp == 32 ? 32 : 64;
+  BM = 128; BN = Cnp == 32 ? 32 : 64; KS = 1;
+  if (srx_dev().force_plan && srx_dev().plan[1] > 0 && Cnp % srx_dev().plan[1] == 0) {  // developer override (SRX_FORCE_PLAN)
+    BM = srx_dev().plan[0]; BN = srx_dev().plan[1]; KS = (BM == 64 && BN == 64 && srx_dev().plan[3] == 2) ? 2 : 1;
+    return 0.f;
+  }
   std::vector<float> heap;
   for (int i = 0; i < NC; ++i) {
     const int bm = cand[i][0], bn = cand[i][1];
     if (bf16 && bm == 144) continue;  // (the 16-row extension is fp32 only)
+    if (i == 6 && (srx_dev().s2_mode & 2)) continue;
     if (Cnp == 32) { if (bn != 32) continue; }
     else if (bn == 32 || Cnp % bn != 0) continue;
     heap.assign(P, 0.f);  // min-heap of CU finish times
@@ -1868,7 +2203,10 @@ void multi_tile(const GMulti& m, int Cnp, int& BM, int& BN, bool bf16 = false) {
         int rank = 1;
         for (int o = 0; o < m.n; ++o) rank += (m.g[o].Kp < m.g[c].Kp);
         if (rank != pass) continue;
-        const float cost = 1.0f + 2.0f * bm * bn * (float)kch * BK / (4 * 64 * 2.1e3f) / eff[i] / (bf16 ? 3.0f : 1.0f);  // (see make_plan)
+        // (see make_plan; the two-group tile: half the chain at 0.8, and a fixed cost nothing overlaps -- set-up and fold of a
+        // 512-thread workgroup that has the CU to itself: measured ~6.5 us on the discriminator's layers)
+        const float t = 2.0f * bm * bn * (float)kch * BK / (4 * 64 * 2.1e3f) / (bf16 ? 3.0f : 1.0f);
+        const float cost = i == 6 ? 6.5f + 0.5f * t / 0.8f : 1.0f + t / eff[i];
         const int tiles = (int)srx_cdiv(m.g[c].M, bm) * (int)srx_cdiv(m.g[c].Cn, bn);
         for (int t = 0; t < tiles; ++t) {
           std::pop_heap(heap.begin(), heap.end(), later);
@@ -1877,12 +2215,13 @@ void multi_tile(const GMulti& m, int Cnp, int& BM, int& BN, bool bf16 = false) {
           std::push_heap(heap.begin(), heap.end(), later);
         }
       }
-    if (makespan < best) { best = makespan; BM = bm; BN = bn; }
+    if (makespan < best) { best = makespan; BM = bm; BN = bn; KS = i == 6 ? 2 : 1; }
   }
+  return best;
 }
 
 // all problems use tile (BM, BN); no K split.  Problems are launched heaviest (largest K) first.
-int run_gconv_multi(GMulti& m, int BM, int BN, hipStream_t st, int precision = 0) {
+int run_gconv_multi(GMulti& m, int BM, int BN, int KS, hipStream_t st, int precision = 0) {
   std::stable_sort(m.g, m.g + m.n, [](const GArgs& x, const GArgs& y) { return x.Kp > y.Kp; });
   int maxk = 0;
   m.first[0] = 0;
@@ -1898,8 +2237,13 @@ int run_gconv_multi(GMulti& m, int BM, int BN, hipStream_t st, int precision = 0
     m.first[i + 1] = m.first[i] + tiles;
     if (a.kchunks > maxk) maxk = a.kchunks;
   }
-  const size_t lds = (size_t)(3 * (BM + BN) * BK) * (precision ? 2 : 4) + (size_t)maxk * 8 * sizeof(int2);
+  const size_t lds = (size_t)(KS * 3 * (BM + BN) * BK) * (precision ? 2 : 4) + (size_t)maxk * 8 * sizeof(int2);
   if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: K range needs %zu bytes of LDS", lds);
+  if (KS == 2) {
+    if (BM != 64 || BN != 64) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d: internal: two wave groups on a tile other than 64 x 64");
+    if (precision) return launch_gconv_multi<64, 64, 32, 32, 0, 1, 2>(m, lds, st);
+    return launch_gconv_multi<64, 64, 32, 32, 0, 0, 2>(m, lds, st);
+  }
   if (precision) {  // bf16 products (round 4: the stride-parity classes of a strided data gradient too)
     if (BM == 128 && BN == 128) return launch_gconv_multi<128, 128, 64, 32, 0, 1>(m, lds, st);
     if (BM == 128 && BN == 64) return launch_gconv_multi<128, 64, 32, 32, 0, 1>(m, lds, st);
@@ -1912,6 +2256,97 @@ int run_gconv_multi(GMulti& m, int BM, int BN, hipStream_t st, int precision = 0
   if (BM == 128 && BN == 64) return launch_gconv_multi<128, 64, 32, 32, 0>(m, lds, st);
   if (BM == 64 && BN == 64) return launch_gconv_multi<64, 64, 32, 32, 0>(m, lds, st);
   return launch_gconv_multi<128, 32, 32, 32, 0>(m, lds, st);
+}
+
+// ---- the fused-class strided data gradient (gconv_s2f_kernel) ----
+// Eligible: 2..4 non-empty classes on ONE M grid (extents multiples of the stride), whole chunks per tap, plain gather.
+bool s2f_eligible(const srx_conv2d_t* d, const BwdClass* cls, int nc) {
+  if ((srx_dev().s2_mode & 1) || nc < 2 || nc > 4 || d->shuffle || d->up || d->precision > 1) return false;
+  if (bwd_ck(d) % BK != 0 || pad_rows(d->Cin) % 64 != 0) return false;
+  for (int i = 0; i < nc; ++i)
+    if (cls[i].K == 0 || cls[i].Hm != cls[0].Hm || cls[i].Wm != cls[0].Wm || cls[i].Hm <= 0 || cls[i].Wm <= 0) return false;
+  return true;
+}
+
+// tile of the fused launch and its estimated time (the model of make_plan / multi_tile: one workgroup slot per CU); a
+// workgroup pays one set-up, one pipeline fill and an epilogue per class
+float s2f_tile(const srx_conv2d_t* d, const BwdClass* cls, int nc, int& BM, int& BN) {
+  const int P = device_cus();
+  const bool bf16 = d->precision != 0;
+  const int Cnp = pad_rows(d->Cin);
+  const int M = d->N * cls[0].Hm * cls[0].Wm;
+  int chunks = 0;
+  for (int i = 0; i < nc; ++i) chunks += cls[i].K / BK;
+  constexpr int NC = 5;
+  const int cand[NC][2] = {{144, 128}, {144, 64}, {128, 128}, {128, 64}, {64, 64}};
+  const float eff[NC] = {0.91f, 0.82f, 0.95f, 0.85f, 0.60f};
+  float best = 1e30f;
+  BM = 0; BN = 0;
+  for (int i = 0; i < NC; ++i) {
+    const int bm = cand[i][0], bn = cand[i][1];
+    if ((bf16 && bm == 144) || Cnp % bn != 0) continue;
+    const float t = 2.0f * bm * bn * (float)chunks * BK / (4 * 64 * 2.1e3f) / eff[i] / (bf16 ? 3.0f : 1.0f);
+    const int64_t tiles = srx_cdiv(M, bm) * (Cnp / bn);
+    const float cost = (float)srx_cdiv(tiles, P) * (1.5f + 0.7f * nc * (bm * bn / 8192.0f) + t);
+    if (cost < best) { best = cost; BM = bm; BN = bn; }
+  }
+  return best;
+}
+
+template <int BM, int BN, int WM, int WN, int XR, int PR>
+int launch_gconv_s2f(const GFused& f, dim3 grid, size_t lds, double fl, hipStream_t st) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_s2f_kernel<BM, BN, WM, WN, XR, PR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  char nm[64];
+  if (srx_prof_on()) snprintf(nm, sizeof(nm), "gconv_s2f_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, XR, PR);
+  SRX_LAUNCH_PROF(nm, fl, (gconv_s2f_kernel<BM, BN, WM, WN, XR, PR>), grid, dim3((BM / WM) * (BN / WN) * 64), lds, st, f);
+  SRX_CHECK_LAUNCH("gconv_s2f_kernel");
+  return SRX_OK;
+}
+
+// `shared`: the launch arguments of any one class (gconv_multi's), `wpk` / `wfloats`: the whole packed data-gradient buffer
+int run_gconv_s2f(const srx_conv2d_t* d, const GArgs& shared, const BwdClass* cls, int nc, const float* wpk, size_t wfloats,
+                  int BM, int BN, hipStream_t st) {
+  GFused f{};
+  f.g = shared;
+  f.g.w = wpk;
+  if (wfloats * sizeof(float) >= 0xfffffff0ull) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: packed weights above 4 GiB");
+  f.g.w_bytes = (unsigned)(wfloats * sizeof(float));
+  f.g.mtiles = (int)srx_cdiv(shared.M, BM);
+  f.nclass = nc;
+  f.cpt = bwd_ck(d) / BK;
+  int pos = 0;
+  double fl = 0.0;
+  for (int i = 0; i < nc; ++i) {
+    S2Class& k = f.c[i];
+    k.nth = cls[i].nth; k.ntw = cls[i].ntw; k.dh0 = cls[i].dminh; k.dw0 = cls[i].dminw;
+    k.chunks = cls[i].K / BK; k.pstart = pos;
+    k.oh_off = cls[i].ph; k.ow_off = cls[i].pw;
+    k.wbase = (unsigned)(cls[i].woff * sizeof(float)); k.kpb = (unsigned)(cls[i].Kp * sizeof(float));
+    pos += (int)srx_roundup(k.chunks, 3);
+    fl += 2.0 * shared.M * shared.Cn * cls[i].K;
+  }
+  f.ptotal = pos;
+  const int Cnp = pad_rows(d->Cin);
+  const bool bf16 = d->precision != 0;
+  const size_t lds = (size_t)(3 * (BM + BN) * BK) * (bf16 ? 2 : 4) + (size_t)(pos + 3) * sizeof(int4) + (size_t)srx_roundup(BM, 4) * 4;
+  if (lds > 160 * 1024) SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: K range needs %zu bytes of LDS", lds);
+  const dim3 grid((unsigned)(f.g.mtiles * (Cnp / BN)));
+  if (bf16) {
+    if (BM == 128 && BN == 128) return launch_gconv_s2f<128, 128, 64, 32, 0, 1>(f, grid, lds, fl, st);
+    if (BM == 128 && BN == 64) return launch_gconv_s2f<128, 64, 32, 32, 0, 1>(f, grid, lds, fl, st);
+    if (BM == 64 && BN == 64) return launch_gconv_s2f<64, 64, 32, 32, 0, 1>(f, grid, lds, fl, st);
+  } else {
+    if (BM == 144 && BN == 128) return launch_gconv_s2f<128, 128, 64, 32, 16, 0>(f, grid, lds, fl, st);
+    if (BM == 144 && BN == 64) return launch_gconv_s2f<128, 64, 32, 32, 16, 0>(f, grid, lds, fl, st);
+    if (BM == 128 && BN == 128) return launch_gconv_s2f<128, 128, 64, 32, 0, 0>(f, grid, lds, fl, st);
+    if (BM == 128 && BN == 64) return launch_gconv_s2f<128, 64, 32, 32, 0, 0>(f, grid, lds, fl, st);
+    if (BM == 64 && BN == 64) return launch_gconv_s2f<64, 64, 32, 32, 0, 0>(f, grid, lds, fl, st);
+  }
+  SRX_FAIL(SRX_E_UNSUPPORTED, "conv2d_bwd_data: internal: no fused-class instantiation for tile %d x %d", BM, BN);
 }
 
 int run_gconv(GArgs& a, const Plan& p, float* ws, size_t ws_floats, hipStream_t st, int precision = 0) {
@@ -2109,7 +2544,7 @@ extern "C" int srx_conv2d_stat_rows(const srx_conv2d_t* d) {
 }
 
 // which: 0 = forward, 1 = data gradient.  out[6] = {BM, BN, tail split, workgroups, KS, multi}
-// (multi = 1: the stride-parity classes run as one gconv_multi_kernel launch)
+// (multi = 1: the stride-parity classes run as one gconv_multi_kernel launch; 2: as one gconv_s2f_kernel launch)
 extern "C" int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out) {
   if (int rc = check_desc(d)) return rc;
   SRX_REQUIRE(out, "conv2d_plan: null pointer");
@@ -2136,10 +2571,19 @@ extern "C" int srx_conv2d_plan(const srx_conv2d_t* d, int which, int* out) {
         m.g[m.n++].Kp = cls[i].Kp;
       }
       p = Plan{};
-      multi_tile(m, pad_rows(d->Cin), p.BM, p.BN, d->precision != 0);
-      p.split = 1; p.ks = 1; p.tail = 0;
-      for (int i = 0; i < m.n; ++i) p.full += (int)srx_cdiv(m.g[i].M, p.BM) * (int)srx_cdiv(d->Cin, p.BN);
-      multi = 1;
+      const float t_multi = multi_tile(m, pad_rows(d->Cin), p.BM, p.BN, p.ks, d->precision != 0);
+      p.split = 1; p.tail = 0;
+      int fbm = 0, fbn = 0;
+      const bool fused = m.n == nc && s2f_eligible(d, cls, nc) &&
+                         (0.97f * s2f_tile(d, cls, nc, fbm, fbn) < t_multi || (srx_dev().s2_mode & 4)) && fbm > 0;
+      if (fused) {  // (multi = 2: all classes of a tile in one workgroup, gconv_s2f_kernel)
+        p.BM = fbm; p.BN = fbn; p.ks = 1;
+        p.full = (int)srx_cdiv(m.g[0].M, fbm) * (pad_rows(d->Cin) / fbn);
+        multi = 2;
+      } else {
+        for (int i = 0; i < m.n; ++i) p.full += (int)srx_cdiv(m.g[i].M, p.BM) * (int)srx_cdiv(d->Cin, p.BN);
+        multi = 1;
+      }
     } else {
       p = bwd_plan(d, cls[0]);
     }
@@ -2505,9 +2949,15 @@ static int conv_bwd_data_impl(const srx_conv2d_t* d, const float* dy, const floa
     }
   }
   if (multi.n > 0) {
-    int bm, bn;
-    multi_tile(multi, pad_rows(d->Cin), bm, bn, d->precision != 0);
-    if (int rc = run_gconv_multi(multi, bm, bn, st, d->precision)) return rc;
+    int bm, bn, ks;
+    const float t_multi = multi_tile(multi, pad_rows(d->Cin), bm, bn, ks, d->precision != 0);
+    if (multi.n == nc && s2f_eligible(d, cls, nc)) {  // all classes of a tile in one workgroup, when that is the shorter launch
+      int fbm, fbn;
+      const float t_fused = s2f_tile(d, cls, nc, fbm, fbn);
+      if (fbm > 0 && (0.97f * t_fused < t_multi || (srx_dev().s2_mode & 4)))  // (a tie goes to the fused launch: measured)
+        return run_gconv_s2f(d, multi.g[0], cls, nc, wpk_bwd, total, fbm, fbn, st);
+    }
+    if (int rc = run_gconv_multi(multi, bm, bn, ks, st, d->precision)) return rc;
   }
   return SRX_OK;
 }
