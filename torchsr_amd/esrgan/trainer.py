@@ -37,6 +37,10 @@ class ESRGANTrainer(SRGANTrainer):
 
     def _phase_disc(self) -> None:
         """esrgan/trainer.py:444-455 (optimizer step is issued by ``_phase_gen`` after the all-reduce)."""
+        self._phase_disc_gen()
+        self._phase_disc_loss()
+
+    def _phase_disc_gen(self) -> None:
         # the three networks exchange NHWC tensors (as in the SRGAN trainer): the batch is converted once, the super-resolved
         # image never goes through the NCHW module boundary
         with torch.no_grad():
@@ -49,6 +53,8 @@ class ESRGANTrainer(SRGANTrainer):
         # the generator update (as the reference's own SRGAN loop does, srgan/trainer.py:444,455-456): 587 GFLOP and
         # ~700 launches per step that change no result.
         self._super_res = self.generator.forward_nhwc(low4)                      # :447 (and :462)
+
+    def _phase_disc_loss(self) -> None:
         # :448-453 -- D(real), D(fake) as one batch; both relativistic terms and their mean in the head's launch
         disc_loss, _ = self.discriminator.pair_loss_nhwc(self._high4, self._super_res.detach())
         self._backward(disc_loss)                                                # :455

@@ -33,6 +33,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from .. import _dev
 from .. import functional as F
 from ..ddp import BackwardCuts, GradBuckets, broadcast_module
 from ..layers import no_weight_grad, set_conv_precision
@@ -500,11 +501,17 @@ class SRGANTrainer:
         parallel: the classifier's gradients are complete then, the convolutions' follow in ``_phase_disc_body``)."""
         # the three networks exchange NHWC tensors directly: the batch is converted once, the super-resolved image
         # never goes through the NCHW module boundary (8 layout passes forward, 4 backward in the reference's call form)
+        self._phase_disc_gen()
+        self._phase_disc_loss()
+
+    def _phase_disc_gen(self) -> None:
         with torch.no_grad():
             low4 = F.to_nhwc(self._static['low_res'], 4)
             self._high4 = F.to_nhwc(self._static['high_res'], 4)
         self.disc_optimizer.zero_grad()                                      # :442
         self._super_res = self.generator.forward_nhwc(low4)                  # :444
+
+    def _phase_disc_loss(self) -> None:
         # :446-448 -- D(real) and D(fake) as one batch; classifier tail, Sigmoid, both BCE terms and their sum are one launch
         # forward and one backward (functional.gan_head)
         disc_loss, _ = self.discriminator.pair_loss_nhwc(self._high4, self._super_res.detach())
@@ -536,11 +543,35 @@ class SRGANTrainer:
         self._resume('g.tail')
 
     def _gan_all(self) -> None:
-        self._phase_disc()
-        self._phase_content()
+        if _dev.NO_OVERLAP or self.device.type != 'cuda':
+            self._phase_disc()
+            self._phase_content()
+        else:
+            # Two branches of ONE captured graph.  The perceptual loss (trainer.py:455) needs the generator's output and the
+            # targets, nothing of the discriminator: its VGG19 forward runs on a side stream next to the discriminator's whole
+            # update (forward on real + fake, backward, weight gradients), and -- autograd runs a node on the stream of its
+            # forward -- its backward runs next to the adversarial term's data gradients through the discriminator.  Every
+            # launch of either branch is cut for the whole chip; what the second branch buys is the other branch's idle
+            # slots: partly filled last rounds, prologues and epilogues, the boundary between dependent launches.  Same
+            # kernels on the same operands: the step's results do not change by a bit.
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            self._phase_disc_gen()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._phase_content()
+            self._phase_disc_loss()
+            main.wait_stream(side)
+            self._content.record_stream(main)
         self._phase_gen()
         self.gen_optimizer.step()                                            # :469
         self._push_loss('gan/train-loss')
+
+    def _side_stream(self):
+        s = self.__dict__.get('_side')
+        if s is None:
+            s = self._side = torch.cuda.Stream(device=self.device)
+        return s
 
     def gan_step(self, low_res: Tensor, high_res: Tensor) -> Dict[str, Tensor]:
         """One full GAN step (``_gan_loop`` without the logging); returns device loss tensors."""
