@@ -15,3 +15,4 @@ NO_T9 = _on('SRX_NO_T9')                        # bf16 inference: the 9x9 output
 NO_WINO = _on('SRX_NO_WINO')                    # VGG19's wide 3x3 layers on the direct gather-GEMM instead of Winograd F(2x2, 3x3)
 NO_BF16S = _on('SRX_NO_BF16S')                  # frozen conv stacks under autocast: fp32-stored activations (round 4's path) instead of bf16 storage
 NO_OVERLAP = _on('SRX_NO_OVERLAP')              # single-graph GAN step: the perceptual-loss branch on the main stream (no second graph branch)
+FWD_OVERLAP_ONLY = _on('SRX_FWD_OVERLAP_ONLY')  # ... only the perceptual loss's FORWARD on the side stream (its backward where autograd puts it)

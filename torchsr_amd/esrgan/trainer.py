@@ -23,6 +23,9 @@ from .generator import Generator
 
 class ESRGANTrainer(SRGANTrainer):
     phase_prefix = 'esrgan'
+    # three gradients meet at the generator's output (pixel, perceptual, adversarial): summing them in another order than autograd
+    # moves last bits, and the backward on the side stream bought nothing here (10.14 vs 10.13 ms): forward only
+    deep_overlap = False
     generator_cls = Generator
     discriminator_cls = Discriminator
     amp_phases = ('psnr', 'gan')          # esrgan/trainer.py:384 and :446,461

@@ -133,6 +133,9 @@ class SRGANTrainer:
     """
 
     phase_prefix = 'srgan'
+    # single-graph GAN step: the perceptual loss's BACKWARD on the side stream too (``_gan_all``).  Exact here -- two gradients meet
+    # at the generator's output and a two-term sum has one rounding whatever its order
+    deep_overlap = True
     generator_cls = Generator
     discriminator_cls = Discriminator
     amp_phases = ('psnr',)  # phases the reference wraps in amp.autocast (trainer.py:382); the GAN loop is fp32
@@ -546,24 +549,51 @@ class SRGANTrainer:
         if _dev.NO_OVERLAP or self.device.type != 'cuda':
             self._phase_disc()
             self._phase_content()
-        else:
-            # Two branches of ONE captured graph.  The perceptual loss (trainer.py:455) needs the generator's output and the
-            # targets, nothing of the discriminator: its VGG19 forward runs on a side stream next to the discriminator's whole
-            # update (forward on real + fake, backward, weight gradients), and -- autograd runs a node on the stream of its
-            # forward -- its backward runs next to the adversarial term's data gradients through the discriminator.  Every
-            # launch of either branch is cut for the whole chip; what the second branch buys is the other branch's idle
-            # slots: partly filled last rounds, prologues and epilogues, the boundary between dependent launches.  Same
-            # kernels on the same operands: the step's results do not change by a bit.
-            main = torch.cuda.current_stream()
-            side = self._side_stream()
-            self._phase_disc_gen()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self._phase_content()
-            self._phase_disc_loss()
+            self._phase_gen()
+            self.gen_optimizer.step()                                        # :469
+            self._push_loss('gan/train-loss')
+            return
+        # Two branches of ONE captured graph.  The perceptual loss (trainer.py:455) needs the generator's output and the
+        # targets, nothing of the discriminator -- and its gradient needs nothing either: d gen_loss / d content is the root
+        # gradient itself.  So the whole VGG19 round trip (forward, L1, backward down to the generator's output) runs on a side
+        # stream, on a detached leaf of the super-resolved batch, next to the discriminator's update (forward on real + fake,
+        # backward, weight gradients, Adam) AND the adversarial term's pass through the updated discriminator; the two
+        # gradients arriving at the generator's output are added where autograd would have added them, and the generator's
+        # backward runs once.  Every launch of either branch is cut for the whole chip; what the second branch buys is the
+        # other branch's idle slots: partly filled last rounds, prologues and epilogues, the boundary between dependent
+        # launches.  Same kernels on the same operands, the same two-term sum: the step's results do not change by a bit
+        # (tools/overlap_check.py).
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        self._phase_disc_gen()
+        sr = self._super_res
+        deep = self.deep_overlap and not _dev.FWD_OVERLAP_ONLY
+        sr_v = sr.detach().requires_grad_(True) if deep else sr
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._super_res = sr_v
+            self._phase_content()
+            content = self._content
+            fwd_done = torch.cuda.Event()
+            fwd_done.record(side)
+            if deep:
+                self._backward(content)           # VGG19 backward: d content / d sr_v, on the side stream
+        self._super_res = sr
+        self._phase_disc_loss()
+        if not deep:
             main.wait_stream(side)
-            self._content.record_stream(main)
-        self._phase_gen()
+            content.record_stream(main)
+            self._phase_gen()
+        else:
+            main.wait_event(fwd_done)             # the adversarial head adds the content VALUE to its term: forward only
+            content.record_stream(main)
+            sr_d = sr.detach().requires_grad_(True)
+            self._super_res, self._content = sr_d, content.detach()
+            self._phase_gen()                     # D update, adversarial term through the updated D, backward down to sr_d
+            main.wait_stream(side)
+            sr_v.grad.record_stream(main)
+            with F.deferred_weight_grads():
+                sr.backward(sr_d.grad + sr_v.grad)
         self.gen_optimizer.step()                                            # :469
         self._push_loss('gan/train-loss')
 
