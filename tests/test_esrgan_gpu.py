@@ -405,6 +405,27 @@ def test_esrgan_step_is_bitwise_reproducible(dev):
             assert torch.equal(a[k], b[k]), k
 
 
+def test_esrgan_two_branch_graph_equals_the_single_stream_step(dev):
+    """ESRGAN's captured step runs the perceptual loss's FORWARD (esrgan/trainer.py:458-459) on a second graph branch next to
+    the discriminator's update; its backward stays where autograd puts it (a three-term sum at the generator's output keeps
+    its order).  Four steps with and without the second branch: bit-identical losses and parameters."""
+    gold = np.load(os.path.join(GOLDEN, 'esrgan.npz'))
+    lr, hr = torch.from_numpy(gold['low_res']).to(dev), torch.from_numpy(gold['high_res']).to(dev)
+    runs = []
+    for overlap in (True, False):
+        t = make_trainer(dev, disable_amp=False, use_graphs=True)
+        t.overlap_branches = overlap
+        losses = [[v.item() for _k, v in sorted(t.gan_step(lr, hr).items())] for _step in range(4)]
+        assert 'gan.all' in t._graphs
+        runs.append((losses, {k: v.clone() for k, v in t.generator.state_dict().items()},
+                     {k: v.clone() for k, v in t.discriminator.state_dict().items()}))
+        del t
+    assert runs[0][0] == runs[1][0]
+    for a, b in ((runs[0][1], runs[1][1]), (runs[0][2], runs[1][2])):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize('bf16', [False, True])
 def test_rrdb_modules_alone_equal_the_trunk_node(dev, bf16):
     """`ResidualInResidualDenseBlock` / `ResidualDenseBlock` called directly (esrgan/residual.py:65-86,110-129: one

@@ -348,6 +348,27 @@ def test_step_is_bitwise_reproducible(dev):
             assert torch.equal(a[k], b[k]), k
 
 
+def test_two_branch_graph_equals_the_single_stream_step(dev):
+    """The captured GAN step runs the perceptual-loss round trip (trainer.py:455 and its share of :468) on a second graph
+    branch next to the discriminator's update (``SRGANTrainer._gan_all``).  Same launches on the same operands and a two-term
+    sum where autograd had one: five BASELINE-size steps with and without the second branch agree to the last bit."""
+    torch.manual_seed(6)
+    lr, hr = torch.rand(16, 3, 24, 24, device=dev), torch.rand(16, 3, 96, 96, device=dev)
+    runs = []
+    for overlap in (True, False):
+        t = make_trainer(dev, True, batch=16)
+        t.overlap_branches = overlap
+        losses = [[v.item() for _k, v in sorted(t.gan_step(lr, hr).items())] for _step in range(5)]
+        assert 'gan.all' in t._graphs
+        runs.append((losses, {k: v.clone() for k, v in t.generator.state_dict().items()},
+                     {k: v.clone() for k, v in t.discriminator.state_dict().items()}))
+        del t
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for a, b in ((runs[0][1], runs[1][1]), (runs[0][2], runs[1][2])):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_pack_tables_take_over_after_the_first_step(dev):
     """After the first optimiser step every conv of G / D is repacked by one table launch per model
     (functional.PackTable) and the lazy per-layer pack finds its key current."""

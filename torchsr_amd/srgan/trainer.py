@@ -136,6 +136,9 @@ class SRGANTrainer:
     # single-graph GAN step: the perceptual loss's BACKWARD on the side stream too (``_gan_all``).  Exact here -- two gradients meet
     # at the generator's output and a two-term sum has one rounding whatever its order
     deep_overlap = True
+    # False: the perceptual-loss branch on the main stream (same launches one after the other, same results).  bench.py's
+    # instrumented eager pass sets it so that every event pair of the launch profiler brackets a kernel that has the chip alone
+    overlap_branches = True
     generator_cls = Generator
     discriminator_cls = Discriminator
     amp_phases = ('psnr',)  # phases the reference wraps in amp.autocast (trainer.py:382); the GAN loop is fp32
@@ -546,7 +549,7 @@ class SRGANTrainer:
         self._resume('g.tail')
 
     def _gan_all(self) -> None:
-        if _dev.NO_OVERLAP or self.device.type != 'cuda':
+        if _dev.NO_OVERLAP or not self.overlap_branches or self.device.type != 'cuda':
             self._phase_disc()
             self._phase_content()
             self._phase_gen()
