@@ -1832,6 +1832,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_rows_kernel(const float* __r
   if (rows_lo) {  // (no PixelShuffle on paired problems)
     if (np < rows_lo) { Cin = outs.cin_lo; } else { np -= rows_lo; dw = outs.dw_hi[o]; dbp = outs.db_hi[o]; }
   }
+  int co = np;
+  if (shuffle_cps) { const int ij = np / shuffle_cps, cc = np - ij * shuffle_cps; co = cc * 4 + ij; }
+  const int T = KH * KW, nE = Cin * T;
+  float* __restrict__ orow = dw + (size_t)co * Cin * T;
+  // round 6: a workgroup lives for three dependent round trips (slab rows, then -- accumulating -- the gradient's old values, then
+  // the bias slabs one after the other in thread 0) and moves ~17 KB; the old values and the bias column are requested FIRST, next
+  // to the slab rows.  Same sums in the same order.
+  constexpr int PRE = 8;  // old values held in registers (Cin * T <= 2048: every layer of the two models)
+  float oldv[PRE];
+#pragma unroll
+  for (int i = 0; i < PRE; ++i) {
+    const int e = tid + 256 * i;
+    oldv[i] = (accumulate && e < nE) ? orow[e] : 0.f;
+  }
+  // bias gradient of this row: the slabs' column sums, one slab per lane of the last wave (summed in slab order below)
+  float bpart = 0.f;
+  const bool bias_wave = dbp != nullptr && tid >= 192;
+  if (bias_wave && nslab <= 64 && tid - 192 < nslab) bpart = bslab_all[((size_t)o * nslab + (tid - 192)) * Cnw + srow];
   // (four consecutive k per thread, 16-byte loads: K and the slab pitch Kw are multiples of 4; with one float per thread the pass was
   // bound by the few bytes it kept in flight, not by its stores: 27 us per launch either way)
   for (int k = 4 * tid; k < K; k += 1024) {
@@ -1847,21 +1865,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_rows_kernel(const float* __r
     for (; z < nslab; ++z) s0 += *reinterpret_cast<const f32x4*>(sp + (size_t)z * zs);
     *reinterpret_cast<f32x4*>(rsum + k) = ((s0 + s1) + (s2 + s3)) * scale;
   }
-  if (tid == 0 && dbp) {  // bias gradient of this row: the slabs' column sums
-    const float* __restrict__ bslab = bslab_all + (size_t)o * nslab * Cnw + srow;
+  if (bias_wave) {
     float s = 0.f;
-    for (int z = 0; z < nslab; ++z) s += bslab[(size_t)z * Cnw];
-    s *= scale;
-    int bi = np;
-    if (shuffle_cps) { const int ij = srow / shuffle_cps, cc = srow - ij * shuffle_cps; bi = cc * 4 + ij; }
-    dbp[bi] = accumulate ? dbp[bi] + s : s;
+    if (nslab <= 64) {
+      for (int z = 0; z < nslab; ++z) s += __shfl(bpart, z, 64);
+    } else {
+      const float* __restrict__ bslab = bslab_all + (size_t)o * nslab * Cnw + srow;
+      for (int z = 0; z < nslab; ++z) s += bslab[(size_t)z * Cnw];
+    }
+    if (tid == 192) {
+      s *= scale;
+      int bi = np;
+      if (shuffle_cps) { const int ij = srow / shuffle_cps, cc = srow - ij * shuffle_cps; bi = cc * 4 + ij; }
+      dbp[bi] = accumulate ? dbp[bi] + s : s;
+    }
   }
   __syncthreads();
-  int co = np;
-  if (shuffle_cps) { const int ij = np / shuffle_cps, cc = np - ij * shuffle_cps; co = cc * 4 + ij; }
-  const int T = KH * KW;
-  float* __restrict__ orow = dw + (size_t)co * Cin * T;
-  for (int e = tid; e < Cin * T; e += 256) {
+#pragma unroll
+  for (int i = 0; i < PRE; ++i) {
+    const int e = tid + 256 * i;
+    if (e < nE) {
+      const int ci = e / T, tap = e - ci * T;
+      const float v = rsum[tap * Ck + ci];
+      orow[e] = accumulate ? oldv[i] + v : v;
+    }
+  }
+  for (int e = tid + 256 * PRE; e < nE; e += 256) {
     const int ci = e / T, tap = e - ci * T;
     const float v = rsum[tap * Ck + ci];
     orow[e] = accumulate ? orow[e] + v : v;
