@@ -23,8 +23,15 @@
 // launches it replaces; 1944 MFMAs per workgroup = 7.4 us of matrix time per SIMD, the rest is the patch staging (2.9 us),
 // the four epilogues (4 us), 20 barriers and LDS reads that are 36 % bank-conflict cycles (region rows of 16..8 pixels
 // in images of 18..10 pixels pitch: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r03_pmc_rdb.txt).
-// 64-byte LDS rows (32 bf16 channels); the 16-byte quad j of row r sits at quad j ^ ((r >> 2) & 3): sixteen consecutive
-// rows then cover all 64 banks once per ds_read_b128 lane group.
+// 64-byte LDS rows (32 bf16 channels).  Weight rows: the 16-byte quad j of row r sits at quad j ^ ((r >> 2) & 3) -- sixteen
+// consecutive rows cover all 64 banks, and the lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same
+// + 32: MI355X_MICROARCH.md, LDS) each see sixteen rows that are consecutive mod 16.  Activation images (round 6): quad j of pixel
+// (y, x) sits at j ^ (y & 3), and a 32-pixel MFMA tile is 8 x 4 pixels with each lane group on one 4 x 4 block (tile_pixel): the
+// 16-byte slot of a read is 4 ((y pitch + x) mod 4) + (j ^ (y & 3)), every image pitch is even, so ANY 4 x 4 block of ANY image --
+// whatever the tap, the region's offset in the source and the pitch -- touches sixteen different slots: conflict-free fragment
+// reads for all (region, source) pairs of the five convs without padding an image (LDS has 3 KB to spare) or splitting a weight
+// unit.  Before: linear 32-pixel runs of a 16..10-pixel-wide region in an 18..10-pixel pitch, 42 % of the LDS cycles conflicts
+// (profiles/r05_rdb_ablation.txt).
 #include "srx_common.h"
 #include <mutex>
 
@@ -155,7 +162,36 @@ __device__ __forceinline__ void dma_wait(int wave_l) {
 __device__ __forceinline__ void rdb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // conv K: pixel tiles of 32, channel tiles of 32; a compute wave takes TPW consecutive pixel tiles of one channel tile
-template <int K> __host__ __device__ constexpr int m_tiles() { return (reg_w(K) * reg_w(K) + 31) / 32; }
+// pixel tiles of conv K's region: 8 x 4 pixels each; the 10 x 10 region of conv 4 would need six of them on four waves, so it
+// takes two 8 x 4 tiles and packs the L-shaped rest into two more (tile_pixel)
+template <int K> __host__ __device__ constexpr int m_tiles() { return K == 4 ? 4 : ((reg_w(K) + 7) / 8) * ((reg_w(K) + 3) / 4); }
+// lane (l31 = lane & 31) of pixel tile mt -> its pixel (qx, qy) of the region; false: the lane has no pixel (coordinates are then
+// clamped into the region: it reads what a neighbour reads and stores nothing).  Row = l31 >> 3; the four-lane runs of a row are
+// dealt to the left / right 4 x 4 block so that the hardware's ds_read_b128 lane groups each own one block (mask 0x96: lanes
+// 0-3, 12-15, 20-27 left, 4-11, 16-19, 28-31 right).
+template <int K>
+__device__ __forceinline__ bool tile_pixel(int mt, int l31, int& qx, int& qy) {
+  constexpr int WK = reg_w(K);
+  const int r = l31 >> 3, right = (0x96 >> (l31 >> 2)) & 1, c = (l31 & 3) + 4 * right;
+  if constexpr (K == 4) {
+    if (mt < 2) { qx = c; qy = 4 * mt + r; return true; }
+    const int idx = 4 * r + (l31 & 3);  // 0..15 inside the lane group
+    if (mt == 2) {  // rows 8, 9 x columns 0..7 (left group) and columns 8, 9 x rows 0..7 (right group): two-way conflicts here
+      qx = right ? 8 + (idx & 1) : (idx & 7);
+      qy = right ? (idx >> 1) : 8 + (idx >> 3);
+      return true;
+    }
+    qx = 8 + (idx & 1); qy = 8 + ((idx >> 1) & 1);  // the corner
+    return !right && idx < 4;
+  } else {
+    constexpr int TX = (WK + 7) / 8;
+    const int tx = mt % TX, ty = mt / TX;
+    qx = 8 * tx + c; qy = 4 * ty + r;
+    const bool ok = qx < WK && qy < WK;
+    qx = min(qx, WK - 1); qy = min(qy, WK - 1);
+    return ok;
+  }
+}
 template <int K> __host__ __device__ constexpr int n_tiles() { return conv_n(K) / 32; }
 template <int K> __host__ __device__ constexpr int tpw() { return (m_tiles<K>() * n_tiles<K>() + NCOMPUTE - 1) / NCOMPUTE; }
 // wave -> (first pixel tile, channel tile, number of tiles)
@@ -173,17 +209,23 @@ __device__ __forceinline__ void job(int wave, int& mt0, int& nt, int& cnt) {
 // stage epilogues (no conversion, no LDS image of the next source, no global stores): results are garbage in all three.
 template <int K, int S, int U, int ABL>
 __device__ __forceinline__ void mma_unit(const unsigned char* lds, Wave& w) {
-  constexpr int NK = conv_n(K), WS = src_w(S), WK = reg_w(K), RK = WK * WK, TPW = tpw<K>();
+  constexpr int NK = conv_n(K), WS = src_w(S), TPW = tpw<K>();
   constexpr int D = reg_org(K) - src_org(S) - 1;  // source coordinate of tap (0,0) = region coordinate + D
   int mt0, nt, cnt;
   job<K>(w.wave, mt0, nt, cnt);
   if (cnt == 0) return;
-  int bp[TPW];
+  // byte offset of the fragment (tile i, tap row th, k-half kk) inside the source image; the tap column is an immediate
+  int ao[TPW][3][2];
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
-    const int q = min((mt0 + i) * 32 + w.l31, RK - 1);
-    const int qy = q / WK, qx = q - qy * WK;
-    bp[i] = (qy + D) * WS + qx + D;
+    int qx, qy;
+    tile_pixel<K>(mt0 + i, w.l31, qx, qy);
+#pragma unroll
+    for (int th = 0; th < 3; ++th) {
+      const int sy = qy + D + th;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) ao[i][th][kk] = (sy * WS + qx + D) * 64 + (((kk * 2 + w.h) ^ (sy & 3)) << 4);
+    }
   }
   const int nrow = nt * 32 + w.l31;
   const unsigned char* wrow = lds + OFF_W + unit_slot(U) * SLOT_BYTES + nrow * 64;
@@ -202,7 +244,7 @@ __device__ __forceinline__ void mma_unit(const unsigned char* lds, Wave& w) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) w.acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one, one, w.acc[i], 0, 0, 0);
     }
-    (void)wrow; (void)act; (void)wsw; (void)bp;
+    (void)wrow; (void)act; (void)wsw; (void)ao;
     return;
   }
   auto fetch = [&](int t, int set) {
@@ -211,11 +253,9 @@ __device__ __forceinline__ void mma_unit(const unsigned char* lds, Wave& w) {
       wf[set][kk] = *reinterpret_cast<const bf16x8*>(wrow + t * NK * 64 + (((kk * 2 + w.h) ^ wsw) << 4));
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-      const int p = bp[i] + (t / 3) * WS + (t % 3);
-      const int psw = (p >> 2) & 3;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
-        xf[set][i][kk] = *reinterpret_cast<const bf16x8*>(act + p * 64 + (((kk * 2 + w.h) ^ psw) << 4));
+        xf[set][i][kk] = *reinterpret_cast<const bf16x8*>(act + ao[i][t / 3][kk] + (t % 3) * 64);
     }
   };
   fetch(0, 0);
@@ -259,13 +299,13 @@ __device__ __forceinline__ void mma_unit(const unsigned char* lds, Wave& w) {
 // loads, out-of-image lanes discard)
 template <int K>
 __device__ __forceinline__ void load_masks(const RdbArgs& a, const Wave& w, f32x4 (&m)[2][4]) {
-  constexpr int WK = reg_w(K), RK = WK * WK, ORG = reg_org(K), TPW = tpw<K>(), CH = 64 + 32 * (4 - K);
+  constexpr int ORG = reg_org(K), TPW = tpw<K>(), CH = 64 + 32 * (4 - K);
   int mt0, nt, cnt;
   job<K>(w.wave, mt0, nt, cnt);
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
-    const int q = min((mt0 + i) * 32 + w.l31, RK - 1);
-    const int qy = q / WK, qx = q - qy * WK;
+    int qx, qy;
+    tile_pixel<K>(mt0 + i, w.l31, qx, qy);
     const int iy = min(max(w.ty0 + qy + ORG, 0), a.H - 1), ix = min(max(w.tx0 + qx + ORG, 0), a.W - 1);
     const float* mp = a.buf + ((size_t)(w.n_img * a.H + iy) * a.W + ix) * a.bld + CH + 4 * w.h;
 #pragma unroll
@@ -275,7 +315,7 @@ __device__ __forceinline__ void load_masks(const RdbArgs& a, const Wave& w, f32x
 
 template <int K, bool BWD>
 __device__ __forceinline__ void epilogue_mid(const RdbArgs& a, unsigned char* lds, Wave& w, const f32x4 (&masks)[2][4]) {
-  constexpr int WK = reg_w(K), RK = WK * WK, ORG = reg_org(K), TPW = tpw<K>();
+  constexpr int WK = reg_w(K), ORG = reg_org(K), TPW = tpw<K>();
   constexpr int CH = BWD ? 64 + 32 * (4 - K) : 64 + 32 * (K - 1);  // channel slot of this stage's tensor in buf / gout
   int mt0, nt, cnt;
   job<K>(w.wave, mt0, nt, cnt);
@@ -287,9 +327,9 @@ __device__ __forceinline__ void epilogue_mid(const RdbArgs& a, unsigned char* ld
   }
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
-    const int q = (mt0 + i) * 32 + w.l31;
-    if (i >= cnt || q >= RK) continue;
-    const int qy = q / WK, qx = q - qy * WK;
+    int qx, qy;
+    if (!tile_pixel<K>(mt0 + i, w.l31, qx, qy) || i >= cnt) continue;
+    const int q = qy * WK + qx;
     const int oy = qy + ORG, ox = qx + ORG;
     const int iy = w.ty0 + oy, ix = w.tx0 + ox;
     const bool in_img = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
@@ -297,7 +337,7 @@ __device__ __forceinline__ void epilogue_mid(const RdbArgs& a, unsigned char* ld
     const size_t pix = (size_t)(w.n_img * a.H + min(max(iy, 0), a.H - 1)) * a.W + min(max(ix, 0), a.W - 1);
     float* gp = (BWD ? a.gout + pix * a.gld : a.buf + pix * a.bld) + CH + 4 * w.h;
     unsigned char* cp = lds + src_off(K + 1) + q * 64 + 8 * w.h;
-    const int psw = (q >> 2) & 3;
+    const int psw = qy & 3;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 v;
@@ -325,8 +365,8 @@ __device__ __forceinline__ void epilogue_out(const RdbArgs& a, const unsigned ch
   int mt0, nt, cnt;
   job<5>(w.wave, mt0, nt, cnt);
   if (cnt == 0) return;
-  const int q = mt0 * 32 + w.l31;  // < 64
-  const int qy = q / RT, qx = q - qy * RT;
+  int qx, qy;
+  tile_pixel<5>(mt0, w.l31, qx, qy);  // (8 x 8: every lane has a pixel)
   const int iy = w.ty0 + qy, ix = w.tx0 + qx;
   if (!((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)) return;
   const size_t pix = (size_t)(w.n_img * a.H + iy) * a.W + ix;
@@ -355,8 +395,8 @@ template <bool BWD>
 __device__ __forceinline__ void load_skip(const RdbArgs& a, const Wave& w, f32x4 (&xs)[4], f32x4 (&ex)[4]) {
   int mt0, nt, cnt;
   job<5>(w.wave, mt0, nt, cnt);
-  const int q = mt0 * 32 + w.l31;
-  const int qy = q / RT, qx = q - qy * RT;
+  int qx, qy;
+  tile_pixel<5>(min(mt0, m_tiles<5>() - 1), w.l31, qx, qy);
   const int iy = min(w.ty0 + qy, a.H - 1), ix = min(w.tx0 + qx, a.W - 1);  // (clamped: stores are masked, loads are not)
   const size_t pix = (size_t)(w.n_img * a.H + iy) * a.W + ix;
   const float* xp = (BWD ? a.skip + pix * a.skip_ld : a.src + pix * a.ld) + 32 * min(nt, 1) + 4 * w.h;
@@ -453,7 +493,7 @@ __global__ __launch_bounds__(NTHREADS) void rdb_kernel(const RdbArgs a) {
       if constexpr (BWD) { v0 *= a.scale; v1 *= a.scale; }  // g5 = scale * dy, rounded after the product (as autograd hands it on)
       const bf16x8 pk = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3],
                          (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
-      *reinterpret_cast<bf16x8*>(lds + (g >> 2) * (PW * PW * 64) + p * 64 + (((g & 3) ^ ((p >> 2) & 3)) << 4)) = pk;
+      *reinterpret_cast<bf16x8*>(lds + (g >> 2) * (PW * PW * 64) + p * 64 + (((g & 3) ^ ((p / PW) & 3)) << 4)) = pk;
     }
   }
   if constexpr (!BWD) {
