@@ -13,7 +13,8 @@
 //     of the bf16 MFMA peak that is free); pixels outside the image are stored as the zeros the next conv's padding reads.
 //   * weights come as bf16 tiles pre-swizzled for the LDS image (srx_rdb_pack, once per optimiser step for all blocks):
 //     one unit = one 32-channel source x 9 taps x all output channels (18 / 36 KB).  Waves 4..7 stream them by LDS-DMA into
-//     a ring of four 18 KB slots, three units ahead (conv 5's 36 KB units: one ahead); ONE barrier per unit, 20 units per block.
+//     a ring of four 18 KB slots, one GROUP of units (two 18 KB units, or one 36 KB unit of conv 5) ahead; ONE barrier per group,
+//     14 groups per block (round 6; before: one barrier per unit, 20 per block).
 //   * waves 0..3 (one per SIMD) multiply: a wave owns up to two 32-pixel x 32-channel output tiles of the current conv and
 //     reads every weight fragment once for both; fragments are requested two taps ahead, reads and address arithmetic
 //     interleaved with the MFMAs (sched_group_barrier).  Operands are (weights as A, pixels as B) so that a lane ends
@@ -71,12 +72,25 @@ constexpr int SLOT_BYTES = 9 * 32 * 64;         // 18432: a unit of conv 1..4; c
 constexpr int NSLOT = 4;
 constexpr int OFF_W = ACT_BYTES;
 constexpr int OFF_BIAS = OFF_W + NSLOT * SLOT_BYTES;
-// The weight ring (round 4, second step): four 18 KB slots.  A unit of conv 1..4 sits in slot u % 4 and is requested THREE
-// units before it is multiplied (at the barrier that opens unit u - 3 the slot's previous tenant, unit u - 4, has just been
-// finished); conv 5's 36 KB units alternate between the slot pairs {2,3} and {0,1} and stay one unit ahead, as before.  With
-// one unit ahead every barrier waited for an L2 round trip of the weight stream (~0.55 us x 20; the MFMAs of a small unit
-// take 0.27-0.55 us).
-__host__ __device__ constexpr int unit_slot(int u) { return u < 14 ? u % NSLOT : ((u & 1) ? 0 : 2); }
+// The weight ring: four 18 KB slots = two halves.  Round 6: the units are multiplied in GROUPS -- two 18 KB units of one conv, or a
+// single unit where a conv has an odd count (its last, which carries the epilogue), or one 36 KB unit of conv 5 -- and a group
+// fills one half of the ring; the halves alternate.  ONE barrier per group (14 instead of 20): at the barrier that opens group g
+// the half of group g - 1 is free and group g + 1 is requested into it, to be multiplied one group later; the two units of a group
+// run as ONE 18-tap pipeline.  In-kernel stamps had put ~600-780 cycles of every unit outside its MFMAs: the fragment reads of
+// its first two taps (nothing of a unit can be read before its barrier), the drain of its last MFMAs and the rendezvous itself.
+// (Round 4's ring had every unit in a slot of its own, requested three units ahead with counted vmcnt waits.)
+constexpr int NGROUPS = 14;
+__host__ __device__ constexpr int grp_first(int g) {
+  constexpr int first[NGROUPS + 1] = {0, 2, 4, 5, 7, 9, 11, 13, 14, 15, 16, 17, 18, 19, NUNITS};
+  return first[g];
+}
+__host__ __device__ constexpr int grp_count(int g) { return grp_first(g + 1) - grp_first(g); }
+__host__ __device__ constexpr int unit_group(int u) {
+  int g = 0;
+  while (grp_first(g + 1) <= u) ++g;
+  return g;
+}
+__host__ __device__ constexpr int unit_slot(int u) { return 2 * (unit_group(u) & 1) + (u - grp_first(unit_group(u))); }
 constexpr int LDS_BYTES = OFF_BIAS + 192 * 4;   // 160512
 constexpr int NTHREADS = 512;
 
@@ -207,63 +221,71 @@ __device__ __forceinline__ void job(int wave, int& mt0, int& nt, int& cnt) {
 // code is untouched): 1 = the MFMAs multiply constant registers, no fragment is read from LDS (what the block costs without
 // its LDS operand traffic); 2 = every fragment is read, no MFMA is issued (what the reads cost alone); 3 = ABL 0 without the
 // stage epilogues (no conversion, no LDS image of the next source, no global stores): results are garbage in all three.
-template <int K, int S, int U, int ABL>
-__device__ __forceinline__ void mma_unit(const unsigned char* lds, Wave& w) {
-  constexpr int NK = conv_n(K), WS = src_w(S), TPW = tpw<K>();
-  constexpr int D = reg_org(K) - src_org(S) - 1;  // source coordinate of tap (0,0) = region coordinate + D
-  int mt0, nt, cnt;
-  job<K>(w.wave, mt0, nt, cnt);
-  if (cnt == 0) return;
-  // byte offset of the fragment (tile i, tap row th, k-half kk) inside the source image; the tap column is an immediate
-  int ao[TPW][3][2];
+template <int K, int S>
+__device__ __forceinline__ void frag_offsets(const Wave& w, int mt0, int (&ao)[tpw<K>()][3][2]) {
+  constexpr int WS = src_w(S), D = reg_org(K) - src_org(S) - 1;  // source coordinate of tap (0,0) = region coordinate + D
+  constexpr int BASE = src_off(S);
 #pragma unroll
-  for (int i = 0; i < TPW; ++i) {
+  for (int i = 0; i < tpw<K>(); ++i) {
     int qx, qy;
     tile_pixel<K>(mt0 + i, w.l31, qx, qy);
 #pragma unroll
     for (int th = 0; th < 3; ++th) {
       const int sy = qy + D + th;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) ao[i][th][kk] = (sy * WS + qx + D) * 64 + (((kk * 2 + w.h) ^ (sy & 3)) << 4);
+      for (int kk = 0; kk < 2; ++kk) ao[i][th][kk] = BASE + (sy * WS + qx + D) * 64 + (((kk * 2 + w.h) ^ (sy & 3)) << 4);
     }
   }
+}
+// A group: units U0 .. U0 + NU - 1 = sources S0 .. of conv K, 9 NU taps in one software pipeline.
+template <int K, int S0, int NU, int U0, int ABL>
+__device__ __forceinline__ void mma_group(const unsigned char* lds, Wave& w) {
+  constexpr int NK = conv_n(K), TPW = tpw<K>(), NT = 9 * NU;
+  int mt0, nt, cnt;
+  job<K>(w.wave, mt0, nt, cnt);
+  if (cnt == 0) return;
+  // byte offset (from the start of LDS) of the fragment (unit, tile i, tap row th, k-half kk); the tap column is an immediate
+  int ao[NU][TPW][3][2];
+  frag_offsets<K, S0>(w, mt0, ao[0]);
+  if constexpr (NU > 1) frag_offsets<K, S0 + 1>(w, mt0, ao[NU - 1]);
+  constexpr int slot_first = unit_slot(U0), slot_last = unit_slot(U0 + NU - 1);
   const int nrow = nt * 32 + w.l31;
-  const unsigned char* wrow = lds + OFF_W + unit_slot(U) * SLOT_BYTES + nrow * 64;
+  const unsigned char* wrow = lds + OFF_W + nrow * 64;
   const int wsw = (nrow >> 2) & 3;
-  const unsigned char* act = lds + src_off(S);
   // fragments of tap t + 2 are requested before tap t is multiplied: the wave is alone on its SIMD and an LDS read
-  // under load (four waves reading, four writing the next weights) returns after ~250 cycles -- two taps of MFMAs
+  // under load (four waves reading, the next weights landing) returns after ~250 cycles -- two taps of MFMAs
   // (one tap ahead: 255 cycles per tap measured in-kernel, twice the MFMA time)
   bf16x8 wf[3][2], xf[3][TPW][2];
   if constexpr (ABL == 1) {  // constant operands: the matrix pipe alone
     const bf16x8 one = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int i = 0; i < TPW; ++i) w.acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one, one, w.acc[i], 0, 0, 0);
     }
-    (void)wrow; (void)act; (void)wsw; (void)ao;
+    (void)wrow; (void)wsw; (void)ao;
     return;
   }
-  auto fetch = [&](int t, int set) {
+  auto fetch = [&](int tt, int set) {
+    const int ui = tt / 9, t = tt - 9 * ui;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
-      wf[set][kk] = *reinterpret_cast<const bf16x8*>(wrow + t * NK * 64 + (((kk * 2 + w.h) ^ wsw) << 4));
+      wf[set][kk] = *reinterpret_cast<const bf16x8*>(wrow + (ui == 0 ? slot_first : slot_last) * SLOT_BYTES + t * NK * 64 + (((kk * 2 + w.h) ^ wsw) << 4));
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
-        xf[set][i][kk] = *reinterpret_cast<const bf16x8*>(act + ao[i][t / 3][kk] + (t % 3) * 64);
+        xf[set][i][kk] = *reinterpret_cast<const bf16x8*>(lds + ao[ui][i][t / 3][kk] + (t % 3) * 64);
     }
   };
   fetch(0, 0);
   fetch(1, 1);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    if (t + 2 < 9) fetch(t + 2, (t + 2) % 3);
+  for (int t = 0; t < NT; ++t) {
+    if (t + 2 < NT) fetch(t + 2, (t + 2) % 3);
     if constexpr (ABL == 2) {  // the reads alone: every fragment is consumed by an empty asm, nothing is multiplied
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -409,42 +431,42 @@ __device__ __forceinline__ void load_skip(const RdbArgs& a, const Wave& w, f32x4
   }
 }
 
-template <int U, bool BWD, int ABL>
-__device__ __forceinline__ void run_units(const RdbArgs& a, unsigned char* lds, Wave& w, int tid, f32x4 (&xs)[4],
-                                          f32x4 (&ex)[4]) {
-  constexpr int K = unit_conv(U), S = U - unit_first(K);
-  // unit U's weights (and, for S == 0, the previous conv's output image) are in LDS; unit U - 1's slot is free
+template <int G, bool BWD, int ABL>
+__device__ __forceinline__ void run_groups(const RdbArgs& a, unsigned char* lds, Wave& w, int tid, f32x4 (&xs)[4],
+                                           f32x4 (&ex)[4]) {
+  constexpr int U0 = grp_first(G), NU = grp_count(G), K = unit_conv(U0), S0 = U0 - unit_first(K), SL = S0 + NU - 1;
+  static_assert(unit_conv(U0 + NU - 1) == K, "a group stays inside one conv");
+  // group G's weights (and, for S0 == 0, the previous conv's output image) are in LDS; the ring half of group G - 1 is free
   rdb_lds_barrier();
-  rdb_stamp(a, lds, w.wave, w.lane, 2 + 2 * U);
+#pragma unroll
+  for (int u = U0; u < U0 + NU; ++u) rdb_stamp(a, lds, w.wave, w.lane, 2 + 2 * u);  // (developer stamps: a group's units open together)
   if (w.wave >= NCOMPUTE) {
-    const int lt = tid - NCOMPUTE * 64, wl = srx_uniform(lt >> 6);
-    constexpr int NEXT = U <= 10 ? U + 3 : (U == 12 ? 14 : (U >= 14 && U + 1 < NUNITS ? U + 1 : -1));  // the request this barrier frees a slot for
-    if constexpr (NEXT >= 0) dma_unit<NEXT>(a, (unsigned)(size_t)lds, lt);
-    // unit U + 1 has landed before the next barrier; what was requested after it flies on
-    if constexpr (U + 1 < NUNITS) {
-      if constexpr (U <= 10) dma_wait<2, 0>(wl);        // units U + 2, U + 3
-      else if constexpr (U == 11) dma_wait<1, 0>(wl);   // unit 13
-      else if constexpr (U == 12) dma_wait<0, 1>(wl);   // unit 14
-      else dma_wait<0, 0>(wl);
+    const int lt = tid - NCOMPUTE * 64;
+    if constexpr (G >= 1 && G + 1 < NGROUPS) {  // (groups 0 and 1 are requested before the first barrier)
+      dma_unit<grp_first(G + 1)>(a, (unsigned)(size_t)lds, lt);
+      if constexpr (grp_count(G + 1) > 1) dma_unit<grp_first(G + 1) + 1>(a, (unsigned)(size_t)lds, lt);
     }
+    // group G + 1 has landed before the next barrier (nothing else is in flight: a group is requested one group ahead)
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), expcnt / lgkmcnt untouched
   } else {
-    if (S == 0) {
+    if (S0 == 0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) w.acc[i][r] = 0.f;
     }
-    if constexpr (U == unit_first(5)) load_skip<BWD>(a, w, xs, ex);
+    if constexpr (U0 == unit_first(5)) load_skip<BWD>(a, w, xs, ex);
     f32x4 masks[2][4];
-    if constexpr (BWD && S == K && K < 5) load_masks<K>(a, w, masks);
-    mma_unit<K, S, U, ABL>(lds, w);
-    if constexpr (S == K && ABL != 3) {  // last source of stage K
+    if constexpr (BWD && SL == K && K < 5) load_masks<K>(a, w, masks);
+    mma_group<K, S0, NU, U0, ABL>(lds, w);
+    if constexpr (SL == K && ABL != 3) {  // the group ends stage K
       if constexpr (K < 5) epilogue_mid<K, BWD>(a, lds, w, masks);
       else epilogue_out<BWD>(a, lds, w, xs, ex);
     }
   }
-  rdb_stamp(a, lds, w.wave, w.lane, 3 + 2 * U);
-  if constexpr (U + 1 < NUNITS) run_units<U + 1, BWD, ABL>(a, lds, w, tid, xs, ex);
+#pragma unroll
+  for (int u = U0; u < U0 + NU; ++u) rdb_stamp(a, lds, w.wave, w.lane, 3 + 2 * u);
+  if constexpr (G + 1 < NGROUPS) run_groups<G + 1, BWD, ABL>(a, lds, w, tid, xs, ex);
 }
 
 template <bool BWD, int ABL = 0>
@@ -459,11 +481,13 @@ __global__ __launch_bounds__(NTHREADS) void rdb_kernel(const RdbArgs a) {
   w.n_img = b / a.tiles_y; w.ty0 = ty * RT; w.tx0 = tx * RT;
 
   rdb_stamp(a, lds, w.wave, w.lane, 0);
-  if (w.wave >= NCOMPUTE) {  // the first three weight units
+  if (w.wave >= NCOMPUTE) {  // the first two groups of weight units (both halves of the ring)
     const int lt = tid - NCOMPUTE * 64;
+    static_assert(grp_first(2) == 4 && grp_count(0) == 2 && grp_count(1) == 2, "groups 0 and 1 are units 0..3");
     dma_unit<0>(a, (unsigned)(size_t)lds, lt);
     dma_unit<1>(a, (unsigned)(size_t)lds, lt);
     dma_unit<2>(a, (unsigned)(size_t)lds, lt);
+    dma_unit<3>(a, (unsigned)(size_t)lds, lt);
   }
   // the input patch, rounded to bf16 once: 324 pixels x 8 groups of 8 channels; every load is issued before the first
   // conversion (out-of-image pixels read a clamped address and are zeroed afterwards)
@@ -502,10 +526,10 @@ __global__ __launch_bounds__(NTHREADS) void rdb_kernel(const RdbArgs a) {
       reinterpret_cast<float*>(lds + OFF_BIAS)[tid] = a.bias[k][tid < 128 ? (tid & 31) : tid - 128];
     }
   }
-  if (w.wave >= NCOMPUTE) dma_wait<2, 0>(srx_uniform((tid - NCOMPUTE * 64) >> 6));  // unit 0 has landed (units 1, 2 may fly on)
+  if (w.wave >= NCOMPUTE) dma_wait<2, 0>(srx_uniform((tid - NCOMPUTE * 64) >> 6));  // group 0 has landed (group 1 = units 2, 3 may fly on)
   rdb_stamp(a, lds, w.wave, w.lane, 1);
   f32x4 xs[4], ex[4];
-  run_units<0, BWD, ABL>(a, lds, w, tid, xs, ex);
+  run_groups<0, BWD, ABL>(a, lds, w, tid, xs, ex);
   if (a.dbg && w.lane < DBG_SLOTS)  // (each wave copies the stamps its own lane 0 wrote)
     a.dbg[((size_t)blockIdx.x * 8 + w.wave) * DBG_SLOTS + w.lane] = reinterpret_cast<const unsigned*>(lds + LDS_BYTES)[w.wave * DBG_SLOTS + w.lane];
 }
@@ -596,7 +620,7 @@ static int rdb_launch(RdbArgs& a, const char* what, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rdb_kernel<BWD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rdb_kernel<BWD, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  if (const int abl = srx_dev().rdb_ablate; abl >= 1 && abl <= 3 && !a.dbg) {  // developer ablations (garbage results): see mma_unit
+  if (const int abl = srx_dev().rdb_ablate; abl >= 1 && abl <= 3 && !a.dbg) {  // developer ablations (garbage results): see mma_group
     const dim3 g((unsigned)grid), b(NTHREADS);
     if (abl == 1) hipLaunchKernelGGL((rdb_kernel<BWD, 1>), g, b, LDS_BYTES, srx_stream(stream), a);
     else if (abl == 2) hipLaunchKernelGGL((rdb_kernel<BWD, 2>), g, b, LDS_BYTES, srx_stream(stream), a);
