@@ -475,7 +475,11 @@ __global__ __launch_bounds__(NTHREADS) void rdb_kernel(const RdbArgs a) {
   const int tid = threadIdx.x;
   Wave w;
   w.lane = tid & 63; w.h = w.lane >> 5; w.l31 = w.lane & 31; w.wave = srx_uniform(tid >> 6);
+  // workgroups are dealt to the eight XCDs round robin; tiles are numbered so that an XCD gets a contiguous run of them -- at
+  // batch 16 x 32 x 32 two whole images per XCD: the 5-pixel halo a tile re-reads from its neighbours (an 18 x 18 patch for 8 x 8
+  // outputs) and the shared weight stream then hit in that XCD's own L2 instead of crossing the fabric from every other one
   int b = blockIdx.x;
+  if ((gridDim.x & 7) == 0) b = (b & 7) * (int)(gridDim.x >> 3) + (b >> 3);
   const int tx = b % a.tiles_x; b /= a.tiles_x;
   const int ty = b % a.tiles_y;
   w.n_img = b / a.tiles_y; w.ty0 = ty * RT; w.tx0 = tx * RT;
