@@ -69,7 +69,10 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = srx_uniform(tid >> 6);
   const int j = wave & 1, hk = wave >> 1;
   const int i31 = lane & 31, h2 = lane >> 5;
-  const int m0 = blockIdx.x * RT;
+  // tiles are numbered so that each XCD (workgroups are dealt to the eight of them round robin) owns a contiguous run -- two whole
+  // images at 16 x 24 x 24: the rows a tile's patch shares with its neighbours then come from that XCD's own L2 (round 6)
+  const int bid = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int m0 = bid * RT;
   const int n = m0 / a.HW, p0 = m0 - n * a.HW;  // HW % 36 == 0: a tile never crosses an image
   const int r_first = p0 / a.W;
   const int r_last = (p0 + RT - 1) / a.W;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     t1 += __shfl_xor(t1, 32, 64);
     t2 += __shfl_xor(t2, 32, 64);
     tp = srx_wave_sum(tp);
-    float* row = a.bn.part + (size_t)blockIdx.x * (2 * 64 + 4);
+    float* row = a.bn.part + (size_t)bid * (2 * 64 + 4);
     if (h2 == 0) { row[col] = t1; row[64 + col] = t2; }
     if (lane == 0) row[128 + j] = tp;
   }
@@ -321,8 +324,8 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     if (h2 == 0) {
-      a.part[((size_t)blockIdx.x * 64 + col) * 2 + 0] = s1;
-      a.part[((size_t)blockIdx.x * 64 + col) * 2 + 1] = s2;
+      a.part[((size_t)bid * 64 + col) * 2 + 0] = s1;
+      a.part[((size_t)bid * 64 + col) * 2 + 1] = s2;
     }
   }
 }
