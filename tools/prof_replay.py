@@ -5,7 +5,7 @@
 The trace of `bench.py` holds set-up, warm-up, the timed hipGraph replays, the roofline leg and the other configurations; a
 `--stats` summary averages over all of them.  Here the trace is cut at every `per_step`-th launch of the marker kernel (the
 Adam tick closes an optimiser phase: two per GAN step), the MODAL launch count per cut identifies the replays of the timed
-step, and only cuts of exactly that count and the modal kernel sequence are averaged -- eager steps, the roofline leg and
+step, and only cuts of exactly that count and the modal set of kernels are averaged -- eager steps, the roofline leg and
 every other workload drop out.  Prints per kernel: launches per step, average duration, ms per step; then the span of a
 replay (first start to last end), the kernel-time sum and the "< 8 us" line.
 """
@@ -49,9 +49,10 @@ def main():
     # the timed replays: the most frequent launch count, then the most frequent name sequence of that count
     n_modal = counts.most_common(1)[0][0]
     cand = [c for c in cuts if len(c) == n_modal]
-    seqs = collections.Counter(tuple(r['Kernel_Name'] for r in c) for c in cand)
+    # (compared as multisets: a step with two graph branches starts its kernels in a slightly different order every replay)
+    seqs = collections.Counter(tuple(sorted(r['Kernel_Name'] for r in c)) for c in cand)
     seq_modal = seqs.most_common(1)[0][0]
-    steps = [c for c in cand if tuple(r['Kernel_Name'] for r in c) == seq_modal]
+    steps = [c for c in cand if tuple(sorted(r['Kernel_Name'] for r in c)) == seq_modal]
     # graph replays are back to back: drop cuts whose span is far above the median (eager steps of the same sequence)
     span = sorted(int(c[-1]['End_Timestamp']) - int(c[0]['Start_Timestamp']) for c in steps)
     med = span[len(span) // 2]
