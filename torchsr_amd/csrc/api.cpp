@@ -44,6 +44,7 @@ static SrxDevSwitches read_switches() {
   s.no_first3 = flag("SRX_NO_FIRST3");
   s.no_c64 = flag("SRX_NO_C64");
   s.no_wgrad_dma = flag("SRX_NO_WGRAD_DMA");
+  s.no_wgrad_lin = flag("SRX_NO_WGRAD_LIN");
   s.wgrad_nsplit = num("SRX_WGRAD_NSPLIT");
   s.wgrad_rows_nsplit = num("SRX_WGRAD_ROWS_NSPLIT");
   s.first3_wgs_per_cu = num("SRX_FIRST3_WGS_PER_CU");

@@ -1419,8 +1419,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WMulti mp) {
 // runs here) a thread owns ONE row of the chunk and both 32-float halves of it (same tap, same validity: the second request is the
 // first + 32 elements), and the chunk image in LDS is [half][32 rows][32 floats] -- still lane-linear for the DMA, and a wave's MFMA
 // operand is exactly one half.  Half the bookkeeping per MFMA.
-template <bool WIDE>
+// LIN (round 6, with WIDE): stride 1, output as large as the input, no PixelShuffle on dy, K and the dy columns in whole tiles of 64.
+// Then both element offsets are LINEAR in the row m -- x: (m + dh Wi + dw) Ci + kc, dy: m Cd + col -- and all that is left of the row
+// state is one bit per row: does tap (dh, dw) of pixel m fall inside the image.  The workgroup's tap is uniform (a k-tile of 64 lies
+// inside one tap), so the bits of its row split are built ONCE per workgroup -- one ballot per 64 rows -- into an LDS table of one word
+// per chunk, and a request is a bit test, two selects and three adds where it was ~40 instructions of coordinates and wrap tests
+// (every one of them matrix time: the f32 MFMA shares the vector ALUs).  Same loads in the same order: bit-identical slabs.
+constexpr int WG_MASKW = 768;  // chunks (incl. the two look-ahead requests) a LIN workgroup can index: 3 KB next to the 48 KB ring
+template <bool WIDE, bool LIN = false>
 __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WMulti mp) {
+  static_assert(!LIN || WIDE, "LIN is a form of WIDE");
   const WArgs& a = mp.a;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   int wi;
@@ -1473,6 +1481,20 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WMulti mp) {
   const int mbeg = zsplit * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
+  __shared__ unsigned okmask[LIN ? WG_MASKW : 1];
+  if constexpr (LIN) {  // bit r of word c: tap (dh, dw) of row mbeg + 32 c + r is inside the image (and the row inside the split)
+    const int nrows = (((mend - mbeg + 31) / 32 + 2) * 32 + 63) & ~63;
+    for (int base = wave * 64; base < nrows; base += 256) {
+      const int m = mbeg + base + lane;
+      int n, rem, mh, mw;
+      srx_divmod(m, a.HmWm, a.inv_HmWm, n, rem);
+      srx_divmod(rem, a.Wm, a.inv_Wm, mh, mw);
+      const bool ok = m < mend && ((unsigned)(mh + dh) < (unsigned)a.Hi) && ((unsigned)(mw + dw) < (unsigned)a.Wi);
+      const unsigned long long bits = __ballot(ok);
+      if (lane == 0) { okmask[base >> 5] = (unsigned)bits; okmask[(base >> 5) + 1] = (unsigned)(bits >> 32); }
+    }
+    __syncthreads();
+  }
   // row state of this thread's rows (r0 [+ 16 p] of the current chunk), advanced by one chunk per request
   int rm[NP], rmh[NP], rmw[NP];
   unsigned rox[NP], rod[NP];
@@ -1496,7 +1518,30 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WMulti mp) {
   // four requests per wave and chunk, always (so that the waits can be counted).  Two rows per thread: the thread's 16 bytes of row
   // r0 + 16 p land at byte 16 tid + 4096 p of the slot ([32 rows][64 floats]).  WIDE: the thread's 16 bytes of half hf of row r0 land
   // at byte 16 tid + 4096 hf ([half][32 rows][32 floats])
+  constexpr unsigned OORL = 0xfffff000u;  // (an out-of-range offset that stays out of range with the second half's 128 bytes added)
+  unsigned lin_x = 0, lin_d = 0, lin_w = 0;
+  int lin_c = 0;
+  if constexpr (LIN) {
+    lin_x = 4u * (unsigned)((mbeg + r0 + dh * a.Wi + dw) * a.Ci + kc);  // (wraps for rows whose tap lies in front of the tensor: masked)
+    lin_d = 4u * (unsigned)((mbeg + r0) * a.Cd + col);
+    lin_w = okmask[0];
+  }
+  const unsigned lin_sx = 128u * (unsigned)a.Ci, lin_sd = 128u * (unsigned)a.Cd;  // 32 rows further, in bytes
   auto request = [&](int slot) {
+    if constexpr (LIN) {
+      const bool okx = (lin_w >> r0) & 1u;
+      const bool okd = rm[0] < mend;
+      const unsigned vx = okx ? lin_x : OORL, vd = okd ? lin_d : OORL;
+      const unsigned dst = (unsigned)srx_uniform((int)((unsigned)(slot * CHUNK * 4) + (unsigned)(wave * 1024)));
+      dma(rx_, vx, ldsX + dst);
+      dma(rd_, vd, ldsD + dst);
+      dma(rx_, vx + 128u, ldsX + dst + 4096u);
+      dma(rd_, vd + 128u, ldsD + dst + 4096u);
+      rm[0] += 32; lin_x += lin_sx; lin_d += lin_sd;
+      lin_c += 1;
+      lin_w = okmask[lin_c];  // (the next request's word: back long before it is tested)
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const bool valid = rm[p] < mend;
@@ -3245,8 +3290,13 @@ static int wgrad_multi_impl(const srx_conv2d_t* d, int nprob, int per_out, const
     snprintf(nm, sizeof(nm), "wgrad_kernel<%d> MxNxK=%dx%dx%d x%d", d->precision ? 1 : 0, a.M, d->Cout, a.K, nprob);
   if (d->precision) SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<1>, grid, dim3(256), 0, st, mp);
   else if (srx_dev().no_wgrad_dma) SRX_LAUNCH_PROF(nm, wfl, wgrad_kernel<0>, grid, dim3(256), 0, st, mp);
-  else if (g.Ck % 64 == 0 && a.Cdv % 64 == 0 && (!a.dy_shuffle || a.dy_shuffle % 64 == 0))
-    SRX_LAUNCH_PROF(nm, wfl, wgrad_dma_kernel<true>, grid, dim3(256), 0, st, mp);
+  else if (g.Ck % 64 == 0 && a.Cdv % 64 == 0 && (!a.dy_shuffle || a.dy_shuffle % 64 == 0)) {
+    // LIN: offsets linear in the row, validity from a per-workgroup bit table (see wgrad_dma_kernel)
+    const bool lin = !srx_dev().no_wgrad_lin && a.in_stride == 1 && a.Hi == a.Hm && a.Wi == a.Wm && !a.dy_shuffle && a.K % 64 == 0 &&
+                     a.rows_per_split / 32 + 3 <= WG_MASKW && a.in_bytes < 0xfff00000u && a.dy_bytes < 0xfff00000u;
+    if (lin) SRX_LAUNCH_PROF(nm, wfl, (wgrad_dma_kernel<true, true>), grid, dim3(256), 0, st, mp);
+    else SRX_LAUNCH_PROF(nm, wfl, wgrad_dma_kernel<true>, grid, dim3(256), 0, st, mp);
+  }
   else SRX_LAUNCH_PROF(nm, wfl, wgrad_dma_kernel<false>, grid, dim3(256), 0, st, mp);
   SRX_CHECK_LAUNCH("wgrad_kernel");
   }

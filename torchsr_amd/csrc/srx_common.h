@@ -31,7 +31,7 @@ void srx_set_error(const char* fmt, ...);
 
 // api.cpp: developer switches, read from the environment once at load time (never on a launch path)
 struct SrxDevSwitches {
-  bool no_rt36, no_wgrad_rows, no_bn_bwd_fuse, no_bn_fwd_fuse, no_first3, no_c64, force_plan, no_wgrad_dma, no_wino, old_wgrad_reduce, wino_no_tail;
+  bool no_rt36, no_wgrad_rows, no_bn_bwd_fuse, no_bn_fwd_fuse, no_first3, no_c64, force_plan, no_wgrad_dma, no_wgrad_lin, no_wino, old_wgrad_reduce, wino_no_tail;
   int wgrad_nsplit, wgrad_rows_nsplit, first3_wgs_per_cu, thin_fwd_rows, reserved_cus, c64_ablate, rdb_ablate, wino_zsplit, wino_bn;
   int s2_mode;  // SRX_S2_MODE: strided data gradients -- bit 0: no fused-class kernel (gconv_s2f_kernel), bit 1: no two-group 64x64 tile
   int plan[4];  // SRX_FORCE_PLAN = "BM,BN,split,ks"
