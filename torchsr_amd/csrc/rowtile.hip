@@ -16,7 +16,7 @@
 //
 // The input is staged once as a zero-padded 2-D patch (image rows r-1 .. r+span, columns -1 .. W) in LDS, so
 // a tap is a constant address offset and there are no bounds checks in the loop.  Pixel stride 68 floats
-// keeps the b128 fragment reads of 16 consecutive pixels on distinct banks.
+// (and a row pitch of (W + 2) x 68 + 56) keeps the b128 fragment reads of a lane group on distinct banks, row wraps included.
 // The two channel halves are folded through LDS; bias, activation, BatchNorm partial sums and the store
 // follow the generic epilogue (gconv.hip).
 #include "srx_common.h"
@@ -30,6 +30,11 @@ constexpr int RT48 = 48;   // 32 + 4 x 4 (192 workgroups) when fewer than 256 CU
 constexpr int RT12 = 12;   // 3 x 4, no 32-pixel block: small batches (2 x 24 x 24 = 96 workgroups instead of 32; a third of the
                            // matrix time per workgroup -- the pre-training step at the reference's CPU batch size, BASELINE configs[0])
 constexpr int PSTR = 68;   // floats per patch pixel (64 channels + 4 pad)
+constexpr int RSKEW = 56;  // floats of skew per patch row (round 6): consecutive pixels are 17 sixteen-byte slots apart (= 1 mod 16: the
+                           // lane groups of a ds_read_b128 -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} -- see sixteen different slots),
+                           // but the step from an image row's last pixel to the next row's first is 3 x 17 = 3 mod 16, and the lanes
+                           // behind the wrap collided with lanes in front of it (25 % of the LDS cycles, profiles/r05_pmc_srgan.txt);
+                           // 14 more slots per patch row make that step 65 = 1 mod 16 as well
 constexpr int KTOT = 576;  // 9 taps x 64 channels
 constexpr int PF = 8;      // weight fragments in flight per wave
 constexpr int PB = 8;      // patch b128 loads per thread and batch
@@ -57,7 +62,7 @@ struct RtArgs {
   srx_rt36_bnb_t bnb;
 };
 
-// NB = batches of PB patch loads per thread (1 up to 2048 b128 slots, 2 up to the 64 KB LDS limit): a
+// NB = batches of PB patch loads per thread (1 up to 2048 b128 slots, 2 up to the 96 KB the kernel may ask for): a
 // compile-time count, so that ALL input loads and the first weight fragments are in flight together
 // and the compiler can wait on them with exact vmcnt values (a runtime loop drains the queue per trip).
 template <int NB, bool BNR = false, bool BNL = false, bool BNB = false, int RT = RT36>
@@ -88,6 +93,8 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   const unsigned quad16 = 16u * (tid & 15);
   int pr = (tid >> 4) / W2, pc = (tid >> 4) - pr * W2, sidx = tid >> 4;
   const int npix = prows * W2;
+  const int ROWP = W2 * PSTR + RSKEW;  // floats per patch row
+  int loff[NB * PB];           // LDS offset (floats) of the slot's quad
   unsigned okm = 0, ownm = 0;  // BNL / BNB: slots that hold an image pixel / one of this workgroup's own 36 pixels
   unsigned zoff[NB * PB];      // BNL / BNB: byte offset of the slot's pixel quad (input and side output have the same shape)
   f32x4 yb[(BNB || BNL) ? NB * PB : 1];  // BNB: the BatchNorm layer's forward input at the slot; BNL: the addend (or zeros)
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
     const bool ok = sidx < npix && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
     const unsigned off = (unsigned)((n * a.H + ih) * a.W + iw) * 256u + quad16;
     v[u] = srx_bload(rin, ok ? off : 0xffffffffu, 0);
+    loff[u] = pr * ROWP + pc * PSTR + 4 * (tid & 15);
     if constexpr (BNB) yb[u] = srx_bload(rby, ok ? off : 0xffffffffu, 0);
     if constexpr (BNL) yb[u] = srx_bload(rby, (ok && has_res) ? off : 0xffffffffu, 0);  // (no addend: reads 0, touches nothing)
     if constexpr (BNL || BNB) {
@@ -173,23 +181,20 @@ __global__ __launch_bounds__(256) void rt36_conv3x3_c64_kernel(const RtArgs a) {
   }
   // ---- patch -> LDS.  Surplus slots (e >= nslots) land in the slack the host adds behind the patch.
 #pragma unroll
-  for (int u = 0; u < NB * PB; ++u) {
-    const int e = u * 256 + tid;
-    *reinterpret_cast<f32x4*>(patch + (e >> 4) * PSTR + 4 * (e & 15)) = v[u];
-  }
+  for (int u = 0; u < NB * PB; ++u) *reinterpret_cast<f32x4*>(patch + loff[u]) = v[u];
   __syncthreads();
 
   // ---- per-lane patch addresses (tap (0,0) = one row up, one column left: the patch origin is (-1,-1))
   auto slot = [&](int q) {  // pixel q of the image -> patch slot of its (-1,-1) neighbour
     const int ih = q / a.W, iw = q - ih * a.W;
-    return ((ih - r_first) * W2 + iw) * PSTR;
+    return (ih - r_first) * ROWP + iw * PSTR;
   };
   const int choff = 32 * hk + 4 * h2;
   const float* a32 = patch + (MAIN ? slot(p0 + i31) : 0) + choff;
   const float* a4[XB];
 #pragma unroll
   for (int b = 0; b < XB; ++b) a4[b] = patch + slot(p0 + 32 * MAIN + 4 * b + (lane & 3)) + choff;
-  const int rowoff = W2 * PSTR;
+  const int rowoff = ROWP;
 
   // two accumulator chains: with one wave per SIMD a single dependent MFMA chain leaves issue gaps
   f32x16 acc, accb;
@@ -342,14 +347,16 @@ int patch_rows_max(int W, int RT) {  // tiles start at columns (RT t) mod W only
 int patch_batches(int W, int RT) { return (int)srx_cdiv((int64_t)patch_rows_max(W, RT) * (W + 2) * 16, 256 * PB); }
 
 size_t lds_bytes(int W, int RT) {  // every thread stores all its NB * PB slots: size for the rounded-up slot count
-  const size_t patch = (size_t)patch_batches(W, RT) * (256 * PB / 16) * PSTR * sizeof(float);
+  // (rows the rounded-up slot count reaches, each W + 2 pixels + the skew)
+  const size_t slots = (size_t)patch_batches(W, RT) * (256 * PB / 16);
+  const size_t patch = ((slots + (size_t)W + 1) / (size_t)(W + 2)) * ((size_t)(W + 2) * PSTR + RSKEW) * sizeof(float);
   const size_t fold = 2 * (size_t)(RT >= 32 ? RT - 16 : RT) * 64 * sizeof(float);
   return patch > fold ? patch : fold;
 }
 
 bool tile_fits(const srx_conv2d_t* d, int RT) {
   const int64_t hw = (int64_t)d->H * d->W;
-  return hw % RT == 0 && d->W >= 3 && patch_batches(d->W, RT) <= 2 && lds_bytes(d->W, RT) <= 80 * 1024;
+  return hw % RT == 0 && d->W >= 3 && patch_batches(d->W, RT) <= 2 && lds_bytes(d->W, RT) <= 96 * 1024;
 }
 
 // Pixels per workgroup.  36 cuts the reference batch (16 x 24 x 24) into exactly 256 workgroups, one per CU; when the plan may
@@ -404,7 +411,7 @@ int srx_rt36_run(const srx_conv2d_t* d, const float* in, const float* wpk, const
     static std::once_flag once_;                                                                                          \
     std::call_once(once_, [] {                                                                                            \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt36_conv3x3_c64_kernel<NB_, R_, L_, B_, T_>),             \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                   \
     });                                                                                                                   \
     SRX_LAUNCH_PROF(nm, fl, (rt36_conv3x3_c64_kernel<NB_, R_, L_, B_, T_>), grid, dim3(256), lds, st, a);                 \
   } while (0)
