@@ -442,6 +442,10 @@ __global__ __launch_bounds__(256) void wino_fixup_kernel(const float* __restrict
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 v[8];
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    // (bias and mask are requested with the first trip's partials, not behind the sum: round 6)
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, mk = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + (i % cq) * 4);
+    if (mask) mk = *reinterpret_cast<const f32x4*>(mask + i * 4);
     for (int z0 = 0; z0 < zsplit; z0 += 8) {  // eight partials per trip, loads first, added in order
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(part + (size_t)min(z0 + u, zsplit - 1) * stride + i * 4);
@@ -449,13 +453,12 @@ __global__ __launch_bounds__(256) void wino_fixup_kernel(const float* __restrict
       for (int u = 0; u < 8; ++u)
         if (z0 + u < zsplit) s += v[u];
     }
-    if (bias) s += *reinterpret_cast<const f32x4*>(bias + (i % cq) * 4);
+    if (bias) s += bv;
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] = fmaxf(s[e], 0.f);
     }
     if (mask) {
-      const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + i * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] = mk[e] > 0.f ? s[e] : 0.f;
     }
@@ -477,6 +480,19 @@ __global__ __launch_bounds__(512) void wino_tail_fixup_kernel(const WinoArgs a) 
   const bool tvalid = t < a.T;
   if (!tvalid && !a.stats) return;
   const float* src = a.tpart + (size_t)blockIdx.x * a.tsplit * (WT * 4 * BN) + (size_t)(et * 4) * BN + 4 * cq;
+  // the mask of the layer below and the bias do not depend on the partial sums: requested FIRST, next to the first trip's parts (a
+  // workgroup of this kernel is two or three dependent round trips long and nothing else; round 6)
+  const int tw = t % a.TW, r = t / a.TW, th = r % a.TH, n = r / a.TH;
+  const int co = cb * BN + 4 * cq;
+  const size_t p00 = (((size_t)n * a.H + 2 * th) * a.W + 2 * tw) * a.Cout + co;
+  const size_t offs[4] = {p00, p00 + a.Cout, p00 + (size_t)a.W * a.Cout, p00 + (size_t)a.W * a.Cout + a.Cout};
+  f32x4 mk[4];
+  if (a.mask && tvalid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) mk[p] = *reinterpret_cast<const f32x4*>(a.mask + offs[p]);
+  }
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + co);
   f32x4 y[4];
   f32x4 v[4][4];
   for (int z0 = 0; z0 < a.tsplit; z0 += 4) {  // four parts per trip: loads first, added in order
@@ -492,17 +508,7 @@ __global__ __launch_bounds__(512) void wino_tail_fixup_kernel(const WinoArgs a) 
         for (int p = 0; p < 4; ++p) y[p] = (z0 + u == 0) ? v[u][p] : y[p] + v[u][p];
       }
   }
-  const int tw = t % a.TW, r = t / a.TW, th = r % a.TH, n = r / a.TH;
-  const int co = cb * BN + 4 * cq;
-  const size_t p00 = (((size_t)n * a.H + 2 * th) * a.W + 2 * tw) * a.Cout + co;
-  const size_t offs[4] = {p00, p00 + a.Cout, p00 + (size_t)a.W * a.Cout, p00 + (size_t)a.W * a.Cout + a.Cout};
-  f32x4 mk[4];
-  if (a.mask && tvalid) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) mk[p] = *reinterpret_cast<const f32x4*>(a.mask + offs[p]);
-  }
   if (a.bias) {
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
     for (int p = 0; p < 4; ++p) y[p] += bv;
   }
